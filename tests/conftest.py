@@ -1,0 +1,38 @@
+"""pytest configuration: registers the ``gpu`` marker and exposes the golden vectors."""
+
+from __future__ import annotations
+
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+if str(ROOT) not in sys.path:
+    sys.path.insert(0, str(ROOT))
+
+GOLDEN = Path(__file__).resolve().parent / "golden"
+
+
+def pytest_configure(config: pytest.Config) -> None:
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def unhex(s: str) -> int:
+    return -int(s[1:], 16) if s.startswith("-") else int(s, 16)
+
+
+@pytest.fixture(scope="session")
+def golden_ref_keys() -> dict:
+    return json.loads((GOLDEN / "ref_keys.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def golden_decrypt_synth() -> dict:
+    return json.loads((GOLDEN / "decrypt_synth.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def golden_biprime() -> dict:
+    return json.loads((GOLDEN / "biprime.json").read_text())

@@ -1,0 +1,114 @@
+"""The oracle (oracle/oracle.py) against the golden vectors recorded from the reference itself.
+
+Golden vectors: tests/golden/*.json, produced by tests/golden/make_golden.py by running the
+unmodified reference modules (PSK:52-127, DK:1056-1209) in the build container.
+"""
+
+from __future__ import annotations
+
+import random
+
+import pytest
+import sympy
+
+from oracle import oracle
+from conftest import unhex
+
+
+def _decrypt_groups(*dicts):
+    for d in dicts:
+        for name, grp in d.items():
+            yield name, grp
+
+
+def test_partial_decrypt_and_combine_match_reference(golden_ref_keys, golden_decrypt_synth):
+    checked = 0
+    for name, grp in _decrypt_groups(golden_ref_keys, golden_decrypt_synth):
+        n = unhex(grp["n"])
+        degree, n_fac = grp["degree"], unhex(grp["n_fac"])
+        theta_inv = unhex(grp["theta_inv"])
+        assert oracle.mod_inv(unhex(grp["theta"]), n) == theta_inv
+        shares = {int(i): unhex(v) for i, v in grp["shares"].items()}
+        assert n_fac == oracle.n_factorial(grp["n_parties"])
+        for case in grp["cases"]:
+            c = unhex(case["c"])
+            partials = {int(i): unhex(v) for i, v in case["partials"].items()}
+            if "corrupt" not in name:
+                for i, share in shares.items():
+                    assert oracle.partial_decrypt(c, n, i, degree, n_fac, share) == partials[i], (name, i)
+            if case["error"] == "ValueError":
+                with pytest.raises(ValueError):
+                    oracle.decrypt_combine(partials, n, degree, theta_inv)
+            else:
+                assert oracle.decrypt_combine(partials, n, degree, theta_inv) == unhex(case["m"])
+            checked += 1
+    assert checked >= 80
+
+
+def test_negative_lagrange_exponent_present(golden_decrypt_synth):
+    """PSK:89-91 (negative exponent → inverse) is exercised by the vectors."""
+    grp = golden_decrypt_synth["k2048_n3_t1"]
+    exps = [
+        oracle.partial_decrypt_exponent(int(i), grp["degree"], unhex(grp["n_fac"]), unhex(s))
+        for i, s in grp["shares"].items()
+    ]
+    assert any(e < 0 for e in exps) and any(e > 0 for e in exps)
+
+
+def test_combine_missing_share_raises_keyerror(golden_decrypt_synth):
+    grp = golden_decrypt_synth["k128_n3_t1"]
+    case = grp["cases"][0]
+    partials = {int(i): unhex(v) for i, v in case["partials"].items()}
+    del partials[2]
+    with pytest.raises(KeyError):
+        oracle.decrypt_combine(partials, unhex(grp["n"]), grp["degree"], unhex(grp["theta_inv"]))
+
+
+def test_biprime_v_and_verdict_match_reference(golden_biprime):
+    for cand in golden_biprime["candidates"]:
+        modulus = unhex(cand["modulus"])
+        g_values = [unhex(g) for g in cand["g_values"]]
+        nbip = cand["correct_param_biprime"]
+        v_by_party = {}
+        for i in range(1, cand["n_parties"] + 1):
+            p_i, q_i = unhex(cand["p_parts"][i - 1]), unhex(cand["q_parts"][i - 1])
+            got = oracle.biprime_test_v_calculation(g_values, i, modulus, p_i, q_i, nbip)
+            assert got == [unhex(v) for v in cand["v"][str(i)]], (cand["label"], i)
+            v_by_party[i] = got
+        if cand["verdict"] == "KeyError":
+            with pytest.raises(KeyError):
+                oracle.biprime_test_with_v_i(v_by_party, modulus, nbip)
+        else:
+            assert oracle.biprime_test_with_v_i(v_by_party, modulus, nbip) is cand["verdict"], cand["label"]
+
+
+def test_sieve_matches_reference(golden_biprime):
+    for block in golden_biprime["sieve"]:
+        primes = oracle.small_prime_list(block["prime_threshold"])
+        assert len(primes) == block["n_primes"]
+        assert primes[:3] == block["first"] and primes[-1] == block["last"]
+        for case in block["cases"]:
+            assert oracle.small_prime_divisors_test(primes, unhex(case["modulus"])) is case["has_small_divisor"]
+
+
+def test_jacobi_matches_sympy():
+    rng = random.Random(7)
+    for bits in (8, 16, 64, 131, 1027):
+        for _ in range(60):
+            n = rng.getrandbits(bits) | 1
+            if n < 3:
+                continue
+            a = rng.randrange(0, n)
+            assert oracle.jacobi_symbol(a, n) == sympy.jacobi_symbol(a, n)
+    assert oracle.jacobi_symbol(0, 9) == 0 and oracle.jacobi_symbol(0, 1) == 1
+
+
+def test_small_prime_list_matches_sympy():
+    for thr in (1, 2, 3, 10, 200, 2000):
+        assert oracle.small_prime_list(thr) == [int(p) for p in sympy.primerange(3, thr + 1)]
+
+
+def test_mult_list():
+    assert oracle.mult_list([]) == 1
+    assert oracle.mult_list([3, -4, 5]) == -60
+    assert oracle.mult_list([3, 4, 5], 7) == 60 % 7
