@@ -1,0 +1,109 @@
+/*
+ * mxpaillier — C ABI of the MI355X (gfx950) big-integer engine for the compute hot path of
+ * TNO-MPC/protocols.distributed_keygen (distributed Paillier keygen + threshold decryption).
+ *
+ * The reference is pure Python; its arithmetic leaf is `pow_mod` / `mod_inv` of the un-vendored
+ * package tno.mpc.encryption_schemes.utils (gmpy2 -> libgmp when installed), bound by name at
+ *   src/tno/mpc/protocols/distributed_keygen/distributed_keygen.py:35   (DK)
+ *   src/tno/mpc/protocols/distributed_keygen/paillier_shared_key.py:20  (PSK)
+ * Each entry point below replaces one Python loop over those scalar calls; INTEGRATION.md shows
+ * the ctypes binding a maintainer of the reference would add.
+ *
+ * Conventions
+ *   - Big integers are little-endian arrays of `limbs` uint32 words ("rows"), element-major:
+ *     element e occupies words [e*limbs, (e+1)*limbs).  This is `int.to_bytes(4*limbs,"little")`.
+ *   - d_* pointers are DEVICE pointers (e.g. torch.Tensor.data_ptr()), h_* are HOST pointers.
+ *   - The caller owns every buffer, including the workspace; the library allocates nothing that
+ *     outlives a call.  All work is enqueued on `stream` (a hipStream_t, NULL = default stream);
+ *     calls return after enqueueing.  Host arrays (h_*) may be freed/reused on return.
+ *   - Return value: MX_OK (0) or a negative MX_ERR_* code; nothing throws across the ABI.
+ *   - Moduli must be odd and >= 3.  Supported modulus size: up to 16 700 bits.
+ *   - Bases / partials must be < their modulus (the reference guarantees this: UT:361, PSK:92);
+ *     larger values are accepted as long as they are < 2^(32*limbs) and < modulus * 2^24.
+ */
+#ifndef MXPAILLIER_H
+#define MXPAILLIER_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MX_OK 0
+#define MX_ERR_ARG (-1)          /* null pointer / non-positive size */
+#define MX_ERR_SIZE (-2)         /* modulus too large for the engine */
+#define MX_ERR_MODULUS (-3)      /* even or < 3 modulus */
+#define MX_ERR_WORKSPACE (-4)    /* workspace too small */
+#define MX_ERR_HIP (-5)          /* a HIP runtime call failed (see mx_last_hip_error) */
+
+/* ABI version (major*100 + minor). */
+int mx_version(void);
+const char* mx_error_string(int code);
+/* hipGetErrorString of the last failing HIP call made by this library in this thread. */
+const char* mx_last_hip_error(void);
+
+/* ---- modular exponentiation ------------------------------------------------------------
+ * Bytes of device workspace needed by mx_powmod_shared / mx_powmod_multi for these sizes. */
+int64_t mx_powmod_workspace_bytes(int limbs, int exp_limbs, int64_t batch, int64_t groups);
+
+/* d_out[e] = d_bases[e] ^ exp mod mod   for e in [0, batch): one modulus and one exponent for the
+ * whole batch.  Replaces the loop `[secret_key.partial_decrypt(c) for c in ciphertext_sequence]`
+ * (DK:463-466, single: DK:345-349) whose body is `pow_mod(c, exp, n_square)` (PSK:92), and any
+ * other fixed-(exponent, modulus) batch (e.g. r^N mod N^2 of Paillier encryption).
+ *   h_mod: limbs words, h_exp: exp_limbs words (exponent >= 0; a negative Lagrange exponent,
+ *   PSK:89-91, is handled by the caller inverting the base, as the reference does). */
+int mx_powmod_shared(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod,
+                     const uint32_t* h_exp, int limbs, int exp_limbs, int64_t batch,
+                     void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* d_out[g*group_size + k] = d_bases[g*group_size + k] ^ h_exps[g] mod h_mods[g].
+ * Replaces the candidate loop DK:1313-1329 over __biprime_test_v_calculation, whose body is
+ * `pow_mod(g, (N - p_i - q_i + 1) // 4, N)` (DK:1094) or `pow_mod(g, (p_i + q_i) // 4, N)`
+ * (DK:1097): group g = candidate modulus, group_size = number of Jacobi-1 bases kept (40). */
+int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods,
+                    const uint32_t* h_exps, int limbs, int exp_limbs, int64_t groups,
+                    int64_t group_size, void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- small-prime sieve -----------------------------------------------------------------
+ * d_out[e] = 1 if some h_primes[k] divides candidate e else 0.  Replaces
+ * `__small_prime_divisors_test(prime_list, n)` (DK:1197-1209) looped over the batch of
+ * candidates at DK:1288-1292.  Primes must be odd and < 2^16 ... 2^31 (any odd 31-bit value). */
+int64_t mx_sieve_workspace_bytes(int limbs, int n_primes);
+int mx_sieve(const uint32_t* d_candidates, uint8_t* d_out, const uint32_t* h_primes, int n_primes,
+             int limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- share recombination ---------------------------------------------------------------
+ * For every ciphertext e:  x = prod_{i<n_partials} d_partials[i][e] mod N^2;
+ *   d_status[e] = 1 and d_out[e] = 0           if (x - 1) % N != 0   (PSK:119-123 -> ValueError)
+ *   d_status[e] = 0 and d_out[e] = ((x - 1) / N * theta_inv) % N     (PSK:125)
+ * Replaces `PaillierSharedKey.decrypt` (PSK:95-127) looped at DK:510-515 (single: DK:378-380).
+ *   d_partials: [n_partials][batch][limbs2] words, residues mod N^2 (players 1..degree+1 in order)
+ *   h_n: limbs words (N; N^2 is derived), h_theta_inv: limbs words; limbs2 >= words of N^2
+ *   d_out: [batch][limbs] words. */
+int64_t mx_combine_workspace_bytes(int limbs, int limbs2, int n_partials, int64_t batch);
+int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* d_status, const uint32_t* h_n,
+               const uint32_t* h_theta_inv, int limbs, int limbs2, int n_partials, int64_t batch,
+               void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* ---- biprimality verdict ---------------------------------------------------------------
+ * d_pass[g*n_slots + k] = 1 iff  v_1 == +-prod_{i>=2} v_i (mod N_g) for test slot k, where
+ * d_v is [n_parties][groups][n_slots][limbs] (party index 1 first).  Replaces the per-slot test
+ * of __biprime_test_with_v_i (DK:1147-1158); the caller ANDs the slots (DK:1160-1172). */
+int64_t mx_verdict_workspace_bytes(int limbs, int n_parties, int64_t groups, int64_t n_slots);
+int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* h_mods, int limbs,
+                       int n_parties, int64_t groups, int64_t n_slots, void* d_workspace,
+                       int64_t workspace_bytes, void* stream);
+
+/* ---- diagnostics -----------------------------------------------------------------------
+ * Runs the DPP cross-lane primitives against their ds_bpermute reference forms for every group
+ * width on the current device; returns the number of mismatching lanes (0 = pass) or MX_ERR_*. */
+int mx_selftest_lanes(void* stream);
+/* Engine geometry chosen for a modulus of `mod_bits` bits: lanes per element (K), limbs per lane
+ * (L), limb width (W) and Montgomery blocks; returns MX_OK or MX_ERR_SIZE. */
+int mx_geometry(int mod_bits, int* lanes_per_element, int* limbs_per_lane, int* limb_bits, int* blocks);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MXPAILLIER_H */

@@ -1,0 +1,72 @@
+"""ctypes binding of libmxpaillier.so (include/mxpaillier.h).  No CPU fallback exists: if the
+HIP library is missing, importing this module fails loudly."""
+
+from __future__ import annotations
+
+import ctypes
+from ctypes import c_char_p, c_int, c_int64, c_void_p, POINTER
+from pathlib import Path
+
+LIB_PATH = Path(__file__).resolve().parent / "libmxpaillier.so"
+
+MX_OK = 0
+ERRORS = {-1: "MX_ERR_ARG", -2: "MX_ERR_SIZE", -3: "MX_ERR_MODULUS", -4: "MX_ERR_WORKSPACE", -5: "MX_ERR_HIP"}
+
+# name -> (restype, argtypes); every symbol include/mxpaillier.h declares
+SYMBOLS = {
+    "mx_version": (c_int, []),
+    "mx_error_string": (c_char_p, [c_int]),
+    "mx_last_hip_error": (c_char_p, []),
+    "mx_powmod_workspace_bytes": (c_int64, [c_int, c_int, c_int64, c_int64]),
+    "mx_powmod_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_sieve_workspace_bytes": (c_int64, [c_int, c_int]),
+    "mx_sieve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_combine_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int64]),
+    "mx_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_verdict_workspace_bytes": (c_int64, [c_int, c_int, c_int64, c_int64]),
+    "mx_biprime_verdict": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_selftest_lanes": (c_int, [c_void_p]),
+    "mx_geometry": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+}
+
+
+class MxError(RuntimeError):
+    """A C-ABI call returned a negative status."""
+
+    def __init__(self, code: int, where: str, detail: str = "") -> None:
+        self.code = code
+        super().__init__(f"{where}: {ERRORS.get(code, code)}{(' — ' + detail) if detail else ''}")
+
+
+def load() -> ctypes.CDLL:
+    if not LIB_PATH.exists():
+        raise ImportError(
+            f"{LIB_PATH} is missing — build it with `python -m protocols.distributed_keygen_amd.build` "
+            "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
+        )
+    lib = ctypes.CDLL(str(LIB_PATH))
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the library does not export it
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+_lib = None
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        _lib = load()
+    return _lib
+
+
+def check(code: int, where: str) -> int:
+    if code < 0:
+        detail = ""
+        if code == -5:
+            detail = lib().mx_last_hip_error().decode()
+        raise MxError(code, where, detail)
+    return code

@@ -1,0 +1,393 @@
+// extern "C" entry points of libmxpaillier.so (declared in include/mxpaillier.h).
+#include "mx_host.hpp"
+#include "mx_powmod.hpp"
+#include "mx_sieve.hpp"
+#include "mx_combine.hpp"
+#include "mx_verdict.hpp"
+#include <cstring>
+
+namespace mxh {
+thread_local hipError_t g_last_hip = hipSuccess;
+}
+using namespace mxh;
+
+namespace {
+
+// Largest modulus the engine takes: R = 2^(W*L*64) >= 16 N.
+constexpr int MAX_MOD_BITS = LIMB_BITS * LIMBS_PER_LANE * 64 - 4;
+// Sizing queries only know the row width; assume the widest modulus that fits it.
+inline int sizing_bits(int limbs) { return 32 * limbs < MAX_MOD_BITS ? 32 * limbs : MAX_MOD_BITS; }
+
+// ---- modexp ------------------------------------------------------------------------------
+struct PowmodPlan {
+  Geometry geo;
+  int win = 1;
+  int64_t nblocks = 0, nlanes = 0;
+  int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_table = 0, total = 0;
+};
+
+bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p) {
+  if (!choose_geometry(mod_bits, p.geo)) return false;
+  p.win = fixed_window(32 * exp_limbs);
+  int gpw = 64 / p.geo.K;
+  p.nblocks = (batch + gpw - 1) / gpw;
+  p.nlanes = p.nblocks * 64;
+  int64_t o = 0;
+  p.off_mods = o;  o += align256((int64_t)groups * limbs * 4);
+  p.off_rmodn = o; o += align256((int64_t)groups * limbs * 4);
+  p.off_exps = o;  o += align256((int64_t)groups * (exp_limbs + 1) * 4);
+  p.off_table = o; o += align256(((int64_t)1 << p.win) * p.geo.L * p.nlanes * 4);
+  p.total = o;
+  return true;
+}
+
+template <int K>
+int launch_powmod_k(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE, LIMB_BITS, true>;
+  size_t lds = (size_t)(64 / K) * M_t::LDS_WORDS * 4;
+  hipLaunchKernelGGL((mx::powmod_kernel<K, LIMBS_PER_LANE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods, const uint32_t* h_exps,
+                int limbs, int exp_limbs, int64_t groups, int64_t group_size, void* d_ws, int64_t ws_bytes,
+                void* stream) {
+  if (!d_bases || !d_out || !h_mods || !h_exps || !d_ws) return MX_ERR_ARG;
+  if (limbs <= 0 || exp_limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t batch = groups * group_size;
+  int max_bits = 0;
+  for (int64_t g = 0; g < groups; ++g) {
+    const u32* n = h_mods + g * limbs;
+    if (!(n[0] & 1u)) return MX_ERR_MODULUS;
+    int b = bit_length(n, limbs);
+    if (b < 2) return MX_ERR_MODULUS;
+    if (b > max_bits) max_bits = b;
+  }
+  PowmodPlan p;
+  if (!plan_powmod(max_bits, limbs, exp_limbs, batch, groups, p)) return MX_ERR_SIZE;
+  // the sizing call only knows `limbs`; it assumes the largest modulus that fits them
+  if (p.total > ws_bytes) return MX_ERR_WORKSPACE;
+  int max_ebits = 0;
+  for (int64_t g = 0; g < groups; ++g) {
+    int b = bit_length(h_exps + g * exp_limbs, exp_limbs);
+    if (b > max_ebits) max_ebits = b;
+  }
+  int ndigits = (max_ebits + p.win - 1) / p.win;
+  if (ndigits < 1) ndigits = 1;
+
+  // per-group constants: R mod N with R = 2^(W*L*nblk)
+  const int m = p.geo.W * p.geo.L * p.geo.nblk;
+  std::vector<u32> rmodn((size_t)groups * limbs);
+  for (int64_t g = 0; g < groups; ++g) two_pow_mod(rmodn.data() + g * limbs, h_mods + g * limbs, limbs, m);
+  std::vector<u32> exps((size_t)groups * (exp_limbs + 1), 0u);
+  for (int64_t g = 0; g < groups; ++g)
+    std::memcpy(exps.data() + g * (exp_limbs + 1), h_exps + g * exp_limbs, (size_t)exp_limbs * 4);
+
+  char* ws = (char*)d_ws;
+  MX_HIP(hipMemcpyAsync(ws + p.off_mods, h_mods, (size_t)groups * limbs * 4, hipMemcpyHostToDevice, s));
+  MX_HIP(hipMemcpyAsync(ws + p.off_rmodn, rmodn.data(), rmodn.size() * 4, hipMemcpyHostToDevice, s));
+  MX_HIP(hipMemcpyAsync(ws + p.off_exps, exps.data(), exps.size() * 4, hipMemcpyHostToDevice, s));
+  // the copies above read pageable host memory: HIP stages them before returning, so the
+  // vectors may go out of scope; make that explicit for the two temporaries
+  MX_HIP(hipStreamSynchronize(s));
+
+  mx::PowmodArgs a;
+  a.bases = d_bases; a.out = d_out;
+  a.mods = (const u32*)(ws + p.off_mods);
+  a.rmodn = (const u32*)(ws + p.off_rmodn);
+  a.exps = (const u32*)(ws + p.off_exps);
+  a.table = (u32*)(ws + p.off_table);
+  a.batch = batch; a.group_size = group_size;
+  a.limbs = limbs; a.elimbs = exp_limbs; a.ndigits = ndigits; a.win = p.win; a.nblk = p.geo.nblk;
+  switch (p.geo.K) {
+    case 1: return launch_powmod_k<1>(a, p.nblocks, s);
+    case 2: return launch_powmod_k<2>(a, p.nblocks, s);
+    case 4: return launch_powmod_k<4>(a, p.nblocks, s);
+    case 8: return launch_powmod_k<8>(a, p.nblocks, s);
+    case 16: return launch_powmod_k<16>(a, p.nblocks, s);
+    case 32: return launch_powmod_k<32>(a, p.nblocks, s);
+    case 64: return launch_powmod_k<64>(a, p.nblocks, s);
+  }
+  return MX_ERR_SIZE;
+}
+
+// ---- lane self-test ------------------------------------------------------------------------
+template <int K>
+__device__ int lanes_check(unsigned v) {
+  using D = mx::Lanes<K, true>;
+  using R = mx::Lanes<K, false>;
+  unsigned kn = D::keep_next_mask(), kp = D::keep_prev_mask();
+  int bad = 0;
+  bad += D::bcast0(v) != R::bcast0(v);
+  bad += D::from_next(v, kn) != R::from_next(v, kn);
+  bad += D::from_prev(v, kp) != R::from_prev(v, kp);
+  // semantic anchors independent of either implementation
+  unsigned lane = threadIdx.x & 63, pos = lane & (K - 1), base = lane - pos;
+  unsigned f = lane * 2654435761u + 12345u;   // f(lane)
+  auto F = [](unsigned l) { return l * 2654435761u + 12345u; };
+  bad += D::bcast0(f) != F(base);
+  bad += D::from_next(f, kn) != (pos == K - 1 ? 0u : F(lane + 1));
+  bad += D::from_prev(f, kp) != (pos == 0 ? 0u : F(lane - 1));
+  return bad;
+}
+
+__global__ void lanes_selftest_kernel(int* out) {
+  unsigned v = threadIdx.x * 40503u + 977u;
+  int bad = 0;
+  bad += lanes_check<1>(v);
+  bad += lanes_check<2>(v);
+  bad += lanes_check<4>(v);
+  bad += lanes_check<8>(v);
+  bad += lanes_check<16>(v);
+  bad += lanes_check<32>(v);
+  bad += lanes_check<64>(v);
+  atomicAdd(out, bad);
+}
+
+}  // namespace
+
+extern "C" {
+
+int mx_version(void) { return 100; }
+
+const char* mx_error_string(int code) {
+  switch (code) {
+    case MX_OK: return "ok";
+    case MX_ERR_ARG: return "invalid argument";
+    case MX_ERR_SIZE: return "modulus too large for the engine";
+    case MX_ERR_MODULUS: return "modulus must be odd and >= 3";
+    case MX_ERR_WORKSPACE: return "workspace too small";
+    case MX_ERR_HIP: return "HIP runtime error";
+  }
+  return "unknown error";
+}
+
+const char* mx_last_hip_error(void) { return hipGetErrorString(g_last_hip); }
+
+int mx_geometry(int mod_bits, int* k, int* l, int* w, int* blocks) {
+  Geometry g;
+  if (!choose_geometry(mod_bits, g)) return MX_ERR_SIZE;
+  if (k) *k = g.K;
+  if (l) *l = g.L;
+  if (w) *w = g.W;
+  if (blocks) *blocks = g.nblk;
+  return MX_OK;
+}
+
+int64_t mx_powmod_workspace_bytes(int limbs, int exp_limbs, int64_t batch, int64_t groups) {
+  if (limbs <= 0 || exp_limbs <= 0 || batch <= 0 || groups <= 0) return MX_ERR_ARG;
+  PowmodPlan p;
+  if (!plan_powmod(sizing_bits(limbs), limbs, exp_limbs, batch, groups, p)) return MX_ERR_SIZE;
+  return p.total;
+}
+
+int mx_powmod_shared(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
+                     int limbs, int exp_limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes,
+                     void* stream) {
+  return powmod_impl(d_bases, d_out, h_mod, h_exp, limbs, exp_limbs, 1, batch, d_workspace, workspace_bytes, stream);
+}
+
+int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods, const uint32_t* h_exps,
+                    int limbs, int exp_limbs, int64_t groups, int64_t group_size, void* d_workspace,
+                    int64_t workspace_bytes, void* stream) {
+  return powmod_impl(d_bases, d_out, h_mods, h_exps, limbs, exp_limbs, groups, group_size, d_workspace,
+                     workspace_bytes, stream);
+}
+
+int mx_selftest_lanes(void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  int* d = nullptr;
+  MX_HIP(hipMalloc(&d, sizeof(int)));
+  int h = 0;
+  hipError_t e = hipMemsetAsync(d, 0, sizeof(int), s);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(lanes_selftest_kernel, dim3(1), dim3(64), 0, s, d);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpyAsync(&h, d, sizeof(int), hipMemcpyDeviceToHost, s);
+  if (e == hipSuccess) e = hipStreamSynchronize(s);
+  hipFree(d);
+  MX_HIP(e);
+  return h;
+}
+
+}  // extern "C"
+
+// ---- sieve ---------------------------------------------------------------------------------
+namespace {
+struct SievePlan { int np_pad; int64_t off_primes, off_pw, off_inv, off_lim, total; };
+SievePlan plan_sieve(int limbs, int np) {
+  SievePlan p;
+  p.np_pad = (np + 63) / 64 * 64;
+  int64_t o = 0;
+  p.off_primes = o; o += align256((int64_t)np * 4);
+  p.off_pw = o;     o += align256((int64_t)limbs * p.np_pad * 4);
+  p.off_inv = o;    o += align256((int64_t)p.np_pad * 8);
+  p.off_lim = o;    o += align256((int64_t)p.np_pad * 8);
+  p.total = o;
+  return p;
+}
+}  // namespace
+
+extern "C" int64_t mx_sieve_workspace_bytes(int limbs, int n_primes) {
+  if (limbs <= 0 || n_primes <= 0) return MX_ERR_ARG;
+  return plan_sieve(limbs, n_primes).total;
+}
+
+extern "C" int mx_sieve(const uint32_t* d_cands, uint8_t* d_out, const uint32_t* h_primes, int n_primes, int limbs,
+                        int64_t batch, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_cands || !d_out || !h_primes || !d_ws || limbs <= 0 || n_primes <= 0 || batch <= 0) return MX_ERR_ARG;
+  if (limbs > 1024) return MX_ERR_SIZE;
+  for (int k = 0; k < n_primes; ++k)
+    if (!(h_primes[k] & 1u) || h_primes[k] < 3 || h_primes[k] >= (1u << 21)) return MX_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  SievePlan p = plan_sieve(limbs, n_primes);
+  if (p.total > ws_bytes) return MX_ERR_WORKSPACE;
+  char* ws = (char*)d_ws;
+  MX_HIP(hipMemcpyAsync(ws + p.off_primes, h_primes, (size_t)n_primes * 4, hipMemcpyHostToDevice, s));
+  mx::SieveArgs a;
+  a.cands = d_cands; a.out = d_out;
+  a.primes = (const u32*)(ws + p.off_primes);
+  a.pw = (u32*)(ws + p.off_pw);
+  a.inv = (u64*)(ws + p.off_inv);
+  a.lim = (u64*)(ws + p.off_lim);
+  a.batch = batch; a.limbs = limbs; a.np = n_primes; a.np_pad = p.np_pad;
+  hipLaunchKernelGGL(mx::sieve_setup_kernel, dim3((unsigned)(p.np_pad / 64)), dim3(64), 0, s, a);
+  MX_HIP(hipGetLastError());
+  int64_t nblocks = (batch + mx::SIEVE_C - 1) / mx::SIEVE_C;
+  size_t lds = (size_t)limbs * mx::SIEVE_C * 4;
+  hipLaunchKernelGGL(mx::sieve_kernel, dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+// ---- share recombination -------------------------------------------------------------------
+namespace {
+template <int K>
+int launch_combine_k(const mx::CombineArgs& a, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE, LIMB_BITS, true>;
+  int gpw = 64 / K;
+  int64_t nblocks = (a.batch + gpw - 1) / gpw;
+  size_t lds = (size_t)gpw * M_t::LDS_WORDS * 4;
+  hipLaunchKernelGGL((mx::combine_kernel<K, LIMBS_PER_LANE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+}  // namespace
+
+extern "C" int64_t mx_combine_workspace_bytes(int limbs, int limbs2, int n_partials, int64_t batch) {
+  if (limbs <= 0 || limbs2 < limbs || n_partials <= 0 || batch <= 0) return MX_ERR_ARG;
+  return align256((int64_t)5 * limbs2 * 4);
+}
+
+extern "C" int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* d_status, const uint32_t* h_n,
+                          const uint32_t* h_theta_inv, int limbs, int limbs2, int n_partials, int64_t batch,
+                          void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_partials || !d_out || !d_status || !h_n || !h_theta_inv || !d_ws) return MX_ERR_ARG;
+  if (limbs <= 0 || limbs2 < limbs || n_partials <= 0 || batch <= 0) return MX_ERR_ARG;
+  if (!(h_n[0] & 1u)) return MX_ERR_MODULUS;
+  int bits1 = bit_length(h_n, limbs);
+  if (bits1 < 2) return MX_ERR_MODULUS;
+  std::vector<u32> n2((size_t)2 * limbs);
+  mul_words(n2.data(), h_n, limbs, h_n, limbs);
+  int bits2 = bit_length(n2.data(), 2 * limbs);
+  if ((bits2 + 31) / 32 > limbs2) return MX_ERR_ARG;   // rows too narrow for N^2
+  Geometry g2;
+  if (!choose_geometry(bits2, g2)) return MX_ERR_SIZE;
+  Geometry g1 = g2;
+  g1.nblk = (bits1 + 4 + g1.W * g1.L - 1) / (g1.W * g1.L);
+  if (align256((int64_t)5 * limbs2 * 4) > ws_bytes) return MX_ERR_WORKSPACE;
+  // constants, each limbs2 words: N | N^2 | R1 mod N | R2 mod N^2 | theta_inv
+  std::vector<u32> c((size_t)5 * limbs2, 0u);
+  std::memcpy(&c[0], h_n, (size_t)limbs * 4);
+  std::memcpy(&c[limbs2], n2.data(), (size_t)std::min(limbs2, 2 * limbs) * 4);
+  two_pow_mod(&c[(size_t)2 * limbs2], h_n, limbs, g1.W * g1.L * g1.nblk);
+  {
+    std::vector<u32> n2p(limbs2, 0u);
+    std::memcpy(n2p.data(), n2.data(), (size_t)std::min(limbs2, 2 * limbs) * 4);
+    two_pow_mod(&c[(size_t)3 * limbs2], n2p.data(), limbs2, g2.W * g2.L * g2.nblk);
+  }
+  std::memcpy(&c[(size_t)4 * limbs2], h_theta_inv, (size_t)limbs * 4);
+  hipStream_t s = (hipStream_t)stream;
+  MX_HIP(hipMemcpyAsync(d_ws, c.data(), c.size() * 4, hipMemcpyHostToDevice, s));
+  MX_HIP(hipStreamSynchronize(s));
+  const u32* w = (const u32*)d_ws;
+  mx::CombineArgs a;
+  a.partials = d_partials; a.out = d_out; a.status = d_status;
+  a.n = w; a.n2 = w + limbs2; a.rmodn1 = w + 2 * (size_t)limbs2; a.rmodn2 = w + 3 * (size_t)limbs2;
+  a.theta_inv = w + 4 * (size_t)limbs2;
+  a.batch = batch; a.limbs = limbs; a.limbs2 = limbs2; a.np = n_partials;
+  a.nblk1 = g1.nblk; a.nblk2 = g2.nblk;
+  switch (g2.K) {
+    case 1: return launch_combine_k<1>(a, s);
+    case 2: return launch_combine_k<2>(a, s);
+    case 4: return launch_combine_k<4>(a, s);
+    case 8: return launch_combine_k<8>(a, s);
+    case 16: return launch_combine_k<16>(a, s);
+    case 32: return launch_combine_k<32>(a, s);
+    case 64: return launch_combine_k<64>(a, s);
+  }
+  return MX_ERR_SIZE;
+}
+
+// ---- biprimality verdict -------------------------------------------------------------------
+namespace {
+template <int K>
+int launch_verdict_k(const mx::VerdictArgs& a, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE, LIMB_BITS, true>;
+  int gpw = 64 / K;
+  int64_t total = a.groups * a.n_slots;
+  int64_t nblocks = (total + gpw - 1) / gpw;
+  size_t lds = (size_t)gpw * M_t::LDS_WORDS * 4;
+  hipLaunchKernelGGL((mx::verdict_kernel<K, LIMBS_PER_LANE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+}  // namespace
+
+extern "C" int64_t mx_verdict_workspace_bytes(int limbs, int n_parties, int64_t groups, int64_t n_slots) {
+  if (limbs <= 0 || n_parties <= 0 || groups <= 0 || n_slots <= 0) return MX_ERR_ARG;
+  return 2 * align256((int64_t)groups * limbs * 4);
+}
+
+extern "C" int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* h_mods, int limbs,
+                                  int n_parties, int64_t groups, int64_t n_slots, void* d_ws, int64_t ws_bytes,
+                                  void* stream) {
+  if (!d_v || !d_pass || !h_mods || !d_ws || limbs <= 0 || n_parties <= 0 || groups <= 0 || n_slots <= 0)
+    return MX_ERR_ARG;
+  int max_bits = 0;
+  for (int64_t g = 0; g < groups; ++g) {
+    const u32* n = h_mods + g * limbs;
+    if (!(n[0] & 1u)) return MX_ERR_MODULUS;
+    int b = bit_length(n, limbs);
+    if (b < 2) return MX_ERR_MODULUS;
+    if (b > max_bits) max_bits = b;
+  }
+  Geometry geo;
+  if (!choose_geometry(max_bits, geo)) return MX_ERR_SIZE;
+  int64_t part = align256((int64_t)groups * limbs * 4);
+  if (2 * part > ws_bytes) return MX_ERR_WORKSPACE;
+  std::vector<u32> rmodn((size_t)groups * limbs);
+  for (int64_t g = 0; g < groups; ++g)
+    two_pow_mod(rmodn.data() + g * limbs, h_mods + g * limbs, limbs, geo.W * geo.L * geo.nblk);
+  hipStream_t s = (hipStream_t)stream;
+  char* ws = (char*)d_ws;
+  MX_HIP(hipMemcpyAsync(ws, h_mods, (size_t)groups * limbs * 4, hipMemcpyHostToDevice, s));
+  MX_HIP(hipMemcpyAsync(ws + part, rmodn.data(), rmodn.size() * 4, hipMemcpyHostToDevice, s));
+  MX_HIP(hipStreamSynchronize(s));
+  mx::VerdictArgs a;
+  a.v = d_v; a.pass = d_pass; a.mods = (const u32*)ws; a.rmodn = (const u32*)(ws + part);
+  a.groups = groups; a.n_slots = n_slots; a.limbs = limbs; a.n_parties = n_parties; a.nblk = geo.nblk;
+  switch (geo.K) {
+    case 1: return launch_verdict_k<1>(a, s);
+    case 2: return launch_verdict_k<2>(a, s);
+    case 4: return launch_verdict_k<4>(a, s);
+    case 8: return launch_verdict_k<8>(a, s);
+    case 16: return launch_verdict_k<16>(a, s);
+    case 32: return launch_verdict_k<32>(a, s);
+    case 64: return launch_verdict_k<64>(a, s);
+  }
+  return MX_ERR_SIZE;
+}

@@ -1,0 +1,111 @@
+// Host-side helpers of the C ABI: tiny fixed-purpose big-integer routines (only what is needed
+// to prepare per-modulus constants), geometry selection, error plumbing.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <vector>
+#include <string>
+#include "../../../include/mxpaillier.h"
+
+namespace mxh {
+
+typedef uint32_t u32;
+typedef uint64_t u64;
+
+constexpr int LIMB_BITS = 29;   // W
+constexpr int LIMBS_PER_LANE = 9;   // L
+
+struct Geometry {
+  int K = 0;      // lanes per element
+  int L = LIMBS_PER_LANE;
+  int W = LIMB_BITS;
+  int nblk = 0;   // Montgomery R = 2^(W*L*nblk)
+};
+
+// R = 2^(W*L*nblk) must be >= 16 N (lazy reduction bound, mx_mont.hpp), nblk <= K.
+inline bool choose_geometry(int mod_bits, Geometry& g) {
+  if (mod_bits < 2) return false;
+  int need = mod_bits + 4;
+  int per_blk = g.W * g.L;
+  g.nblk = (need + per_blk - 1) / per_blk;
+  int k = 1;
+  while (k < g.nblk) k <<= 1;
+  if (k > 64) return false;
+  g.K = k;
+  return true;
+}
+
+inline int bit_length(const u32* x, int limbs) {
+  for (int i = limbs - 1; i >= 0; --i)
+    if (x[i]) return 32 * i + (32 - __builtin_clz(x[i]));
+  return 0;
+}
+
+inline bool geq(const std::vector<u32>& a, const u32* b, int limbs) {   // a has limbs+1 words
+  if (a[limbs]) return true;
+  for (int i = limbs - 1; i >= 0; --i) {
+    if (a[i] != b[i]) return a[i] > b[i];
+  }
+  return true;
+}
+
+// out[0..limbs) = 2^m mod n  (n odd, >= 3, m >= bit_length(n) - 1)
+inline void two_pow_mod(u32* out, const u32* n, int limbs, int m) {
+  int bits = bit_length(n, limbs);
+  std::vector<u32> x(limbs + 1, 0u);
+  x[(bits - 1) / 32] = 1u << ((bits - 1) % 32);   // 2^(bits-1) < n
+  for (int e = bits - 1; e < m; ++e) {
+    u32 carry = 0;
+    for (int i = 0; i <= limbs; ++i) {
+      u32 v = x[i];
+      x[i] = (v << 1) | carry;
+      carry = v >> 31;
+    }
+    if (geq(x, n, limbs)) {
+      u64 borrow = 0;
+      for (int i = 0; i < limbs; ++i) {
+        u64 d = (u64)x[i] - n[i] - borrow;
+        x[i] = (u32)d;
+        borrow = (d >> 63) & 1;
+      }
+      x[limbs] -= (u32)borrow;
+    }
+  }
+  for (int i = 0; i < limbs; ++i) out[i] = x[i];
+}
+
+// x*y for small host-side products (schoolbook); out has la+lb words
+inline void mul_words(u32* out, const u32* a, int la, const u32* b, int lb) {
+  for (int i = 0; i < la + lb; ++i) out[i] = 0;
+  for (int i = 0; i < la; ++i) {
+    u64 carry = 0;
+    for (int j = 0; j < lb; ++j) {
+      u64 t = (u64)a[i] * b[j] + out[i + j] + carry;
+      out[i + j] = (u32)t;
+      carry = t >> 32;
+    }
+    out[i + lb] = (u32)carry;
+  }
+}
+
+inline int fixed_window(int exp_bits) {
+  // minimise ceil(bits/w) multiplications + 2^w - 2 table products
+  int best = 1;
+  long bestc = -1;
+  for (int w = 1; w <= 7; ++w) {
+    long c = (exp_bits + w - 1) / w + (1L << w) - 2;
+    if (bestc < 0 || c < bestc) { bestc = c; best = w; }
+  }
+  return best;
+}
+
+inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
+
+extern thread_local hipError_t g_last_hip;
+inline bool hip_ok(hipError_t e) {
+  if (e != hipSuccess) { g_last_hip = e; return false; }
+  return true;
+}
+#define MX_HIP(call) do { if (!mxh::hip_ok(call)) return MX_ERR_HIP; } while (0)
+
+}  // namespace mxh

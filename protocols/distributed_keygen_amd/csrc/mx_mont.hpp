@@ -1,0 +1,292 @@
+// Lane-distributed, reduced-radix ("lazy carry") Montgomery arithmetic for gfx950.
+//
+// Number format
+//   A big integer is held by a GROUP of K consecutive lanes of one wavefront; lane p owns the
+//   L limbs [p*L, (p+1)*L) of radix 2^W (W = 29): capacity S = K*L limbs.  Operands are "almost
+//   normalised" (every limb < 2^W + 2^7); accumulators are 64-bit columns that are NOT carried
+//   while a multiplication runs.  This is what makes the inner loop one instruction per
+//   multiply-accumulate: on gfx950 v_mad_u64_u32 (32x32 + 64 -> 64) issues at the rate of a plain
+//   add, but it has no carry-in, so a radix-2^32 carry chain would cost a second instruction per
+//   MAC (profiles/r01_ubench_valu_rates.txt).  With W = 29 a column can absorb 2*L products
+//   (< 2^58 each) for L <= 18 before it is handed to the neighbouring lane, which is exactly how
+//   long a column lives in one lane — no carry handling in the loop at all.
+//
+// Montgomery multiplication (word-serial CIOS, R = 2^(W*L*nblk) >= 16 N so no conditional
+// subtraction is ever needed between operations: inputs < 2N give outputs < 2N):
+//   for every limb b_i of b (fetched from an LDS copy of b, same address for the whole group):
+//     t += a * b_i                     L  x v_mad_u64_u32 per lane
+//     q  = (t_0 * n0inv) mod 2^W       computed by the group's lane 0, broadcast by DPP
+//     t += N * q                       L  x v_mad_u64_u32 per lane
+//     t >>= W                          lane-local register renaming; one W-bit word crosses to
+//                                      the lower neighbour by DPP, the rest of column 0 is a
+//                                      local 64-bit add into column 1
+//
+// Everything in this header is device code shared by the modexp, share-combine and biprimality
+// verdict kernels.  It replaces the reference's calls into gmpy2/CPython big-int pow
+// (reference: distributed_keygen.py:1094,1097; paillier_shared_key.py:92,115-125).
+#pragma once
+#include "mx_lanes.hpp"
+
+namespace mx {
+
+typedef long long i64;
+
+template <int K, int L, int W, bool USE_DPP = true>
+struct Mont {
+  static_assert(L >= 2, "L >= 2");
+  static_assert(W >= 16 && W <= 30, "radix");
+  using LN = Lanes<K, USE_DPP>;
+  static constexpr u32 MASK = (1u << W) - 1u;
+  static constexpr int S = K * L;              // capacity in limbs
+  static constexpr int LDS_WORDS = S + 4;      // per-group scratch (32-bit words)
+
+  u32 n[L];      // modulus slice (exact W-bit limbs)
+  u32 n0inv;     // -N^-1 mod 2^W
+  u32 keep_next, keep_prev;
+  int p;         // lane position in the group
+  int nblk;      // R = 2^(W*L*nblk)
+  u32* lds;      // this group's LDS scratch, LDS_WORDS words
+
+  // ------------------------------------------------------------------ setup / conversion
+  __device__ __forceinline__ void init(u32* lds_group, int nblk_) {
+    p = LN::pos();
+    keep_next = LN::keep_next_mask();
+    keep_prev = LN::keep_prev_mask();
+    lds = lds_group;
+    nblk = nblk_;
+  }
+
+  // Cooperative copy of `nwords` 32-bit words (global memory, contiguous per element: the
+  // group reads one contiguous span, lane-consecutive) into the group's LDS scratch, zero padded.
+  __device__ __forceinline__ void stage_words(const u32* __restrict__ src, int nwords) {
+    __syncthreads();
+    for (int k = p; k < LDS_WORDS; k += K) lds[k] = (k < nwords) ? src[k] : 0u;
+    __syncthreads();
+  }
+
+  // radix-2^32 words in LDS -> this lane's L radix-2^W limbs
+  __device__ __forceinline__ void limbs_from_lds(u32 (&dst)[L]) const {
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      int bit = W * (p * L + j);
+      int w = bit >> 5, off = bit & 31;
+      u64 v = (u64)lds[w] | ((u64)lds[w + 1] << 32);
+      dst[j] = (u32)(v >> off) & MASK;
+    }
+  }
+
+  __device__ __forceinline__ void load(u32 (&dst)[L], const u32* __restrict__ src, int nwords) {
+    stage_words(src, nwords);
+    limbs_from_lds(dst);
+  }
+
+  // exact W-bit limbs (this lane's slice) -> radix-2^32 words in global memory
+  __device__ __forceinline__ void store(u32* __restrict__ dst, int nwords, const u32 (&x)[L], bool valid) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < L; ++j) lds[p * L + j] = x[j];
+    if (p == 0) { lds[S] = 0; lds[S + 1] = 0; lds[S + 2] = 0; lds[S + 3] = 0; }
+    __syncthreads();
+    for (int k = p; k < nwords; k += K) {
+      int bit = 32 * k;
+      int g = bit / W, off = bit - g * W;
+      u32 out = 0;
+      if (g < S) {
+        u64 v = (u64)lds[g] >> off;
+        v |= (u64)lds[g + 1] << (W - off);
+        if (2 * W - off < 32) v |= (u64)lds[g + 2] << (2 * W - off);
+        out = (u32)v;
+      }
+      if (valid) dst[k] = out;
+    }
+    __syncthreads();
+  }
+
+  // n[] must be loaded; computes n0inv = -N^-1 mod 2^W from the group's limb 0
+  __device__ __forceinline__ void setup_modulus() {
+    u32 n0 = LN::bcast0(n[0]);
+    u32 x = n0;                     // Newton: x <- x (2 - n0 x) doubles the correct low bits (3 -> 48)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) x *= 2u - n0 * x;
+    n0inv = (0u - x) & MASK;
+  }
+
+  // ------------------------------------------------------------------ carry handling
+  // 64-bit columns -> almost-normalised limbs (limb 1 may exceed 2^W by < 2^7).  One local carry
+  // sweep, one neighbour exchange, one two-limb fix-up; value preserved exactly.
+  __device__ __forceinline__ void normalize_weak(u32 (&r)[L], u64 (&t)[L]) const {
+    u64 c = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      u64 v = t[j] + c;
+      r[j] = (u32)v & MASK;
+      c = v >> W;
+    }
+    if constexpr (K > 1) {
+      u32 clo = LN::from_prev((u32)c, keep_prev);
+      u32 chi = LN::from_prev((u32)(c >> 32), keep_prev);
+      u64 v = (u64)r[0] + ((u64)clo | ((u64)chi << 32));
+      r[0] = (u32)v & MASK;
+      r[1] += (u32)(v >> W);
+    }
+  }
+
+  // 64-bit columns -> exact W-bit limbs; returns (in the group's top lane) the carry that left
+  // the S-limb number.  Wave-uniform loop: runs until no lane of the wave has a pending carry.
+  __device__ __forceinline__ u64 normalize_full(u32 (&r)[L], u64 (&t)[L]) const {
+    u64 c = 0, top = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      u64 v = t[j] + c;
+      r[j] = (u32)v & MASK;
+      c = v >> W;
+    }
+    while (true) {
+      if (p == K - 1) top += c;
+      u64 cin = 0;
+      if constexpr (K > 1) {
+        u32 clo = LN::from_prev((u32)c, keep_prev);
+        u32 chi = LN::from_prev((u32)(c >> 32), keep_prev);
+        cin = (u64)clo | ((u64)chi << 32);
+      }
+      if (!__any(cin != 0)) break;
+      c = cin;
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        u64 v = (u64)r[j] + c;
+        r[j] = (u32)v & MASK;
+        c = v >> W;
+      }
+    }
+    return top;
+  }
+
+  // x (exact limbs, x <= 2N-ish but < 2^(W*S)) -> x mod N for x < 2N: one conditional subtraction,
+  // done as x + (2^(W*S) - N) and a test of the carry out of the top limb.
+  __device__ __forceinline__ void cond_sub(u32 (&x)[L]) const {
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = (u64)x[j] + (u64)(MASK - n[j]);
+    if (p == 0) t[0] += 1;
+    u32 u[L];
+    u64 top = normalize_full(u, t);
+    u32 ge = LN::bcast_from((u32)(top != 0), K - 1);
+#pragma unroll
+    for (int j = 0; j < L; ++j) x[j] = ge ? u[j] : x[j];
+  }
+
+  // true (group-uniform) iff x == y limb for limb; both exact
+  __device__ __forceinline__ bool equal(const u32 (&x)[L], const u32 (&y)[L]) const {
+    u32 d = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) d |= x[j] ^ y[j];
+    return !LN::group_any(d != 0);
+  }
+  __device__ __forceinline__ bool is_zero(const u32 (&x)[L]) const {
+    u32 d = 0;
+#pragma unroll
+    for (int j = 0; j < L; ++j) d |= x[j];
+    return !LN::group_any(d != 0);
+  }
+
+  // r = x + y (lazy: result almost-normalised, value exact)
+  __device__ __forceinline__ void add(u32 (&r)[L], const u32 (&x)[L], const u32 (&y)[L]) const {
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = (u64)x[j] + (u64)y[j];
+    normalize_weak(r, t);
+  }
+
+  // ------------------------------------------------------------------ Montgomery product
+  // r = a * b / R mod N (lazy: r < 2N when a, b < 4N).  r may alias a or b.
+  // If RECORD_Q, the quotient digits q_i are kept (limb i of Q lives in the lane/slot that owns
+  // limb i) — used by the exact division in the share-combine kernel.
+  template <bool RECORD_Q = false>
+  __device__ __forceinline__ void mul(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], u32* qrec = nullptr) {
+    // stage b where every lane of the group can read any limb of it
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < L; ++j) lds[p * L + j] = b[j];
+    __syncthreads();
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = 0;
+    u32 qr[L];
+    if constexpr (RECORD_Q) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) qr[j] = 0;
+    }
+    for (int blk = 0; blk < nblk; ++blk) {
+      u32 bb[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];
+#pragma unroll
+      for (int i = 0; i < L; ++i) {
+        const u32 bi = bb[i];
+        t[0] += (u64)a[0] * bi;
+        u32 q = ((u32)t[0] * n0inv) & MASK;
+        q = LN::bcast0(q);
+        if constexpr (RECORD_Q) qr[i] = (blk == p) ? q : qr[i];
+        t[0] += (u64)n[0] * q;
+#pragma unroll
+        for (int j = 1; j < L; ++j) {
+          t[j] += (u64)a[j] * bi;
+          t[j] += (u64)n[j] * q;
+        }
+        // divide by 2^W: column 0 leaves; its low W bits belong to the lower neighbour's top
+        // column (zero for the group's lane 0 by construction of q), the rest carries into column 1
+        u64 carry = t[0] >> W;
+        u32 lo = (u32)t[0] & MASK;
+        u32 recv = LN::from_next(lo, keep_next);
+        t[0] = t[1] + carry;
+#pragma unroll
+        for (int j = 1; j < L - 1; ++j) t[j] = t[j + 1];
+        t[L - 1] = recv;
+      }
+    }
+    normalize_weak(r, t);
+    if constexpr (RECORD_Q) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) qrec[j] = qr[j];
+    }
+  }
+
+  // ------------------------------------------------------------------ constants
+  // one: the integer 1 (limb 0 of the group's lane 0)
+  __device__ __forceinline__ void set_small(u32 (&x)[L], u32 v) const {
+#pragma unroll
+    for (int j = 0; j < L; ++j) x[j] = 0;
+    if (p == 0) x[0] = v;
+  }
+
+  // Given rmodn = R mod N (Montgomery form of 1), returns R^2 mod N (Montgomery form of R),
+  // by raising 2 to the power W*L*nblk in the Montgomery domain (square-and-double).
+  __device__ __forceinline__ void compute_r2(u32 (&r2)[L], const u32 (&rmodn)[L]) {
+    const int m = W * L * nblk;
+    u32 x[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) x[j] = rmodn[j];
+    int top = 31 - __builtin_clz((unsigned)m);
+    for (int bit = top; bit >= 0; --bit) {
+      if (bit != top) mul(x, x, x);
+      if ((m >> bit) & 1) add(x, x, x);
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) r2[j] = x[j];
+  }
+
+  // lazy Montgomery-domain value -> canonical residue in [0, N), exact limbs
+  __device__ __forceinline__ void from_mont_canonical(u32 (&out)[L], const u32 (&x)[L]) {
+    u32 one[L];
+    set_small(one, 1);
+    u32 y[L];
+    mul(y, x, one);               // y = x / R mod N, y <= N
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = y[j];
+    normalize_full(out, t);
+    cond_sub(out);
+  }
+};
+
+}  // namespace mx

@@ -1,0 +1,289 @@
+"""Batched GPU operators over the C ABI (include/mxpaillier.h).
+
+Two levels:
+  * tensor level (``*_t``): operands are device-resident ``torch.int32`` tensors of limb rows
+    ``[batch, limbs]`` — what bench.py and the multi-GPU path use;
+  * int level: Python ints in / out, mirroring the reference's scalar operators
+    (``pow_mod(value, exponent, modulus)`` of tno.mpc.encryption_schemes.utils, bound at
+    distributed_keygen.py:35 and paillier_shared_key.py:20) as the batched forms
+    ``powmod_batch`` / ``powmod_batch_multi`` / ``sieve_batch`` / ``combine_batch`` /
+    ``biprime_verdict_batch``.
+
+PyTorch is used only for device memory and streams.  There is no CPU fallback: constructing an
+Engine without a GPU or without the built library raises.
+"""
+
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import numpy as np
+
+from . import _lib, limbs as _limbs
+
+
+class Engine:
+    """One engine per process/GPU.  Not re-entrant (matches the reference's single asyncio thread)."""
+
+    def __init__(self, device: Optional[int] = None) -> None:
+        import torch
+
+        if not torch.cuda.is_available():
+            raise RuntimeError("protocols.distributed_keygen_amd needs an AMD GPU (torch.cuda unavailable); no CPU fallback")
+        self.torch = torch
+        self.lib = _lib.lib()
+        idx = torch.cuda.current_device() if device is None else int(device)
+        self.device = torch.device("cuda", idx)
+        self._ws = None
+
+    # ------------------------------------------------------------------ plumbing
+    def _stream_ptr(self) -> int:
+        return int(self.torch.cuda.current_stream(self.device).cuda_stream)
+
+    def _workspace(self, nbytes: int):
+        if nbytes < 0:
+            _lib.check(int(nbytes), "workspace query")
+        if self._ws is None or self._ws.numel() < nbytes:
+            self._ws = None
+            self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+        return self._ws
+
+    def to_device(self, rows: np.ndarray):
+        """uint32 rows -> int32 device tensor (bit pattern preserved)."""
+        t = self.torch.from_numpy(np.ascontiguousarray(rows, dtype="<u4").view(np.int32))
+        return t.to(self.device, non_blocking=False)
+
+    @staticmethod
+    def to_host(t) -> np.ndarray:
+        return t.detach().cpu().numpy().view(np.uint32)
+
+    def synchronize(self) -> None:
+        self.torch.cuda.current_stream(self.device).synchronize()
+
+    def selftest_lanes(self) -> int:
+        with self.torch.cuda.device(self.device):
+            return _lib.check(self.lib.mx_selftest_lanes(self._stream_ptr()), "mx_selftest_lanes")
+
+    def geometry(self, mod_bits: int) -> Tuple[int, int, int, int]:
+        import ctypes
+
+        k, l, w, b = (ctypes.c_int() for _ in range(4))
+        _lib.check(self.lib.mx_geometry(mod_bits, k, l, w, b), "mx_geometry")
+        return k.value, l.value, w.value, b.value
+
+    # ------------------------------------------------------------------ modexp, tensor level
+    def powmod_shared_t(self, bases_t, mod: int, exp: int, out_t=None):
+        """out[e] = bases[e]^exp mod `mod`; bases_t: int32 [batch, limbs] on this device."""
+        if exp < 0:
+            raise ValueError("negative exponent: invert the base first (paillier_shared_key.py:89-91)")
+        batch, limbs = bases_t.shape
+        if _limbs.limbs_for(mod) > limbs:
+            raise ValueError("modulus wider than the limb rows")
+        elimbs = _limbs.limbs_for(exp)
+        h_mod = _limbs.pack_one(mod, limbs)
+        h_exp = _limbs.pack_one(exp, elimbs)
+        if out_t is None:
+            out_t = self.torch.empty_like(bases_t)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, 1))
+            rc = self.lib.mx_powmod_shared(
+                bases_t.data_ptr(), out_t.data_ptr(), h_mod.ctypes.data, h_exp.ctypes.data,
+                limbs, elimbs, batch, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_powmod_shared")
+        return out_t
+
+    def powmod_multi_t(self, bases_t, mods: Sequence[int], exps: Sequence[int], group_size: int, out_t=None):
+        """out[g*group_size+k] = bases[g*group_size+k]^exps[g] mod mods[g]."""
+        groups = len(mods)
+        if len(exps) != groups:
+            raise ValueError("one exponent per modulus expected")
+        if any(e < 0 for e in exps):
+            raise ValueError("negative exponent")
+        batch, limbs = bases_t.shape
+        if batch != groups * group_size:
+            raise ValueError("bases must hold groups*group_size rows")
+        if _limbs.max_bits(mods) > 32 * limbs:
+            raise ValueError("modulus wider than the limb rows")
+        elimbs = _limbs.limbs_for_bits(_limbs.max_bits(exps))
+        h_mods = _limbs.pack(mods, limbs)
+        h_exps = _limbs.pack(exps, elimbs)
+        if out_t is None:
+            out_t = self.torch.empty_like(bases_t)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, groups))
+            rc = self.lib.mx_powmod_multi(
+                bases_t.data_ptr(), out_t.data_ptr(), h_mods.ctypes.data, h_exps.ctypes.data,
+                limbs, elimbs, groups, group_size, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_powmod_multi")
+        return out_t
+
+    # ------------------------------------------------------------------ modexp, int level
+    def powmod_batch(self, bases: Sequence[int], exp: int, mod: int) -> List[int]:
+        """[pow_mod(b, exp, mod) for b in bases] on the GPU (exp >= 0)."""
+        if len(bases) == 0:
+            return []
+        _check_modulus(mod)
+        limbs = _limbs.limbs_for(mod)
+        rows = _limbs.pack([_reduce(b, mod) for b in bases], limbs)
+        out = self.powmod_shared_t(self.to_device(rows), mod, exp)
+        return _limbs.unpack(self.to_host(out))
+
+    def powmod_batch_multi(
+        self, bases: Sequence[Sequence[int]], exps: Sequence[int], mods: Sequence[int]
+    ) -> List[List[int]]:
+        """[[pow_mod(b, exps[g], mods[g]) for b in bases[g]] for g]; ragged groups are padded."""
+        groups = len(mods)
+        if groups == 0:
+            return []
+        if len(bases) != groups or len(exps) != groups:
+            raise ValueError("bases, exps and mods must have one entry per group")
+        for m in mods:
+            _check_modulus(m)
+        gsize = max(len(b) for b in bases)
+        if gsize == 0:
+            return [[] for _ in bases]
+        limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
+        flat = []
+        for b, m in zip(bases, mods):
+            flat.extend(_reduce(x, m) for x in b)
+            flat.extend([0] * (gsize - len(b)))
+        rows = _limbs.pack(flat, limbs)
+        out = self.powmod_multi_t(self.to_device(rows), list(mods), list(exps), gsize)
+        vals = _limbs.unpack(self.to_host(out))
+        return [vals[g * gsize : g * gsize + len(bases[g])] for g in range(groups)]
+
+
+    # ------------------------------------------------------------------ sieve
+    def sieve_t(self, cands_t, primes: Sequence[int], out_t=None):
+        """uint8 [batch]: 1 iff some prime divides candidate e (distributed_keygen.py:1197-1209)."""
+        batch, limbs = cands_t.shape
+        h_primes = np.ascontiguousarray(np.asarray(list(primes), dtype=np.uint32))
+        if out_t is None:
+            out_t = self.torch.empty(batch, dtype=self.torch.uint8, device=self.device)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_sieve_workspace_bytes(limbs, len(h_primes)))
+            rc = self.lib.mx_sieve(
+                cands_t.data_ptr(), out_t.data_ptr(), h_primes.ctypes.data, len(h_primes), limbs, batch,
+                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_sieve")
+        return out_t
+
+    def sieve_batch(self, candidates: Sequence[int], primes: Sequence[int]) -> List[bool]:
+        """[__small_prime_divisors_test(primes, n) for n in candidates]."""
+        if len(candidates) == 0:
+            return []
+        primes = [int(p) for p in primes]
+        if len(primes) == 0:
+            return [False] * len(candidates)
+        if any(c < 0 for c in candidates):
+            raise ValueError("candidates must be non-negative")
+        limbs = _limbs.limbs_for_bits(_limbs.max_bits(candidates))
+        out = self.sieve_t(self.to_device(_limbs.pack(candidates, limbs)), primes)
+        return [bool(x) for x in out.cpu().numpy()]
+
+    # ------------------------------------------------------------------ share recombination
+    def combine_t(self, partials_t, n: int, theta_inv: int, out_t=None, status_t=None):
+        """partials_t int32 [n_partials, batch, limbs2] (players 1..degree+1 in order) ->
+        (plaintext rows int32 [batch, limbs(N)], status uint8 [batch], 1 = not divisible by N)."""
+        n_partials, batch, limbs2 = partials_t.shape
+        _check_modulus(n)
+        limbs = _limbs.limbs_for(n)
+        if _limbs.limbs_for(n * n) > limbs2:
+            raise ValueError("partial rows narrower than N^2")
+        if not 0 <= theta_inv < n:
+            raise ValueError("theta_inv must be a residue modulo N")
+        h_n = _limbs.pack_one(n, limbs)
+        h_t = _limbs.pack_one(theta_inv, limbs)
+        if out_t is None:
+            out_t = self.torch.empty((batch, limbs), dtype=self.torch.int32, device=self.device)
+        if status_t is None:
+            status_t = self.torch.empty(batch, dtype=self.torch.uint8, device=self.device)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_combine_workspace_bytes(limbs, limbs2, n_partials, batch))
+            rc = self.lib.mx_combine(
+                partials_t.data_ptr(), out_t.data_ptr(), status_t.data_ptr(), h_n.ctypes.data, h_t.ctypes.data,
+                limbs, limbs2, n_partials, batch, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_combine")
+        return out_t, status_t
+
+    def combine_batch(
+        self, partials: Sequence[Sequence[int]], n: int, theta_inv: int
+    ) -> Tuple[List[int], List[bool]]:
+        """partials[e] = the degree+1 partial decryptions of ciphertext e (player 1 first).
+        Returns (messages, ok); ok[e] False where the reference raises ValueError (PSK:119-123)."""
+        if len(partials) == 0:
+            return [], []
+        n_partials = len(partials[0])
+        if any(len(p) != n_partials for p in partials):
+            raise ValueError("every ciphertext needs the same number of partial decryptions")
+        n2 = n * n
+        limbs2 = _limbs.limbs_for(n2)
+        rows = np.stack([_limbs.pack([_reduce(p[i], n2) for p in partials], limbs2) for i in range(n_partials)])
+        out_t, status_t = self.combine_t(self.to_device(rows), n, theta_inv)
+        ok = [not bool(x) for x in status_t.cpu().numpy()]
+        return _limbs.unpack(self.to_host(out_t)), ok
+
+    # ------------------------------------------------------------------ biprimality verdict
+    def biprime_verdict_t(self, v_t, mods: Sequence[int], pass_t=None):
+        """v_t int32 [n_parties, groups, n_slots, limbs] (party 1 first) -> uint8 [groups, n_slots]."""
+        n_parties, groups, n_slots, limbs = v_t.shape
+        if len(mods) != groups:
+            raise ValueError("one modulus per group expected")
+        h_mods = _limbs.pack(mods, limbs)
+        if pass_t is None:
+            pass_t = self.torch.empty((groups, n_slots), dtype=self.torch.uint8, device=self.device)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_verdict_workspace_bytes(limbs, n_parties, groups, n_slots))
+            rc = self.lib.mx_biprime_verdict(
+                v_t.data_ptr(), pass_t.data_ptr(), h_mods.ctypes.data, limbs, n_parties, groups, n_slots,
+                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_biprime_verdict")
+        return pass_t
+
+    def biprime_verdict_batch(self, v: Sequence[Sequence[Sequence[int]]], mods: Sequence[int]) -> List[List[bool]]:
+        """v[g][i][k]: share of party i+1 in test slot k of candidate g (all parties, equal slot counts).
+        Returns per candidate the per-slot result of `v_1 == +-prod_{i>=2} v_i (mod N)` (DK:1147-1158)."""
+        groups = len(mods)
+        if groups == 0:
+            return []
+        n_parties = len(v[0])
+        n_slots = len(v[0][0])
+        if n_slots == 0:
+            return [[] for _ in mods]
+        for m in mods:
+            _check_modulus(m)
+        limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
+        rows = np.stack(
+            [
+                _limbs.pack([_reduce(v[g][i][k], mods[g]) for g in range(groups) for k in range(n_slots)], limbs)
+                for i in range(n_parties)
+            ]
+        ).reshape(n_parties, groups, n_slots, limbs)
+        pass_t = self.biprime_verdict_t(self.to_device(rows), list(mods))
+        arr = pass_t.cpu().numpy().astype(bool)
+        return [list(map(bool, arr[g])) for g in range(groups)]
+
+
+def _check_modulus(mod: int) -> None:
+    if mod < 3 or mod % 2 == 0:
+        raise ValueError("modulus must be odd and >= 3 (Paillier moduli N and N^2 are)")
+
+
+def _reduce(value: int, mod: int) -> int:
+    value = int(value)
+    return value if 0 <= value < mod else value % mod
+
+
+_default_engine: Optional[Engine] = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine()
+    return _default_engine

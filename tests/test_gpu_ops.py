@@ -1,0 +1,130 @@
+"""GPU parity: sieve, share recombination and biprimality verdict vs the oracle / golden vectors."""
+
+from __future__ import annotations
+
+import random
+
+import pytest
+
+from conftest import unhex
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from protocols.distributed_keygen_amd import Engine
+
+    return Engine()
+
+
+# ------------------------------------------------------------------ sieve (DK:1197-1209)
+def test_sieve_golden(eng, golden_biprime):
+    for block in golden_biprime["sieve"]:
+        primes = oracle.small_prime_list(block["prime_threshold"])
+        cands = [unhex(c["modulus"]) for c in block["cases"]]
+        assert eng.sieve_batch(cands, primes) == [c["has_small_divisor"] for c in block["cases"]]
+
+
+@pytest.mark.parametrize("bits,threshold,batch", [(68, 200, 301), (1027, 2000, 1000), (2051, 2000, 777), (2051, 20000, 64), (8200, 2000, 9)])
+def test_sieve_random(eng, bits, threshold, batch):
+    rng = random.Random(bits + threshold)
+    primes = oracle.small_prime_list(threshold)
+    cands = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(batch)]
+    cands[0] = primes[-1] * (cands[0] // primes[-1])          # divisible by the largest prime only if...
+    cands[1] = 0
+    cands[2] = 1
+    cands[3] = primes[0]
+    cands[4] = 2 ** (bits - 1)
+    want = [oracle.small_prime_divisors_test(primes, c) for c in cands]
+    assert eng.sieve_batch(cands, primes) == want
+    assert 0 < sum(want) < batch
+
+
+def test_sieve_edge(eng):
+    assert eng.sieve_batch([], [3, 5]) == []
+    assert eng.sieve_batch([15, 7], []) == [False, False]
+    assert eng.sieve_batch([15, 7, 49], [3]) == [True, False, False]
+    with pytest.raises(Exception):
+        eng.sieve_batch([15], [2])
+
+
+# ------------------------------------------------------------------ share recombination (PSK:95-127)
+def test_combine_golden(eng, golden_ref_keys, golden_decrypt_synth):
+    for src in (golden_ref_keys, golden_decrypt_synth):
+        for name, grp in src.items():
+            n, theta_inv, degree = unhex(grp["n"]), unhex(grp["theta_inv"]), grp["degree"]
+            partials = [[unhex(c["partials"][str(i + 1)]) for i in range(degree + 1)] for c in grp["cases"]]
+            msgs, ok = eng.combine_batch(partials, n, theta_inv)
+            for case, m, good in zip(grp["cases"], msgs, ok):
+                if case["error"] == "ValueError":
+                    assert not good, name
+                else:
+                    assert good and m == unhex(case["m"]), name
+
+
+@pytest.mark.parametrize("key", ["k128_n3_t1", "k1024_n3_t1", "k2048_n3_t1", "k2048_n5_t2"])
+def test_combine_random_and_corrupted(eng, golden_decrypt_synth, key):
+    grp = golden_decrypt_synth[key]
+    n, theta_inv, degree, n_fac = unhex(grp["n"]), unhex(grp["theta_inv"]), grp["degree"], unhex(grp["n_fac"])
+    shares = {int(i): unhex(s) for i, s in grp["shares"].items()}
+    n2 = n * n
+    rng = random.Random(hash(key) % 1000)
+    base = [unhex(c["c"]) for c in grp["cases"]]
+    partials, want = [], []
+    for k in range(13):
+        c = base[k % len(base)] * pow(base[(k + 1) % len(base)], k, n2) % n2     # homomorphic mixes
+        ps = {i: oracle.partial_decrypt(c, n, i, degree, n_fac, shares[i]) for i in range(1, degree + 2)}
+        if k % 4 == 3:
+            ps[1 + k % (degree + 1)] = rng.randrange(n2)                          # inconsistent share
+        partials.append([ps[i] for i in range(1, degree + 2)])
+        try:
+            want.append(oracle.decrypt_combine(ps, n, degree, theta_inv))
+        except ValueError:
+            want.append(None)
+    # x == 0 and x == 1 corner cases of PSK:119-125
+    partials.append([0] + [1] * degree)
+    want.append(None)
+    partials.append([1] * (degree + 1))
+    want.append(0)
+    msgs, ok = eng.combine_batch(partials, n, theta_inv)
+    for m, good, w in zip(msgs, ok, want):
+        assert (w is None and not good) or (good and m == w)
+    assert any(w is None for w in want) and any(w is not None for w in want)
+
+
+# ------------------------------------------------------------------ biprimality verdict (DK:1110-1175)
+def test_verdict_golden(eng, golden_biprime):
+    by_limbs = {}
+    for cand in golden_biprime["candidates"]:
+        if cand["verdict"] == "KeyError":
+            continue
+        nslots = min(len(v) for v in cand["v"].values())
+        by_limbs.setdefault((unhex(cand["modulus"]).bit_length() // 40, cand["n_parties"], nslots), []).append(cand)
+    for (_, npar, nslots), cands in by_limbs.items():
+        mods = [unhex(c["modulus"]) for c in cands]
+        v = [[[unhex(x) for x in c["v"][str(i)][:nslots]] for i in range(1, npar + 1)] for c in cands]
+        got = eng.biprime_verdict_batch(v, mods)
+        for c, slots, vv, m in zip(cands, got, v, mods):
+            want_slots = []
+            for k in range(nslots):
+                prod = 1
+                for i in range(1, npar):
+                    prod *= vv[i][k]
+                want_slots.append(vv[0][k] % m == prod % m or vv[0][k] % m == (-prod) % m)
+            assert slots == want_slots, c["label"]
+            full = nslots >= c["correct_param_biprime"]
+            if c["verdict"] is True:
+                assert full and all(slots)
+            else:
+                assert not all(slots) or not full
+
+
+def test_verdict_negative_and_zero_products(eng):
+    m = (1 << 200) + 235
+    v1 = [5, m - 5, 0, 7, 1, m - 1]
+    v2 = [5, 5, 0, 8, 1, 1]
+    v3 = [1, 1, 9, 1, 1, 1]
+    got = eng.biprime_verdict_batch([[v1, v2, v3]], [m])
+    assert got == [[True, True, True, False, True, True]]

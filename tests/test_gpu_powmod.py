@@ -1,0 +1,127 @@
+"""GPU parity: batched modexp through the C ABI vs the oracle (bit-exact).
+
+Covers every lanes-per-element geometry (K = 1..64), edge operands, ragged batches, and the
+golden vectors recorded from the reference (partial decryptions PSK:92, v-values DK:1094/1097).
+"""
+
+from __future__ import annotations
+
+import random
+
+import pytest
+
+from conftest import unhex
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from protocols.distributed_keygen_amd import Engine
+
+    return Engine()
+
+
+def test_lane_primitives_selftest(eng):
+    assert eng.selftest_lanes() == 0
+
+
+@pytest.mark.parametrize(
+    "mod_bits,exp_bits,batch",
+    [
+        (20, 70, 7),        # K=1, tiny
+        (136, 200, 65),     # K=1 (N^2 of the key_length=64 fixtures)
+        (257, 300, 33),     # K=1, largest
+        (258, 300, 33),     # K=2, smallest
+        (518, 64, 9),       # K=2
+        (1028, 1026, 50),   # K=4  (biprime test, key_length 1024)
+        (1040, 100, 17),    # K=4 largest
+        (2053, 2051, 24),   # K=8  (biprime test, key_length 2048)
+        (4106, 600, 21),    # K=16 (partial decryption modulus, key_length 2048)
+        (8206, 200, 5),     # K=32 (key_length 4096)
+        (16700, 64, 3),     # K=64 largest supported
+    ],
+)
+def test_powmod_shared_random(eng, mod_bits, exp_bits, batch):
+    rng = random.Random(mod_bits * 1000 + exp_bits)
+    mod = rng.getrandbits(mod_bits) | (1 << (mod_bits - 1)) | 1
+    exp = rng.getrandbits(exp_bits) | (1 << (exp_bits - 1))
+    bases = [rng.randrange(mod) for _ in range(batch)]
+    bases[0] = 0
+    bases[1] = 1
+    bases[2] = mod - 1
+    got = eng.powmod_batch(bases, exp, mod)
+    assert got == [oracle.pow_mod(b, exp, mod) for b in bases]
+
+
+@pytest.mark.parametrize("exp", [0, 1, 2, 3, 31, 32, 33, (1 << 64) - 1, 1 << 64])
+def test_powmod_edge_exponents(eng, exp):
+    rng = random.Random(exp % 1000)
+    mod = rng.getrandbits(300) | (1 << 299) | 1
+    bases = [0, 1, 2, mod - 1, mod - 2] + [rng.randrange(mod) for _ in range(12)]
+    assert eng.powmod_batch(bases, exp, mod) == [oracle.pow_mod(b, exp, mod) for b in bases]
+
+
+def test_powmod_small_moduli(eng):
+    for mod in (3, 5, 7, 9, 255, 257, (1 << 29) - 1, (1 << 29) + 1, (1 << 32) - 1, (1 << 32) + 1, (1 << 58) + 1):
+        bases = list(range(0, min(mod, 40)))
+        assert eng.powmod_batch(bases, 12345, mod) == [oracle.pow_mod(b, 12345, mod) for b in bases], mod
+
+
+def test_powmod_unreduced_bases_are_reduced_like_pow(eng):
+    mod = (1 << 200) + 235
+    bases = [mod, mod + 1, 3 * mod + 7, -5, -mod - 2]
+    assert eng.powmod_batch(bases, 77, mod) == [pow(b, 77, mod) for b in bases]
+
+
+def test_powmod_empty_and_errors(eng):
+    assert eng.powmod_batch([], 5, 7) == []
+    with pytest.raises(ValueError):
+        eng.powmod_batch([1, 2], 5, 8)
+    with pytest.raises(ValueError):
+        eng.powmod_batch([1, 2], -5, 7)
+
+
+@pytest.mark.parametrize("mod_bits,groups,gsize", [(131, 9, 40), (1028, 6, 40), (2053, 3, 40), (300, 5, 7)])
+def test_powmod_multi_random(eng, mod_bits, groups, gsize):
+    rng = random.Random(mod_bits + groups)
+    mods = [rng.getrandbits(mod_bits - k % 3) | (1 << (mod_bits - k % 3 - 1)) | 1 for k in range(groups)]
+    exps = [rng.getrandbits(mod_bits - 2 - (k % 5)) for k in range(groups)]
+    exps[0] = 0
+    bases = [[rng.randrange(m) for _ in range(gsize if g != 1 else gsize - 3)] for g, m in enumerate(mods)]
+    got = eng.powmod_batch_multi(bases, exps, mods)
+    want = [[oracle.pow_mod(b, e, m) for b in bs] for bs, e, m in zip(bases, exps, mods)]
+    assert got == want
+
+
+def test_golden_partial_decryptions(eng, golden_decrypt_synth, golden_ref_keys):
+    """c^exp_i mod N^2 for every party of every recorded key (reference outputs, PSK:52-93)."""
+    for src in (golden_ref_keys, golden_decrypt_synth):
+        for name, grp in src.items():
+            if "corrupt" in name:
+                continue
+            n = unhex(grp["n"])
+            n2 = n * n
+            cs = [unhex(c["c"]) for c in grp["cases"]]
+            for i, share in grp["shares"].items():
+                exp = oracle.partial_decrypt_exponent(int(i), grp["degree"], unhex(grp["n_fac"]), unhex(share))
+                bases = cs if exp >= 0 else [oracle.mod_inv(c, n2) for c in cs]
+                got = eng.powmod_batch(bases, abs(exp), n2)
+                assert got == [unhex(c["partials"][i]) for c in grp["cases"]], (name, i)
+
+
+def test_golden_biprime_v_values(eng, golden_biprime):
+    """v = g^e mod N for the Jacobi-1 generators of every recorded candidate (DK:1084-1099)."""
+    by_shape = {}
+    for cand in golden_biprime["candidates"]:
+        modulus = unhex(cand["modulus"])
+        gs = [unhex(g) for g in cand["g_values"]]
+        keep = [g for g in gs if oracle.jacobi_symbol(g, modulus) == 1][: cand["correct_param_biprime"]]
+        for i in range(1, cand["n_parties"] + 1):
+            e = oracle.biprime_exponent(i, modulus, unhex(cand["p_parts"][i - 1]), unhex(cand["q_parts"][i - 1]))
+            want = [unhex(v) for v in cand["v"][str(i)]]
+            by_shape.setdefault((modulus.bit_length() // 64, i == 1), []).append((keep, e, modulus, want))
+    for items in by_shape.values():
+        got = eng.powmod_batch_multi([k for k, _, _, _ in items], [e for _, e, _, _ in items], [m for _, _, m, _ in items])
+        assert got == [w for _, _, _, w in items]
