@@ -45,6 +45,12 @@ def load() -> ctypes.CDLL:
             f"{LIB_PATH} is missing — build it with `python -m protocols.distributed_keygen_amd.build` "
             "(hipcc --offload-arch=gfx950).  There is no CPU fallback."
         )
+    # The HIP runtime must be the one PyTorch ships (torch/lib/libamdhip64.so, same SONAME as the
+    # system ROCm's): whichever is loaded first serves the whole process, and device memory and
+    # streams come from torch.  Loading this library before torch would bind both to /opt/rocm's
+    # runtime, which does not see the GPU on the test machines.
+    import torch  # noqa: F401
+
     lib = ctypes.CDLL(str(LIB_PATH))
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(lib, name)  # AttributeError if the library does not export it

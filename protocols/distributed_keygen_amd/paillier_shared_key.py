@@ -1,0 +1,187 @@
+"""Host-side mirror of the reference's ``PaillierSharedKey`` whose arithmetic runs on the GPU engine.
+
+Reference: src/tno/mpc/protocols/distributed_keygen/paillier_shared_key.py (PSK).  Same constructor
+arguments, attributes, method names, argument meaning and exceptions as PSK:25-127, plus the batched
+forms the reference's loops (distributed_keygen.py:463-466 and 510-515) are replaced with:
+
+    partial_decrypt(ciphertext)            PSK:52-93    -> partial_decrypt_batch(ciphertexts)
+    decrypt(partial_dict)                  PSK:95-127   -> decrypt_batch(partial_dicts)
+
+``share`` is anything with ``.shares[player_id]``, ``.degree`` and ``.n_fac`` (the reference's
+``IntegerShares`` of the un-vendored tno.mpc.encryption_schemes.shamir, or ``ShareView`` below);
+a ciphertext is anything with ``.get_value()`` and ``.scheme.public_key.n`` (the reference's
+``PaillierCiphertext``; when that class is importable the reference's isinstance check is applied
+verbatim).  ``engine`` is injected so the host logic is testable without a GPU; the default is the
+process-wide HIP engine, and there is no CPU arithmetic path in this module beyond the two one-off
+modular inverses the reference also does on the host side of its API (PSK:50, PSK:90).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Any, Dict, Iterable, List, Optional, Sequence
+
+try:  # the reference's ciphertext type, when its (un-vendored) package is installed
+    from tno.mpc.encryption_schemes.paillier.paillier import PaillierCiphertext as _RefCiphertext  # type: ignore
+except Exception:  # pragma: no cover - not installed in the build image
+    _RefCiphertext = None
+
+
+@dataclass
+class ShareView:
+    """The three members of the reference's IntegerShares that PSK:70-85 reads."""
+
+    shares: Dict[int, int]
+    degree: int
+    n_fac: int
+    scaling: int = 0
+
+
+def _mult_list(values: Iterable[int]) -> int:
+    """utils.py:23-38 without modulus."""
+    out = 1
+    for v in values:
+        out *= v
+    return out
+
+
+def batch_mod_inv(values: Sequence[int], modulus: int) -> List[int]:
+    """[mod_inv(v, modulus) for v in values] with ONE modular inversion (Montgomery's trick);
+    raises ValueError like ``pow(v, -1, m)`` when some value is not invertible."""
+    n = len(values)
+    if n == 0:
+        return []
+    prefix = [0] * n
+    acc = 1
+    for i, v in enumerate(values):
+        acc = acc * v % modulus
+        prefix[i] = acc
+    inv = pow(acc, -1, modulus)
+    out = [0] * n
+    for i in range(n - 1, 0, -1):
+        out[i] = inv * prefix[i - 1] % modulus
+        inv = inv * values[i] % modulus
+    out[0] = inv
+    return out
+
+
+class GpuPaillierSharedKey:
+    """Drop-in for ``PaillierSharedKey`` (PSK:25-127) with batched GPU arithmetic."""
+
+    def __init__(self, n: int, t: int, player_id: int, share: Any, theta: int, engine: Any = None) -> None:
+        self.share = share
+        self.n = n
+        self.n_square = n * n
+        self.t = t
+        self.player_id = player_id
+        self.theta = theta
+        self.theta_inv = pow(theta, -1, n)  # mod_inv(self.theta, self.n), PSK:50
+        self._engine = engine
+
+    @classmethod
+    def from_reference(cls, key: Any, engine: Any = None) -> "GpuPaillierSharedKey":
+        """Wrap an existing reference ``PaillierSharedKey`` (same n, t, player_id, share, theta)."""
+        return cls(n=key.n, t=key.t, player_id=key.player_id, share=key.share, theta=key.theta, engine=engine)
+
+    @property
+    def engine(self) -> Any:
+        if self._engine is None:
+            from .engine import default_engine
+
+            self._engine = default_engine()
+        return self._engine
+
+    # ------------------------------------------------------------------ PSK:52-93
+    def lagrange_exponent(self) -> int:
+        """PSK:70-85: n! * prod(other players) * share // prod(j - player_id); may be negative."""
+        others = [i + 1 for i in range(self.share.degree + 1) if i + 1 != self.player_id]
+        numerator = _mult_list(others)
+        denominator = _mult_list([(j - self.player_id) for j in others])
+        return (self.share.n_fac * numerator * self.share.shares[self.player_id]) // denominator
+
+    def _check_ciphertext(self, ciphertext: Any) -> None:
+        is_ct = isinstance(ciphertext, _RefCiphertext) if _RefCiphertext is not None else (
+            hasattr(ciphertext, "get_value") and hasattr(ciphertext, "scheme")
+        )
+        if not is_ct:  # PSK:62-65
+            raise TypeError(f"Expected ciphertext to be a PaillierCiphertext not: {type(ciphertext)}")
+        if self.n != ciphertext.scheme.public_key.n:  # PSK:67-68
+            raise ValueError("encrypted against a different key!")
+
+    def partial_decrypt_batch(self, ciphertexts: Iterable[Any]) -> List[int]:
+        """[self.partial_decrypt(c) for c in ciphertexts] as one GPU batch (DK:463-466)."""
+        values: List[int] = []
+        for ciphertext in ciphertexts:
+            self._check_ciphertext(ciphertext)
+            values.append(ciphertext.get_value())  # get_value(), not peek_value(): PSK:69
+        if not values:
+            return []
+        exp = self.lagrange_exponent()
+        if exp < 0:  # PSK:89-91
+            values = batch_mod_inv([v % self.n_square for v in values], self.n_square)
+            exp = -exp
+        return self.engine.powmod_batch(values, exp, self.n_square)  # PSK:92
+
+    def partial_decrypt(self, ciphertext: Any) -> int:
+        """PSK:52-93."""
+        return self.partial_decrypt_batch([ciphertext])[0]
+
+    # ------------------------------------------------------------------ PSK:95-127
+    def decrypt_batch(self, partial_dicts: Sequence[Dict[int, int]]) -> List[int]:
+        """[self.decrypt(d) for d in partial_dicts] as one GPU batch (DK:510-515).  Raises what
+        the reference's loop would raise at the first offending ciphertext."""
+        needed = self.share.degree + 1
+        rows = []
+        for d in partial_dicts:
+            rows.append([d[i + 1] for i in range(needed)])  # KeyError if a share is absent, PSK:108-110
+        if not rows:
+            return []
+        messages, ok = self.engine.combine_batch(rows, self.n, self.theta_inv)
+        if not all(ok):  # PSK:119-123
+            raise ValueError(
+                "Combined decryption minus one is not divisible by N. This might be caused by the "
+                "fact that the ciphertext that is being decrypted, differs between the parties."
+            )
+        return messages
+
+    def decrypt(self, partial_dict: Dict[int, int]) -> int:
+        """PSK:95-127."""
+        return self.decrypt_batch([partial_dict])[0]
+
+    # ------------------------------------------------------------------ PSK:186-222
+    def __eq__(self, other: object) -> bool:
+        if not hasattr(other, "share") or not hasattr(other, "theta"):
+            raise TypeError(f"Expected comparison with another PaillierSharedKey, not {type(other)}")
+        return (
+            self.share == other.share  # type: ignore[attr-defined]
+            and self.n == other.n  # type: ignore[attr-defined]
+            and self.t == other.t  # type: ignore[attr-defined]
+            and self.player_id == other.player_id  # type: ignore[attr-defined]
+            and self.theta == other.theta  # type: ignore[attr-defined]
+        )
+
+    def __str__(self) -> str:
+        return str({"priv_shared_key": {"n": self.n, "t": self.t, "player_id": self.player_id,
+                                        "theta": self.theta, "share": self.share}})
+
+
+@dataclass
+class PlainCiphertext:
+    """Minimal ciphertext carrier for callers that do not have the tno Paillier package: the raw
+    value plus the public modulus, with the reference's ``get_value`` / ``peek_value`` protocol."""
+
+    value: int
+    n: int
+    fresh: bool = True
+    scheme: Any = field(init=False, repr=False)
+
+    def __post_init__(self) -> None:
+        pk = type("PublicKey", (), {"n": self.n, "g": self.n + 1})()
+        self.scheme = type("Scheme", (), {"public_key": pk})()
+
+    def get_value(self) -> int:
+        self.fresh = False
+        return self.value
+
+    def peek_value(self) -> int:
+        return self.value

@@ -1,0 +1,53 @@
+"""Test double for protocols.distributed_keygen_amd.engine.Engine (int-level API) built on the
+oracle, so the HOST logic of the product (argument checks, ordering, error behaviour, batching,
+sharding) is testable without a GPU.  Lives in tests/ only; the product never imports it."""
+
+from __future__ import annotations
+
+from typing import List, Sequence, Tuple
+
+from oracle import oracle
+
+
+class FakeEngine:
+    def __init__(self) -> None:
+        self.calls: List[Tuple[str, int]] = []
+
+    def powmod_batch(self, bases: Sequence[int], exp: int, mod: int) -> List[int]:
+        self.calls.append(("powmod_batch", len(bases)))
+        if exp < 0:
+            raise ValueError("negative exponent")
+        return [oracle.pow_mod(b, exp, mod) for b in bases]
+
+    def powmod_batch_multi(self, bases, exps, mods):
+        self.calls.append(("powmod_batch_multi", sum(len(b) for b in bases)))
+        return [[oracle.pow_mod(b, e, m) for b in bs] for bs, e, m in zip(bases, exps, mods)]
+
+    def sieve_batch(self, candidates, primes):
+        self.calls.append(("sieve_batch", len(candidates)))
+        return [oracle.small_prime_divisors_test(primes, c) for c in candidates]
+
+    def combine_batch(self, partials, n, theta_inv):
+        self.calls.append(("combine_batch", len(partials)))
+        msgs, ok = [], []
+        for row in partials:
+            try:
+                msgs.append(oracle.decrypt_combine({i + 1: v for i, v in enumerate(row)}, n, len(row) - 1, theta_inv))
+                ok.append(True)
+            except ValueError:
+                msgs.append(0)
+                ok.append(False)
+        return msgs, ok
+
+    def biprime_verdict_batch(self, v, mods):
+        self.calls.append(("biprime_verdict_batch", len(mods)))
+        out = []
+        for vc, m in zip(v, mods):
+            row = []
+            for k in range(len(vc[0])):
+                prod = 1
+                for i in range(1, len(vc)):
+                    prod *= vc[i][k]
+                row.append(vc[0][k] % m == prod % m or vc[0][k] % m == (-prod) % m)
+            out.append(row)
+        return out

@@ -1,0 +1,212 @@
+"""CPU tests of the host layer: C-ABI exports, limb packing, and the mirrors of the reference's
+PaillierSharedKey / biprimality class-methods driven through a test double of the engine, checked
+against the golden vectors recorded from the reference."""
+
+from __future__ import annotations
+
+import random
+import re
+from pathlib import Path
+
+import numpy as np
+import pytest
+
+from conftest import unhex
+from fake_engine import FakeEngine
+from oracle import oracle
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+# ------------------------------------------------------------------ C ABI
+def test_library_builds_loads_and_exports_every_declared_symbol():
+    from protocols.distributed_keygen_amd import _lib, build
+
+    build.build()
+    lib = _lib.load()
+    header = (ROOT / "include" / "mxpaillier.h").read_text()
+    declared = set(re.findall(r"\b(mx_[a-z_0-9]+)\s*\(", header))
+    assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
+    for name in declared:
+        assert hasattr(lib, name)
+    assert lib.mx_version() >= 100
+    assert lib.mx_error_string(-3).decode().startswith("modulus")
+
+
+def test_geometry_query():
+    import ctypes
+
+    from protocols.distributed_keygen_amd import _lib
+
+    lib = _lib.lib()
+    k, l, w, b = (ctypes.c_int() for _ in range(4))
+    for bits, want_k in ((136, 1), (1028, 4), (2053, 8), (4106, 16), (8206, 32), (16700, 64)):
+        assert lib.mx_geometry(bits, k, l, w, b) == 0
+        assert (k.value, l.value, w.value) == (want_k, 9, 29)
+        assert w.value * l.value * b.value >= bits + 4 and b.value <= k.value
+    assert lib.mx_geometry(16701, k, l, w, b) == -2
+    assert lib.mx_powmod_workspace_bytes(129, 132, 10000, 1) > 0
+    assert lib.mx_powmod_workspace_bytes(0, 1, 1, 1) == -1
+
+
+def test_engine_refuses_to_run_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from protocols.distributed_keygen_amd import Engine
+
+    with pytest.raises(RuntimeError):
+        Engine()
+
+
+# ------------------------------------------------------------------ limbs
+def test_pack_unpack_roundtrip():
+    from protocols.distributed_keygen_amd import limbs
+
+    rng = random.Random(3)
+    vals = [0, 1, (1 << 32) - 1, 1 << 32, (1 << 4128) - 1] + [rng.getrandbits(4100) for _ in range(20)]
+    rows = limbs.pack(vals, 129)
+    assert rows.shape == (25, 129) and rows.dtype == np.uint32
+    assert limbs.unpack(rows) == vals
+    assert rows[3, 0] == 0 and rows[3, 1] == 1
+    with pytest.raises(ValueError):
+        limbs.pack([1 << 64], 2)
+    with pytest.raises(ValueError):
+        limbs.pack([-1], 2)
+    assert limbs.limbs_for(1) == 1 and limbs.limbs_for((1 << 32)) == 2 and limbs.limbs_for(0) == 1
+
+
+def test_batch_mod_inv():
+    from protocols.distributed_keygen_amd.paillier_shared_key import batch_mod_inv
+
+    rng = random.Random(5)
+    m = (rng.getrandbits(300) | 1) * (rng.getrandbits(300) | 1)
+    vals = [rng.randrange(1, m) for _ in range(50)]
+    vals = [v for v in vals if oracle.jacobi_symbol(1, 3) and __import__("math").gcd(v, m) == 1]
+    assert batch_mod_inv(vals, m) == [pow(v, -1, m) for v in vals]
+    assert batch_mod_inv([], m) == [] and batch_mod_inv([vals[0]], m) == [pow(vals[0], -1, m)]
+    with pytest.raises(ValueError):
+        batch_mod_inv([vals[0], 0, vals[1]], m)
+
+
+# ------------------------------------------------------------------ PaillierSharedKey mirror
+def _keys(grp, engine):
+    from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, ShareView
+
+    n = unhex(grp["n"])
+    return {
+        int(i): GpuPaillierSharedKey(
+            n=n, t=grp["t"], player_id=int(i),
+            share=ShareView({int(i): unhex(s)}, grp["degree"], unhex(grp["n_fac"])),
+            theta=unhex(grp["theta"]), engine=engine,
+        )
+        for i, s in grp["shares"].items()
+    }
+
+
+def test_shared_key_mirror_matches_reference_outputs(golden_ref_keys, golden_decrypt_synth):
+    from protocols.distributed_keygen_amd.paillier_shared_key import PlainCiphertext
+
+    eng = FakeEngine()
+    for src in (golden_ref_keys, golden_decrypt_synth):
+        for name, grp in src.items():
+            keys = _keys(grp, eng)
+            n = unhex(grp["n"])
+            assert keys[1].theta_inv == unhex(grp["theta_inv"]) and keys[1].n_square == n * n
+            cts = [PlainCiphertext(unhex(c["c"]), n) for c in grp["cases"]]
+            if "corrupt" not in name:
+                for i, key in keys.items():
+                    got = key.partial_decrypt_batch(cts)
+                    assert got == [unhex(c["partials"][str(i)]) for c in grp["cases"]], (name, i)
+                    assert key.partial_decrypt(cts[0]) == got[0]
+                assert all(not c.fresh for c in cts)          # get_value() was used (PSK:69)
+            dicts = [{int(i): unhex(v) for i, v in c["partials"].items()} for c in grp["cases"]]
+            if any(c["error"] for c in grp["cases"]):
+                with pytest.raises(ValueError, match="not divisible by N"):
+                    keys[1].decrypt_batch(dicts)
+            else:
+                assert keys[1].decrypt_batch(dicts) == [unhex(c["m"]) for c in grp["cases"]]
+                assert keys[1].decrypt(dicts[0]) == unhex(grp["cases"][0]["m"])
+    # one launch per batch, not one per ciphertext
+    assert all(count >= 1 for _, count in eng.calls)
+
+
+def test_shared_key_mirror_error_behaviour(golden_decrypt_synth):
+    from protocols.distributed_keygen_amd.paillier_shared_key import PlainCiphertext
+
+    grp = golden_decrypt_synth["k128_n3_t1"]
+    keys = _keys(grp, FakeEngine())
+    n = unhex(grp["n"])
+    with pytest.raises(TypeError):                      # PSK:62-65
+        keys[1].partial_decrypt(12345)
+    with pytest.raises(ValueError, match="different key"):   # PSK:67-68
+        keys[1].partial_decrypt(PlainCiphertext(5, n + 2))
+    d = {int(i): unhex(v) for i, v in grp["cases"][0]["partials"].items()}
+    del d[3]
+    with pytest.raises(KeyError):                       # PSK:108-110
+        keys[1].decrypt(d)
+    assert keys[1].partial_decrypt_batch([]) == [] and keys[1].decrypt_batch([]) == []
+    assert keys[1] == keys[1]
+    with pytest.raises(TypeError):
+        keys[1] == 5  # noqa: B015
+
+
+# ------------------------------------------------------------------ keygen mirrors
+def test_jacobi_mirror_matches_oracle():
+    from protocols.distributed_keygen_amd.biprime import jacobi_symbol
+
+    rng = random.Random(11)
+    for bits in (3, 8, 64, 131, 2051):
+        for _ in range(80):
+            n = rng.getrandbits(bits) | 1
+            a = rng.randrange(-5, 3 * n)
+            assert jacobi_symbol(a, n) == oracle.jacobi_symbol(a, n)
+    with pytest.raises(ValueError):
+        jacobi_symbol(3, 8)
+
+
+def test_biprime_mirrors_match_reference_outputs(golden_biprime):
+    from protocols.distributed_keygen_amd import biprime
+
+    eng = FakeEngine()
+    cands = golden_biprime["candidates"]
+    for npar in (3, 5):
+        sel = [c for c in cands if c["n_parties"] == npar]
+        mods = [unhex(c["modulus"]) for c in sel]
+        gs = [[unhex(g) for g in c["g_values"]] for c in sel]
+        nbips = {c["correct_param_biprime"] for c in sel}
+        for nbip in nbips:
+            idx = [k for k, c in enumerate(sel) if c["correct_param_biprime"] == nbip]
+            v_all = [dict() for _ in idx]
+            for i in range(1, npar + 1):
+                got = biprime.biprime_test_v_calculation_batch(
+                    [gs[k] for k in idx], i, [mods[k] for k in idx],
+                    [unhex(sel[k]["p_parts"][i - 1]) for k in idx], [unhex(sel[k]["q_parts"][i - 1]) for k in idx],
+                    nbip, engine=eng,
+                )
+                assert got == [[unhex(x) for x in sel[k]["v"][str(i)]] for k in idx]
+                for slot, g in zip(v_all, got):
+                    slot[i] = g
+            for k, vd in zip(idx, v_all):
+                want = sel[k]["verdict"]
+                if want == "KeyError":
+                    with pytest.raises(KeyError):
+                        biprime.biprime_test_with_v_i(vd, mods[k], nbip, engine=eng)
+                else:
+                    assert biprime.biprime_test_with_v_i(vd, mods[k], nbip, engine=eng) is want, sel[k]["label"]
+            ok = [k for k in idx if sel[k]["verdict"] != "KeyError"]
+            got = biprime.biprime_test_with_v_i_batch([v_all[idx.index(k)] for k in ok], [mods[k] for k in ok], nbip, engine=eng)
+            assert got == [sel[k]["verdict"] for k in ok]
+
+
+def test_sieve_mirror(golden_biprime):
+    from protocols.distributed_keygen_amd import biprime
+
+    eng = FakeEngine()
+    for block in golden_biprime["sieve"]:
+        primes = oracle.small_prime_list(block["prime_threshold"])
+        mods = [unhex(c["modulus"]) for c in block["cases"]]
+        assert biprime.small_prime_divisors_test_batch(primes, mods, engine=eng) == [c["has_small_divisor"] for c in block["cases"]]
+    assert biprime.small_prime_divisors_test_batch([], [15], engine=eng) == [False]
+    assert biprime.small_prime_divisors_test([3, 5], 35, engine=eng) is True
