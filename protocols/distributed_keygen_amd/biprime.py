@@ -114,8 +114,11 @@ def biprime_test_with_v_i_batch(
     moduli: Sequence[int],
     correct_param_biprime: int,
     engine: Any = None,
-) -> List[bool]:
+    errors: str = "raise",
+) -> List[Any]:
     """Verdict per candidate; ``v_by_party[c][i]`` is the v list of party i for candidate c.
+    With ``errors="return"`` a candidate whose test would raise gets the exception object in its
+    place (a caller that stops at the first passing candidate, DK:1339-1360, never reaches it).
 
     Reference semantics: slots are tested in order, False at the first failing slot
     (DK:1160-1164), True after correct_param_biprime passing slots (DK:1168-1172); reaching a
@@ -133,23 +136,29 @@ def biprime_test_with_v_i_batch(
     if nslots == 0:
         if correct_param_biprime == 0:
             return [False] * len(moduli)
-        raise KeyError(order[0])
+        if errors == "raise":
+            raise KeyError(order[0])
+        return [KeyError(order[0]) for _ in moduli]
     # pad short candidates with zeros: their missing slots are never consulted unless reached
     v = [[[int(x) for x in vc[i][:nslots]] + [0] * (nslots - min(nslots, len(vc[i]))) for i in order] for vc in v_by_party]
     slot_pass = _engine(engine).biprime_verdict_batch(v, list(moduli))
     out: List[bool] = []
     for c, passes in enumerate(slot_pass):
-        verdict = None
+        verdict: Any = None
         for k in range(correct_param_biprime):
             if k >= avail[c]:
-                raise KeyError(order[0])  # reference: AdditiveVariable.get_share on an unset slot
+                # reference: AdditiveVariable.get_share on an unset slot
+                if errors == "raise":
+                    raise KeyError(order[0])
+                verdict = KeyError(order[0])
+                break
             if not passes[k]:
                 verdict = False
                 break
             if k + 1 >= correct_param_biprime:
                 verdict = True
                 break
-        out.append(bool(verdict))
+        out.append(verdict if isinstance(verdict, Exception) else bool(verdict))
     return out
 
 

@@ -26,8 +26,10 @@ struct PowmodPlan {
   int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_table = 0, total = 0;
 };
 
-bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p) {
-  if (!choose_geometry(mod_bits, p.geo)) return false;
+bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p,
+                 int limbs_per_lane = 0) {
+  if (limbs_per_lane == 0) limbs_per_lane = pick_limbs_per_lane(mod_bits, batch);
+  if (!choose_geometry(mod_bits, p.geo, limbs_per_lane)) return false;
   p.win = fixed_window(32 * exp_limbs);
   int gpw = 64 / p.geo.K;
   p.nblocks = (batch + gpw - 1) / gpw;
@@ -41,13 +43,19 @@ bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t 
   return true;
 }
 
-template <int K>
-int launch_powmod_k(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
-  using M_t = mx::Mont<K, LIMBS_PER_LANE, LIMB_BITS, true>;
+template <int K, int L>
+int launch_powmod_kl(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
+  using M_t = mx::Mont<K, L, LIMB_BITS, true>;
   size_t lds = (size_t)(64 / K) * M_t::LDS_WORDS * 4;
-  hipLaunchKernelGGL((mx::powmod_kernel<K, LIMBS_PER_LANE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  hipLaunchKernelGGL((mx::powmod_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
+}
+
+template <int K>
+int launch_powmod_k(const mx::PowmodArgs& a, int64_t nblocks, int limbs_per_lane, hipStream_t s) {
+  if (limbs_per_lane == LIMBS_PER_LANE_WIDE) return launch_powmod_kl<K, LIMBS_PER_LANE_WIDE>(a, nblocks, s);
+  return launch_powmod_kl<K, LIMBS_PER_LANE>(a, nblocks, s);
 }
 
 int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods, const uint32_t* h_exps,
@@ -102,13 +110,13 @@ int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods
   a.batch = batch; a.group_size = group_size;
   a.limbs = limbs; a.elimbs = exp_limbs; a.ndigits = ndigits; a.win = p.win; a.nblk = p.geo.nblk;
   switch (p.geo.K) {
-    case 1: return launch_powmod_k<1>(a, p.nblocks, s);
-    case 2: return launch_powmod_k<2>(a, p.nblocks, s);
-    case 4: return launch_powmod_k<4>(a, p.nblocks, s);
-    case 8: return launch_powmod_k<8>(a, p.nblocks, s);
-    case 16: return launch_powmod_k<16>(a, p.nblocks, s);
-    case 32: return launch_powmod_k<32>(a, p.nblocks, s);
-    case 64: return launch_powmod_k<64>(a, p.nblocks, s);
+    case 1: return launch_powmod_k<1>(a, p.nblocks, p.geo.L, s);
+    case 2: return launch_powmod_k<2>(a, p.nblocks, p.geo.L, s);
+    case 4: return launch_powmod_k<4>(a, p.nblocks, p.geo.L, s);
+    case 8: return launch_powmod_k<8>(a, p.nblocks, p.geo.L, s);
+    case 16: return launch_powmod_k<16>(a, p.nblocks, p.geo.L, s);
+    case 32: return launch_powmod_k<32>(a, p.nblocks, p.geo.L, s);
+    case 64: return launch_powmod_k<64>(a, p.nblocks, p.geo.L, s);
   }
   return MX_ERR_SIZE;
 }
@@ -178,8 +186,10 @@ int mx_geometry(int mod_bits, int* k, int* l, int* w, int* blocks) {
 
 int64_t mx_powmod_workspace_bytes(int limbs, int exp_limbs, int64_t batch, int64_t groups) {
   if (limbs <= 0 || exp_limbs <= 0 || batch <= 0 || groups <= 0) return MX_ERR_ARG;
-  PowmodPlan p;
-  if (!plan_powmod(sizing_bits(limbs), limbs, exp_limbs, batch, groups, p)) return MX_ERR_SIZE;
+  PowmodPlan p, q;
+  if (!plan_powmod(sizing_bits(limbs), limbs, exp_limbs, batch, groups, p, LIMBS_PER_LANE)) return MX_ERR_SIZE;
+  if (plan_powmod(sizing_bits(limbs), limbs, exp_limbs, batch, groups, q, LIMBS_PER_LANE_WIDE) && q.total > p.total)
+    return q.total;
   return p.total;
 }
 

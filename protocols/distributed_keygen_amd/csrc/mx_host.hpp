@@ -5,6 +5,7 @@
 #include <stdint.h>
 #include <vector>
 #include <string>
+#include <cstdlib>
 #include "../../../include/mxpaillier.h"
 
 namespace mxh {
@@ -13,7 +14,8 @@ typedef uint32_t u32;
 typedef uint64_t u64;
 
 constexpr int LIMB_BITS = 29;   // W
-constexpr int LIMBS_PER_LANE = 9;   // L
+constexpr int LIMBS_PER_LANE = 9;   // L of the narrow geometry (more lanes per element)
+constexpr int LIMBS_PER_LANE_WIDE = 18;   // L of the wide geometry (fewer, busier lanes)
 
 struct Geometry {
   int K = 0;      // lanes per element
@@ -23,8 +25,9 @@ struct Geometry {
 };
 
 // R = 2^(W*L*nblk) must be >= 16 N (lazy reduction bound, mx_mont.hpp), nblk <= K.
-inline bool choose_geometry(int mod_bits, Geometry& g) {
+inline bool choose_geometry(int mod_bits, Geometry& g, int limbs_per_lane = LIMBS_PER_LANE) {
   if (mod_bits < 2) return false;
+  g.L = limbs_per_lane;
   int need = mod_bits + 4;
   int per_blk = g.W * g.L;
   g.nblk = (need + per_blk - 1) / per_blk;
@@ -97,6 +100,21 @@ inline int fixed_window(int exp_bits) {
     if (bestc < 0 || c < bestc) { bestc = c; best = w; }
   }
   return best;
+}
+
+// Which limbs-per-lane to run a modexp batch with.  The wide geometry spends a larger share of its
+// instructions on multiply-accumulates (the per-limb bookkeeping is amortised over 2L MACs) but
+// puts half as many lanes on the machine; it pays once the batch still fills every SIMD with
+// at least two wavefronts (1024 SIMDs x 64 lanes).  MX_LIMBS_PER_LANE=9|18 overrides.
+inline int pick_limbs_per_lane(int mod_bits, int64_t batch) {
+  if (const char* e = getenv("MX_LIMBS_PER_LANE")) {
+    int v = atoi(e);
+    if (v == LIMBS_PER_LANE || v == LIMBS_PER_LANE_WIDE) return v;
+  }
+  Geometry wide;
+  if (!choose_geometry(mod_bits, wide, LIMBS_PER_LANE_WIDE)) return LIMBS_PER_LANE;
+  int64_t waves = (batch * wide.K + 63) / 64;
+  return waves >= 2 * 1024 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
 }
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }

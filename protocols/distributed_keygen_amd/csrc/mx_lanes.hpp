@@ -53,14 +53,16 @@ struct Lanes {
     } else if constexpr (!USE_DPP) {
       return (u32)__shfl((int)x, 0, K);
     } else if constexpr (K == 2) {
-      return dpp_mov<DPP_QUAD_0022, 0xF, 0xF, false>(x, x);
+      return dpp_mov<DPP_QUAD_0022, 0xF, 0xF, true>(0, x);
     } else if constexpr (K == 4) {
-      return dpp_mov<DPP_QUAD_0000, 0xF, 0xF, false>(x, x);
+      return dpp_mov<DPP_QUAD_0000, 0xF, 0xF, true>(0, x);
     } else if constexpr (K == 8) {
-      u32 t = dpp_mov<DPP_QUAD_0000, 0xF, 0xF, false>(x, x);
-      return dpp_mov<DPP_ROW_SHR4, 0xF, 0xA, false>(t, t);  // banks 1,3 (lanes 4-7, 12-15) <- banks 0,2
+      // lanes 4 and 12 first fetch lanes 0 and 8 (banks 1,3 <- banks 0,2), then every quad takes
+      // its lane 0; the second move has full masks so it folds into the consumer
+      u32 t = dpp_mov<DPP_ROW_SHR4, 0xF, 0xA, false>(x, x);
+      return dpp_mov<DPP_QUAD_0000, 0xF, 0xF, true>(0, t);
     } else if constexpr (K == 16) {
-      return dpp_mov<DPP_ROW_NEWBCAST0, 0xF, 0xF, false>(x, x);
+      return dpp_mov<DPP_ROW_NEWBCAST0, 0xF, 0xF, true>(0, x);   // full masks + bound_ctrl: foldable into the consumer
     } else if constexpr (K == 32) {
       u32 t = dpp_mov<DPP_ROW_NEWBCAST0, 0xF, 0xF, false>(x, x);
       return dpp_mov<DPP_ROW_BCAST15, 0xA, 0xF, false>(t, t);  // rows 1,3 <- lane 15 of rows 0,2
@@ -87,6 +89,22 @@ struct Lanes {
       return dpp_mov<DPP_ROW_SHL1, 0xF, 0xF, true>(0, x) & keep_next;
     } else if constexpr (K == 32) {
       return dpp_mov<DPP_WAVE_SHL1, 0xF, 0xF, true>(0, x) & keep_next;
+    } else {
+      return dpp_mov<DPP_WAVE_SHL1, 0xF, 0xF, true>(0, x);
+    }
+  }
+
+  // from_next without the boundary mask: the caller ANDs with a per-lane VGPR mask that already
+  // contains keep_next (so that the AND and the DPP move become one v_and_b32_dpp)
+  static __device__ __forceinline__ u32 from_next_raw(u32 x) {
+    if constexpr (K == 1) {
+      return 0;
+    } else if constexpr (!USE_DPP) {
+      return (u32)__shfl_down((int)x, 1, K);
+    } else if constexpr (K == 2) {
+      return dpp_mov<DPP_QUAD_1133, 0xF, 0xF, true>(0, x);
+    } else if constexpr (K <= 16) {
+      return dpp_mov<DPP_ROW_SHL1, 0xF, 0xF, true>(0, x);
     } else {
       return dpp_mov<DPP_WAVE_SHL1, 0xF, 0xF, true>(0, x);
     }

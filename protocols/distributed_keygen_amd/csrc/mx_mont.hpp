@@ -43,6 +43,8 @@ struct Mont {
   u32 n[L];      // modulus slice (exact W-bit limbs)
   u32 n0inv;     // -N^-1 mod 2^W
   u32 keep_next, keep_prev;
+  u32 maskv;     // MASK held in a VGPR (a DPP-modified VOP2 cannot take a literal operand)
+  u32 next_mask; // keep_next & MASK
   int p;         // lane position in the group
   int nblk;      // R = 2^(W*L*nblk)
   u32* lds;      // this group's LDS scratch, LDS_WORDS words
@@ -52,6 +54,9 @@ struct Mont {
     p = LN::pos();
     keep_next = LN::keep_next_mask();
     keep_prev = LN::keep_prev_mask();
+    maskv = MASK;
+    asm volatile("" : "+v"(maskv));   // opaque: keeps the constant in a VGPR
+    next_mask = keep_next & maskv;
     lds = lds_group;
     nblk = nblk_;
   }
@@ -224,8 +229,8 @@ struct Mont {
       for (int i = 0; i < L; ++i) {
         const u32 bi = bb[i];
         t[0] += (u64)a[0] * bi;
-        u32 q = ((u32)t[0] * n0inv) & MASK;
-        q = LN::bcast0(q);
+        // the mask is applied after the broadcast so that it folds into the DPP move (v_and_b32_dpp)
+        const u32 q = LN::bcast0((u32)t[0] * n0inv) & maskv;
         if constexpr (RECORD_Q) qr[i] = (blk == p) ? q : qr[i];
         t[0] += (u64)n[0] * q;
 #pragma unroll
@@ -236,8 +241,7 @@ struct Mont {
         // divide by 2^W: column 0 leaves; its low W bits belong to the lower neighbour's top
         // column (zero for the group's lane 0 by construction of q), the rest carries into column 1
         u64 carry = t[0] >> W;
-        u32 lo = (u32)t[0] & MASK;
-        u32 recv = LN::from_next(lo, keep_next);
+        const u32 recv = LN::from_next_raw((u32)t[0]) & next_mask;
         t[0] = t[1] + carry;
 #pragma unroll
         for (int j = 1; j < L - 1; ++j) t[j] = t[j + 1];

@@ -1,0 +1,109 @@
+"""world_size-2 gloo tests of the sharding layer (protocols/distributed_keygen_amd/dist.py) on CPU
+tensors with a test double of the engine: slices, padding of ragged batches, the single all-gather,
+and that every rank ends with the full, correctly ordered result."""
+
+from __future__ import annotations
+
+import os
+import random
+import socket
+import sys
+from pathlib import Path
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = Path(__file__).resolve().parent.parent
+
+
+def _free_port() -> int:
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank: int, world: int, port: int, ret) -> None:
+    sys.path.insert(0, str(ROOT))
+    sys.path.insert(0, str(ROOT / "tests"))
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from fake_tensor_engine import FakeTensorEngine, _ints, _rows
+        from oracle import oracle
+        from protocols.distributed_keygen_amd import dist as mxdist, limbs as L
+
+        eng = FakeTensorEngine()
+        rng = random.Random(99)            # same inputs on every rank (replicated control)
+        # --- shared-modulus modexp, ragged batch (7 rows over 2 ranks)
+        mod = rng.getrandbits(200) | (1 << 199) | 1
+        exp = rng.getrandbits(190)
+        bases = [rng.randrange(mod) for _ in range(7)]
+        got = mxdist.sharded_powmod_shared(eng, _rows(bases, L.limbs_for(mod)), mod, exp)
+        assert _ints(got) == [pow(b, exp, mod) for b in bases]
+        # --- per-candidate modexp, 3 candidates x 5 bases over 2 ranks
+        mods = [rng.getrandbits(131) | (1 << 130) | 1 for _ in range(3)]
+        exps = [rng.getrandbits(129) for _ in mods]
+        flat = [rng.randrange(m) for m in mods for _ in range(5)]
+        got = mxdist.sharded_powmod_multi(eng, _rows(flat, 5), mods, exps, 5)
+        assert _ints(got) == [pow(b, exps[k // 5], mods[k // 5]) for k, b in enumerate(flat)]
+        # --- sieve verdict bytes
+        primes = oracle.small_prime_list(200)
+        cands = [rng.getrandbits(68) | 1 for _ in range(9)]
+        got = mxdist.sharded_sieve(eng, _rows(cands, 3), primes)
+        assert [bool(x) for x in got.tolist()] == [oracle.small_prime_divisors_test(primes, c) for c in cands]
+        # --- recombination over a ragged batch, with one inconsistent ciphertext
+        from protocols.distributed_keygen_amd import synthetic
+
+        key = synthetic.make_key(64, 3, 1, kappa=20)
+        r2 = random.Random(5)
+        msgs = [3, 1, 4, 1, 5]
+        cts = [synthetic.encrypt(key, m, r2) for m in msgs]
+        parts = [[oracle.partial_decrypt(c, key.n, i, key.degree, key.n_fac, key.shares[i]) for c in cts] for i in (1, 2, 3)]
+        parts[1][3] = (parts[1][3] + 1) % key.n_square
+        limbs2 = L.limbs_for(key.n_square)
+        pt = torch.stack([_rows(p, limbs2) for p in parts])
+        m_t, st = mxdist.sharded_combine(eng, pt, key.n, key.theta_inv)
+        assert st.tolist() == [0, 0, 0, 1, 0]
+        assert [m for m, s in zip(_ints(m_t), st.tolist()) if not s] == [3, 1, 4, 5]
+        # --- biprimality vote
+        m0 = (1 << 100) + 277
+        v = torch.stack([_rows([5, 6, 7, 9, 2, 4], 4), _rows([5, m0 - 6, 8, 9, 2, 4], 4), _rows([1] * 6, 4)]).reshape(3, 3, 2, 4)
+        votes = mxdist.sharded_biprime_vote(eng, v, [m0, m0, m0])
+        assert votes.tolist() == [[1, 1], [0, 1], [1, 1]]
+        assert mxdist.shard_bounds(7, 0, 2) == (0, 4) and mxdist.shard_bounds(7, 1, 2) == (4, 7)
+        ret[rank] = "ok"
+    except Exception as exc:  # surfaced by the parent
+        import traceback
+
+        ret[rank] = "FAIL: " + "".join(traceback.format_exception(type(exc), exc, exc.__traceback__))[-1500:]
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sharded_ops_world2_gloo():
+    world = 2
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        ret = mgr.dict()
+        port = _free_port()
+        procs = [ctx.Process(target=_worker, args=(r, world, port, ret)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(240)
+        assert all(not p.is_alive() for p in procs), "gloo workers hung"
+        assert dict(ret) == {0: "ok", 1: "ok"}, dict(ret)
+
+
+def test_single_process_falls_through():
+    sys.path.insert(0, str(ROOT / "tests"))
+    from fake_tensor_engine import FakeTensorEngine, _ints, _rows
+    from protocols.distributed_keygen_amd import dist as mxdist
+
+    got = mxdist.sharded_powmod_shared(FakeTensorEngine(), _rows([2, 3, 4], 2), 1000003, 5)
+    assert _ints(got) == [32, 243, 1024]

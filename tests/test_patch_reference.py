@@ -1,0 +1,178 @@
+"""Drop-in check against the REAL reference modules (build container only: needs /root/reference).
+
+The unmodified reference ``paillier_shared_key.py`` / ``distributed_keygen.py`` are imported with
+stand-ins for their un-vendored dependencies (the recipe of tests/golden/make_golden.py), three
+in-process parties are wired through an in-memory pool, and the reference's own
+``_decrypt_sequence_raw`` coroutine is run before and after ``patch.install()``: same plaintexts,
+but one modexp launch and one recombination launch per party instead of one per ciphertext.
+A test double of the engine is injected, so this runs without a GPU.
+"""
+
+from __future__ import annotations
+
+import asyncio
+import random
+import sys
+from pathlib import Path
+
+import pytest
+
+REF = Path("/root/reference/src/tno/mpc/protocols/distributed_keygen")
+pytestmark = pytest.mark.skipif(not REF.exists(), reason="reference sources only exist in the build container")
+
+sys.path.insert(0, str(Path(__file__).resolve().parent / "golden"))
+
+
+class Hub:
+    def __init__(self, names):
+        self.names = names
+        self.box = {n: {} for n in names}
+        self.events = {n: {} for n in names}
+
+    def pool(self, me):
+        return FakePool(self, me)
+
+
+class FakePool:
+    """The three calls of tno.mpc.communication.Pool the decrypt path uses (DK:356-375, 476-497)."""
+
+    def __init__(self, hub, me):
+        self.hub, self.me = hub, me
+        self.pool_handlers = {n: None for n in hub.names if n != me}
+
+    def async_broadcast(self, message, msg_id=None, handler_names=None):
+        for n in (handler_names if handler_names is not None else self.pool_handlers):
+            self.hub.box[n].setdefault(msg_id, []).append((self.me, message))
+
+    async def recv_all(self, msg_id=None):
+        while len(self.hub.box[self.me].get(msg_id, [])) < len(self.pool_handlers):
+            await asyncio.sleep(0)
+        return tuple(self.hub.box[self.me].pop(msg_id))
+
+
+@pytest.fixture(scope="module")
+def ref():
+    import make_golden
+
+    psk, dk = make_golden.load_reference()
+    return psk, dk, make_golden
+
+
+def _parties(ref, engine_key):
+    psk, dk, mg = ref
+    shamir = sys.modules["tno.mpc.encryption_schemes.shamir"]
+    key = mg.synth_key(random.Random(77), 128, 3, 1)
+    names = ["p1", "p2", "p3"]
+    hub = Hub(names)
+    out = []
+    for i, me in enumerate(names, start=1):
+        share = shamir.IntegerShares(shamir._Scheme(3), {i: key["shares"][i]}, key["degree"], key["n_fac"] ** 2)
+        dp = object.__new__(dk.DistributedPaillier)
+        dp.secret_key = psk.PaillierSharedKey(n=key["n"], t=1, player_id=i, share=share, theta=key["theta"])
+        dp.pool = hub.pool(me)
+        dp.index = i
+        dp.party_indices = {("self" if n == me else n): k for k, n in enumerate(names, start=1)}
+        dp.session_id = 4242
+        out.append(dp)
+    return key, out
+
+
+def _ciphertexts(ref, key, msgs):
+    _, _, mg = ref
+    pail = sys.modules["tno.mpc.encryption_schemes.paillier"]
+    rng = random.Random(3)
+    scheme = pail._PKScheme(key["n"])
+    return [pail.PaillierCiphertext(mg.encrypt(rng, m, key["n"]), scheme) for m in msgs]
+
+
+def test_decrypt_sequence_is_drop_in_and_batched(ref):
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import patch
+
+    msgs = [0, 1, 7, 123456789, 2**100 + 5]
+    key, parties = _parties(ref, None)
+    cts = _ciphertexts(ref, key, msgs)
+
+    async def run():
+        return await asyncio.gather(*[dp._decrypt_sequence_raw(list(cts)) for dp in parties])
+
+    base = asyncio.run(run())
+    assert [[e.value for e in r] for r in base] == [msgs] * 3      # the reference alone
+
+    eng = FakeEngine()
+    patch.install(engine=eng)
+    try:
+        key, parties = _parties(ref, None)
+        got = asyncio.run(run())
+        assert [[e.value for e in r] for r in got] == [msgs] * 3
+        assert all(type(e.value) is int for r in got for e in r)
+        # per party: one modexp batch of 5 and one recombination batch of 5
+        assert sorted(eng.calls) == sorted([("powmod_batch", 5), ("combine_batch", 5)] * 3)
+        # single-ciphertext path (DK:314-382) still works through the patched scalar methods
+        eng.calls.clear()
+
+        async def one():
+            return await asyncio.gather(*[dp._decrypt_raw(cts[3]) for dp in parties])
+
+        assert [e.value for e in asyncio.run(one())] == [msgs[3]] * 3
+        # receivers: only p1 ("self" for party 1) receives; others return None (DK:341-343, 516)
+        async def recv():
+            return await asyncio.gather(
+                parties[0]._decrypt_sequence_raw(list(cts), ["self"]),
+                parties[1]._decrypt_sequence_raw(list(cts), ["p1"]),
+                parties[2]._decrypt_sequence_raw(list(cts), ["p1"]),
+            )
+
+        r = asyncio.run(recv())
+        assert [e.value for e in r[0]] == msgs and r[1] is None and r[2] is None
+        # a party holding a wrong share -> inconsistent partials -> ValueError like PSK:119-123
+        # (same ciphertexts everywhere, so the message ids of DK:469-475 still match)
+        parties[1].secret_key.share.shares[2] += 1
+        parties[1].secret_key._mx_gpu_key = None
+
+        async def bad():
+            return await asyncio.gather(*[dp._decrypt_sequence_raw(list(cts)) for dp in parties], return_exceptions=True)
+
+        assert all(isinstance(x, ValueError) for x in asyncio.run(bad()))
+    finally:
+        patch.uninstall()
+    key, parties = _parties(ref, None)
+    assert [[e.value for e in r] for r in asyncio.run(run())] == [msgs] * 3   # originals restored
+
+
+def test_patched_keygen_classmethods_match_originals(ref, golden_biprime):
+    from conftest import unhex
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import patch
+
+    _, dk, _ = ref
+    DP = dk.DistributedPaillier
+    names = ["small_prime_divisors_test", "biprime_test_v_calculation", "biprime_test_with_v_i"]
+    orig = {n: getattr(DP, "_DistributedPaillier__" + n) for n in names}
+    cand = next(c for c in golden_biprime["candidates"] if c["label"] == "k128_n3_biprime0")
+    comp = next(c for c in golden_biprime["candidates"] if c["label"] == "k128_n3_composite2")
+    patch.install(engine=FakeEngine())
+    try:
+        new = {n: getattr(DP, "_DistributedPaillier__" + n) for n in names}
+        primes = [3, 5, 7, 11, 13]
+        for m in (15, 77, 221, 10403):
+            assert new["small_prime_divisors_test"](primes, m) == orig["small_prime_divisors_test"](primes, m)
+        for c in (cand, comp):
+            modulus = unhex(c["modulus"])
+            gs = [unhex(g) for g in c["g_values"]]
+            pi = {f"party{i}": i for i in (1, 2, 3)}
+            b_new = dk.Batched(dk.AdditiveVariable(label="v", modulus=modulus), batch_size=40)
+            b_old = dk.Batched(dk.AdditiveVariable(label="v", modulus=modulus), batch_size=40)
+            for i in (1, 2, 3):
+                p_i, q_i = unhex(c["p_parts"][i - 1]), unhex(c["q_parts"][i - 1])
+                a = new["biprime_test_v_calculation"](gs, i, modulus, p_i, q_i, 40)
+                b = orig["biprime_test_v_calculation"](gs, i, modulus, p_i, q_i, 40)
+                va = [v._sharing.get(i) for v in a.variables]
+                assert va == [v._sharing.get(i) for v in b.variables]
+                vals = [x for x in va if x is not None]
+                b_new.set_share(i, vals)
+                b_old.set_share(i, vals)
+            assert new["biprime_test_with_v_i"](b_new, modulus, 40, pi) == orig["biprime_test_with_v_i"](b_old, modulus, 40, pi) == c["verdict"]
+    finally:
+        patch.uninstall()
+    assert getattr(DP, "_DistributedPaillier__small_prime_divisors_test")([3], 9) is True
