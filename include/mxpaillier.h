@@ -19,7 +19,7 @@
  *   - Return value: MX_OK (0) or a negative MX_ERR_* code; nothing throws across the ABI.
  *   - Moduli must be odd and >= 3.  Supported modulus size: up to 16 700 bits.
  *   - Bases / partials must be < their modulus (the reference guarantees this: UT:361, PSK:92);
- *     larger values are accepted as long as they are < 2^(32*limbs) and < modulus * 2^24.
+ *     values up to 16 * modulus (and < 2^(32*limbs)) are still reduced correctly.
  */
 #ifndef MXPAILLIER_H
 #define MXPAILLIER_H
@@ -68,7 +68,7 @@ int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_
 /* ---- small-prime sieve -----------------------------------------------------------------
  * d_out[e] = 1 if some h_primes[k] divides candidate e else 0.  Replaces
  * `__small_prime_divisors_test(prime_list, n)` (DK:1197-1209) looped over the batch of
- * candidates at DK:1288-1292.  Primes must be odd and < 2^16 ... 2^31 (any odd 31-bit value). */
+ * candidates at DK:1288-1292.  Primes must be odd, >= 3 and < 2^21; limbs <= 1024. */
 int64_t mx_sieve_workspace_bytes(int limbs, int n_primes);
 int mx_sieve(const uint32_t* d_candidates, uint8_t* d_out, const uint32_t* h_primes, int n_primes,
              int limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
@@ -95,10 +95,23 @@ int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* h_m
                        int n_parties, int64_t groups, int64_t n_slots, void* d_workspace,
                        int64_t workspace_bytes, void* stream);
 
+/* ---- Jacobi symbol ---------------------------------------------------------------------
+ * d_out[g*group_size + k] = Jacobi symbol (d_values[g*group_size + k] / h_mods[g]) in {-1, 0, +1}.
+ * Replaces the filter `sympy.jacobi_symbol(g, modulus) != 1` of the biprimality test (DK:1089),
+ * evaluated for the up to 4*40 jointly random generators of every candidate (DK:1028, 1084-1099).
+ * Values must be < their modulus (UT:361); moduli odd; limbs <= 129 (4128 bits). */
+int64_t mx_jacobi_workspace_bytes(int limbs, int64_t groups);
+int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
+              int64_t group_size, void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- diagnostics -----------------------------------------------------------------------
  * Runs the DPP cross-lane primitives against their ds_bpermute reference forms for every group
  * width on the current device; returns the number of mismatching lanes (0 = pass) or MX_ERR_*. */
 int mx_selftest_lanes(void* stream);
+/* Modexp lane geometry: 9 (narrow: more lanes per element, best for one small batch at a time),
+ * 18 (wide: fewer, busier lanes; best when the GPU is saturated, e.g. several batches in flight on
+ * different streams) or 0 (automatic from the batch size, the default).  Process-wide. */
+int mx_set_limbs_per_lane(int limbs_per_lane);
 /* Engine geometry chosen for a modulus of `mod_bits` bits: lanes per element (K), limbs per lane
  * (L), limb width (W) and Montgomery blocks; returns MX_OK or MX_ERR_SIZE. */
 int mx_geometry(int mod_bits, int* lanes_per_element, int* limbs_per_lane, int* limb_bits, int* blocks);

@@ -13,8 +13,9 @@ here they are the plain lists those containers carry, in the same order.  Argume
 values and error behaviour follow the reference; the batch forms take one entry per candidate
 modulus (the loops DK:1288-1292, DK:1313-1329, DK:1339-1360).
 
-The Jacobi-symbol filter of DK:1089 (sympy.jacobi_symbol in the reference) runs on the host here;
-a GPU kernel for it is the first "next" row of SURVEY.md §8(f).
+The Jacobi-symbol filter of DK:1089 (sympy.jacobi_symbol in the reference) runs on the device too
+(``Engine.jacobi_batch``: all generators of all candidates in one launch); ``jacobi_symbol`` below
+is the scalar host form kept for callers that need a single symbol.
 """
 
 from __future__ import annotations
@@ -70,15 +71,21 @@ def biprime_exponent(index: int, modulus: int, p_i: int, q_i: int) -> int:
     return (p_i + q_i) // 4
 
 
-def select_generators(g_values: Sequence[int], modulus: int, correct_param_biprime: int) -> List[int]:
-    """The g's DK:1084-1099 exponentiates: in order, Jacobi symbol 1, at most correct_param_biprime."""
-    kept: List[int] = []
-    for g in g_values:
-        if len(kept) == correct_param_biprime:
-            break
-        if jacobi_symbol(g, modulus) != 1:
-            continue
-        kept.append(g)
+def select_generators_batch(
+    g_values: Sequence[Sequence[int]], moduli: Sequence[int], correct_param_biprime: int, engine: Any = None
+) -> List[List[int]]:
+    """Per candidate, the g's DK:1084-1099 exponentiates: in order, Jacobi symbol 1, at most
+    correct_param_biprime.  All symbols of all candidates are one GPU launch."""
+    symbols = _engine(engine).jacobi_batch(g_values, list(moduli))
+    kept: List[List[int]] = []
+    for gs, js in zip(g_values, symbols):
+        row: List[int] = []
+        for g, j in zip(gs, js):
+            if len(row) == correct_param_biprime:
+                break
+            if j == 1:
+                row.append(g)
+        kept.append(row)
     return kept
 
 
@@ -97,7 +104,7 @@ def biprime_test_v_calculation_batch(
         raise ValueError("one g list, p share and q share per candidate modulus expected")
     if len(moduli) == 0:
         return []
-    kept = [select_generators(gs, n, correct_param_biprime) for gs, n in zip(g_values, moduli)]
+    kept = select_generators_batch(g_values, moduli, correct_param_biprime, engine)
     exps = [biprime_exponent(index, n, p, q) for n, p, q in zip(moduli, p_shares, q_shares)]
     return _engine(engine).powmod_batch_multi(kept, exps, list(moduli))
 

@@ -4,12 +4,49 @@
 #include "mx_sieve.hpp"
 #include "mx_combine.hpp"
 #include "mx_verdict.hpp"
+#include "mx_jacobi.hpp"
 #include <cstring>
+#include <algorithm>
 
 namespace mxh {
 thread_local hipError_t g_last_hip = hipSuccess;
+int g_limbs_per_lane = 0;
 }
 using namespace mxh;
+
+// ---- stream-ordered upload of small host operands --------------------------------------------
+// Host operands (moduli, exponents, per-modulus constants) are a few KB.  Copying them with
+// hipMemcpyAsync from pageable memory would either block the host behind all earlier work of the
+// stream or leave the caller's buffer in use after return.  Instead they travel BY VALUE in the
+// kernel-argument block of a one-block copy kernel: the runtime captures the arguments at launch,
+// so the host buffer is free on return, nothing synchronises, and the copy is ordered in the stream.
+namespace {
+constexpr int UPLOAD_WORDS = 896;   // 3.5 KiB of the 4 KiB kernel-argument block
+struct UploadChunk { uint32_t w[UPLOAD_WORDS]; };
+
+__global__ void __launch_bounds__(256) upload_kernel(uint32_t* dst, UploadChunk c, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = c.w[i];
+}
+
+int upload_words(void* d_dst, const uint32_t* h_src, size_t n, hipStream_t s) {
+  if (n <= (size_t)UPLOAD_WORDS * 32) {
+    UploadChunk c;
+    for (size_t off = 0; off < n; off += UPLOAD_WORDS) {
+      int m = (int)std::min<size_t>(UPLOAD_WORDS, n - off);
+      std::memcpy(c.w, h_src + off, (size_t)m * 4);
+      hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(256), 0, s, (uint32_t*)d_dst + off, c, m);
+      MX_HIP(hipGetLastError());
+    }
+    return MX_OK;
+  }
+  // large operand sets (thousands of candidate moduli): staged copy, then wait for it so that the
+  // caller may release h_src
+  MX_HIP(hipMemcpyAsync(d_dst, h_src, n * 4, hipMemcpyHostToDevice, s));
+  MX_HIP(hipStreamSynchronize(s));
+  return MX_OK;
+}
+#define MX_TRY(call) do { int rc__ = (call); if (rc__ != MX_OK) return rc__; } while (0)
+}  // namespace
 
 namespace {
 
@@ -94,12 +131,9 @@ int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods
     std::memcpy(exps.data() + g * (exp_limbs + 1), h_exps + g * exp_limbs, (size_t)exp_limbs * 4);
 
   char* ws = (char*)d_ws;
-  MX_HIP(hipMemcpyAsync(ws + p.off_mods, h_mods, (size_t)groups * limbs * 4, hipMemcpyHostToDevice, s));
-  MX_HIP(hipMemcpyAsync(ws + p.off_rmodn, rmodn.data(), rmodn.size() * 4, hipMemcpyHostToDevice, s));
-  MX_HIP(hipMemcpyAsync(ws + p.off_exps, exps.data(), exps.size() * 4, hipMemcpyHostToDevice, s));
-  // the copies above read pageable host memory: HIP stages them before returning, so the
-  // vectors may go out of scope; make that explicit for the two temporaries
-  MX_HIP(hipStreamSynchronize(s));
+  MX_TRY(upload_words(ws + p.off_mods, h_mods, (size_t)groups * limbs, s));
+  MX_TRY(upload_words(ws + p.off_rmodn, rmodn.data(), rmodn.size(), s));
+  MX_TRY(upload_words(ws + p.off_exps, exps.data(), exps.size(), s));
 
   mx::PowmodArgs a;
   a.bases = d_bases; a.out = d_out;
@@ -174,9 +208,16 @@ const char* mx_error_string(int code) {
 
 const char* mx_last_hip_error(void) { return hipGetErrorString(g_last_hip); }
 
+int mx_set_limbs_per_lane(int limbs_per_lane) {
+  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  g_limbs_per_lane = limbs_per_lane;
+  return MX_OK;
+}
+
 int mx_geometry(int mod_bits, int* k, int* l, int* w, int* blocks) {
   Geometry g;
-  if (!choose_geometry(mod_bits, g)) return MX_ERR_SIZE;
+  int lpl = (g_limbs_per_lane == LIMBS_PER_LANE_WIDE) ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+  if (!choose_geometry(mod_bits, g, lpl)) return MX_ERR_SIZE;
   if (k) *k = g.K;
   if (l) *l = g.L;
   if (w) *w = g.W;
@@ -256,7 +297,7 @@ extern "C" int mx_sieve(const uint32_t* d_cands, uint8_t* d_out, const uint32_t*
   SievePlan p = plan_sieve(limbs, n_primes);
   if (p.total > ws_bytes) return MX_ERR_WORKSPACE;
   char* ws = (char*)d_ws;
-  MX_HIP(hipMemcpyAsync(ws + p.off_primes, h_primes, (size_t)n_primes * 4, hipMemcpyHostToDevice, s));
+  MX_TRY(upload_words(ws + p.off_primes, h_primes, (size_t)n_primes, s));
   mx::SieveArgs a;
   a.cands = d_cands; a.out = d_out;
   a.primes = (const u32*)(ws + p.off_primes);
@@ -321,8 +362,7 @@ extern "C" int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* 
   }
   std::memcpy(&c[(size_t)4 * limbs2], h_theta_inv, (size_t)limbs * 4);
   hipStream_t s = (hipStream_t)stream;
-  MX_HIP(hipMemcpyAsync(d_ws, c.data(), c.size() * 4, hipMemcpyHostToDevice, s));
-  MX_HIP(hipStreamSynchronize(s));
+  MX_TRY(upload_words(d_ws, c.data(), c.size(), s));
   const u32* w = (const u32*)d_ws;
   mx::CombineArgs a;
   a.partials = d_partials; a.out = d_out; a.status = d_status;
@@ -384,9 +424,8 @@ extern "C" int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const ui
     two_pow_mod(rmodn.data() + g * limbs, h_mods + g * limbs, limbs, geo.W * geo.L * geo.nblk);
   hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)d_ws;
-  MX_HIP(hipMemcpyAsync(ws, h_mods, (size_t)groups * limbs * 4, hipMemcpyHostToDevice, s));
-  MX_HIP(hipMemcpyAsync(ws + part, rmodn.data(), rmodn.size() * 4, hipMemcpyHostToDevice, s));
-  MX_HIP(hipStreamSynchronize(s));
+  MX_TRY(upload_words(ws, h_mods, (size_t)groups * limbs, s));
+  MX_TRY(upload_words(ws + part, rmodn.data(), rmodn.size(), s));
   mx::VerdictArgs a;
   a.v = d_v; a.pass = d_pass; a.mods = (const u32*)ws; a.rmodn = (const u32*)(ws + part);
   a.groups = groups; a.n_slots = n_slots; a.limbs = limbs; a.n_parties = n_parties; a.nblk = geo.nblk;
@@ -400,4 +439,41 @@ extern "C" int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const ui
     case 64: return launch_verdict_k<64>(a, s);
   }
   return MX_ERR_SIZE;
+}
+
+// ---- Jacobi symbol -------------------------------------------------------------------------
+namespace {
+template <int NL>
+int launch_jacobi(const mx::JacobiArgs& a, hipStream_t s) {
+  int64_t nblocks = (a.count + 63) / 64;
+  hipLaunchKernelGGL((mx::jacobi_kernel<NL>), dim3((unsigned)nblocks), dim3(64), 0, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+}  // namespace
+
+extern "C" int64_t mx_jacobi_workspace_bytes(int limbs, int64_t groups) {
+  if (limbs <= 0 || groups <= 0) return MX_ERR_ARG;
+  return align256((int64_t)groups * limbs * 4);
+}
+
+extern "C" int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
+                         int64_t group_size, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_values || !d_out || !h_mods || !d_ws || limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
+  if (limbs > 129) return MX_ERR_SIZE;
+  for (int64_t g = 0; g < groups; ++g)
+    if (!(h_mods[g * limbs] & 1u)) return MX_ERR_MODULUS;
+  if (align256((int64_t)groups * limbs * 4) > ws_bytes) return MX_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  MX_TRY(upload_words(d_ws, h_mods, (size_t)groups * limbs, s));
+  mx::JacobiArgs a;
+  a.a = d_values; a.mods = (const u32*)d_ws; a.out = (signed char*)d_out;
+  a.count = groups * group_size; a.group_size = group_size; a.limbs = limbs;
+  if (limbs <= 3) return launch_jacobi<3>(a, s);
+  if (limbs <= 5) return launch_jacobi<5>(a, s);
+  if (limbs <= 9) return launch_jacobi<9>(a, s);
+  if (limbs <= 17) return launch_jacobi<17>(a, s);
+  if (limbs <= 33) return launch_jacobi<33>(a, s);
+  if (limbs <= 65) return launch_jacobi<65>(a, s);
+  return launch_jacobi<129>(a, s);
 }

@@ -105,8 +105,12 @@ inline int fixed_window(int exp_bits) {
 // Which limbs-per-lane to run a modexp batch with.  The wide geometry spends a larger share of its
 // instructions on multiply-accumulates (the per-limb bookkeeping is amortised over 2L MACs) but
 // puts half as many lanes on the machine; it pays once the batch still fills every SIMD with
-// at least two wavefronts (1024 SIMDs x 64 lanes).  MX_LIMBS_PER_LANE=9|18 overrides.
+// at least two wavefronts (1024 SIMDs x 64 lanes) — or when the caller keeps several batches in
+// flight on different streams, which the library cannot see: mx_set_limbs_per_lane(9|18) or the
+// environment variable MX_LIMBS_PER_LANE override the automatic choice.
+extern int g_limbs_per_lane;   // 0 = automatic; set by mx_set_limbs_per_lane
 inline int pick_limbs_per_lane(int mod_bits, int64_t batch) {
+  if (g_limbs_per_lane == LIMBS_PER_LANE || g_limbs_per_lane == LIMBS_PER_LANE_WIDE) return g_limbs_per_lane;
   if (const char* e = getenv("MX_LIMBS_PER_LANE")) {
     int v = atoi(e);
     if (v == LIMBS_PER_LANE || v == LIMBS_PER_LANE_WIDE) return v;

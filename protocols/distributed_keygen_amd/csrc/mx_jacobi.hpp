@@ -1,0 +1,100 @@
+// Batched Jacobi symbol (g / N), N odd: the filter `sympy.jacobi_symbol(g, modulus) != 1` of the
+// reference's biprimality test (distributed_keygen.py:1089), ~4x40 symbols per candidate modulus.
+//
+// Unlike the Montgomery kernels this is a subtract-and-shift algorithm with no multiplications,
+// so the layout is different: ONE THREAD PER SYMBOL, both operands in registers as NL radix-2^32
+// limbs (fully unrolled limb loops, compile-time indices only).  Binary algorithm:
+//     a <- g mod N handled by the caller (g < N as the reference guarantees, UT:361);  t <- 1
+//     while a != 0:
+//         strip the z trailing zero bits of a;  if z odd and N mod 8 in {3,5}: t <- -t
+//         if a < N: swap (a, N); if a = N = 3 (mod 4): t <- -t
+//         a <- a - N
+//     result t if N == 1 else 0
+// Compare (one borrow chain, nothing stored) then subtract in the right direction, in place;
+// lanes of a wave run different trip counts (the loop is ~1.4 iterations per bit), so the kernel is
+// launched with consecutive threads on consecutive symbols of the SAME modulus size.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace mx {
+
+struct JacobiArgs {
+  const uint32_t* a;      // [count][limbs] device: numerators (< modulus of their group)
+  const uint32_t* mods;   // [groups][limbs] device
+  signed char* out;       // [count] device: -1, 0, +1
+  long long count;
+  long long group_size;   // symbols per modulus
+  int limbs;
+};
+
+template <int NL>
+__global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
+  const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
+  const bool valid = idx < A.count;
+  const long long e = valid ? idx : A.count - 1;
+  const uint32_t* pa = A.a + e * A.limbs;
+  const uint32_t* pn = A.mods + (e / A.group_size) * A.limbs;
+  uint32_t a[NL], n[NL];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) {
+    a[j] = j < A.limbs ? pa[j] : 0u;
+    n[j] = j < A.limbs ? pn[j] : 0u;
+  }
+  int t = 1;
+  // Every pass removes at least one bit from a or n, so 64*NL passes always suffice; the bound
+  // makes the kernel terminate on ANY input (an even "modulus" would otherwise never finish).
+  bool done = false;
+  for (int pass = 0; pass < 64 * NL + 2; ++pass) {
+    uint32_t nz = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) nz |= a[j];
+    if (nz == 0) { done = true; break; }
+    // ---- strip trailing zeros (whole limbs first, then bits)
+    while (a[0] == 0) {            // a != 0, so this terminates; 32 zero bits: even count, no sign change
+#pragma unroll
+      for (int j = 0; j < NL - 1; ++j) a[j] = a[j + 1];
+      a[NL - 1] = 0;
+    }
+    const int z = __builtin_ctz(a[0]);
+    if (z) {
+#pragma unroll
+      for (int j = 0; j < NL - 1; ++j) a[j] = __builtin_amdgcn_alignbit(a[j + 1], a[j], z);
+      a[NL - 1] >>= z;
+      const uint32_t n8 = n[0] & 7u;
+      if ((z & 1) && (n8 == 3u || n8 == 5u)) t = -t;
+    }
+    // ---- a < n ?  (borrow of a - n, nothing stored)
+    uint64_t borrow = 0;
+#pragma unroll
+    for (int j = 0; j < NL; ++j) borrow = (((uint64_t)a[j] - n[j] - borrow) >> 63) & 1u;
+    if (borrow) {
+      // (a, n) <- (n - a, a), quadratic reciprocity for the swap
+      if ((a[0] & 3u) == 3u && (n[0] & 3u) == 3u) t = -t;
+      uint64_t b = 0;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const uint32_t x = a[j];
+        const uint64_t y = (uint64_t)n[j] - x - b;
+        a[j] = (uint32_t)y;
+        b = (y >> 63) & 1u;
+        n[j] = x;
+      }
+    } else {
+      uint64_t b = 0;
+#pragma unroll
+      for (int j = 0; j < NL; ++j) {
+        const uint64_t y = (uint64_t)a[j] - n[j] - b;
+        a[j] = (uint32_t)y;
+        b = (y >> 63) & 1u;
+      }
+    }
+  }
+  uint32_t hi = 0;
+#pragma unroll
+  for (int j = 1; j < NL; ++j) hi |= n[j];
+  const bool n_is_one = done && (hi == 0) && (n[0] == 1u);
+  if (valid) A.out[idx] = (signed char)(n_is_one ? t : 0);
+}
+
+}  // namespace mx

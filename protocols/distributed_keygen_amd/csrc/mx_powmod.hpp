@@ -31,7 +31,7 @@ struct PowmodArgs {
 };
 
 template <int K, int L, int W>
-__global__ void __launch_bounds__(64) powmod_kernel(PowmodArgs A) {
+__global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs A) {
   using M_t = Mont<K, L, W, true>;
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;

@@ -60,6 +60,10 @@ class Engine:
     def synchronize(self) -> None:
         self.torch.cuda.current_stream(self.device).synchronize()
 
+    def set_limbs_per_lane(self, limbs_per_lane: int) -> None:
+        """0 = automatic, 9 = narrow geometry, 18 = wide geometry (process-wide; include/mxpaillier.h)."""
+        _lib.check(self.lib.mx_set_limbs_per_lane(int(limbs_per_lane)), "mx_set_limbs_per_lane")
+
     def selftest_lanes(self) -> int:
         with self.torch.cuda.device(self.device):
             return _lib.check(self.lib.mx_selftest_lanes(self._stream_ptr()), "mx_selftest_lanes")
@@ -154,6 +158,45 @@ class Engine:
         vals = _limbs.unpack(self.to_host(out))
         return [vals[g * gsize : g * gsize + len(bases[g])] for g in range(groups)]
 
+
+    # ------------------------------------------------------------------ Jacobi symbol
+    def jacobi_t(self, values_t, mods: Sequence[int], group_size: int, out_t=None):
+        """int8 [groups*group_size]: Jacobi symbol (values[g*group_size+k] / mods[g]) (DK:1089)."""
+        count, limbs = values_t.shape
+        groups = len(mods)
+        if count != groups * group_size:
+            raise ValueError("values must hold groups*group_size rows")
+        h_mods = _limbs.pack(mods, limbs)
+        if out_t is None:
+            out_t = self.torch.empty(count, dtype=self.torch.int8, device=self.device)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_jacobi_workspace_bytes(limbs, groups))
+            rc = self.lib.mx_jacobi(
+                values_t.data_ptr(), out_t.data_ptr(), h_mods.ctypes.data, limbs, groups, group_size,
+                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_jacobi")
+        return out_t
+
+    def jacobi_batch(self, values: Sequence[Sequence[int]], mods: Sequence[int]) -> List[List[int]]:
+        """[[jacobi_symbol(v, mods[g]) for v in values[g]] for g]; ragged groups are padded."""
+        groups = len(mods)
+        if groups == 0:
+            return []
+        for m in mods:
+            if m < 1 or m % 2 == 0:
+                raise ValueError("n should be an odd positive integer")
+        gsize = max(len(v) for v in values)
+        if gsize == 0:
+            return [[] for _ in values]
+        limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
+        flat = []
+        for vs, m in zip(values, mods):
+            flat.extend(_reduce(x, m) for x in vs)
+            flat.extend([0] * (gsize - len(vs)))
+        out = self.jacobi_t(self.to_device(_limbs.pack(flat, limbs)), list(mods), gsize)
+        arr = out.cpu().numpy()
+        return [[int(x) for x in arr[g * gsize : g * gsize + len(values[g])]] for g in range(groups)]
 
     # ------------------------------------------------------------------ sieve
     def sieve_t(self, cands_t, primes: Sequence[int], out_t=None):

@@ -23,6 +23,10 @@ class FakeEngine:
         self.calls.append(("powmod_batch_multi", sum(len(b) for b in bases)))
         return [[oracle.pow_mod(b, e, m) for b in bs] for bs, e, m in zip(bases, exps, mods)]
 
+    def jacobi_batch(self, values, mods):
+        self.calls.append(("jacobi_batch", sum(len(v) for v in values)))
+        return [[oracle.jacobi_symbol(v, m) for v in vs] for vs, m in zip(values, mods)]
+
     def sieve_batch(self, candidates, primes):
         self.calls.append(("sieve_batch", len(candidates)))
         return [oracle.small_prime_divisors_test(primes, c) for c in candidates]

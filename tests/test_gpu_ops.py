@@ -128,3 +128,31 @@ def test_verdict_negative_and_zero_products(eng):
     v3 = [1, 1, 9, 1, 1, 1]
     got = eng.biprime_verdict_batch([[v1, v2, v3]], [m])
     assert got == [[True, True, True, False, True, True]]
+
+
+# ------------------------------------------------------------------ Jacobi symbol (DK:1089)
+@pytest.mark.parametrize("bits,groups,gsize", [(20, 7, 33), (68, 9, 80), (131, 5, 160), (515, 3, 64), (1028, 4, 160), (2053, 3, 160), (4100, 2, 40)])
+def test_jacobi_random(eng, bits, groups, gsize):
+    rng = random.Random(bits)
+    mods = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(groups)]
+    vals = [[rng.randrange(m) for _ in range(gsize)] for m in mods]
+    vals[0][0] = 0
+    vals[0][1] = 1
+    vals[0][2] = mods[0] - 1
+    vals[0][3] = 2
+    vals[1] = vals[1][: gsize - 5]                                   # ragged
+    got = eng.jacobi_batch(vals, mods)
+    assert got == [[oracle.jacobi_symbol(v, m) for v in vs] for vs, m in zip(vals, mods)]
+    assert {x for row in got for x in row} >= {-1, 1}
+
+
+def test_jacobi_special_cases(eng):
+    assert eng.jacobi_batch([[0, 1, 2, 3, 4, 5, 6, 7, 8]], [9]) == [[oracle.jacobi_symbol(v, 9) for v in range(9)]]
+    assert eng.jacobi_batch([[0, 5]], [1]) == [[1, 1]]
+    m = (1 << 64) + 13                                             # common factor -> 0
+    assert eng.jacobi_batch([[3 * 7, (m // 7) * 7 if m % 7 == 0 else 0]], [21 * 5 + 0 if False else 105]) == [[oracle.jacobi_symbol(21, 105), oracle.jacobi_symbol(0, 105)]]
+    big = (1 << 2000) + 297
+    pw = [1 << k for k in (1, 31, 32, 33, 64, 1999)]                # long runs of trailing zeros
+    assert eng.jacobi_batch([pw], [big]) == [[oracle.jacobi_symbol(v, big) for v in pw]]
+    with pytest.raises(ValueError):
+        eng.jacobi_batch([[1]], [8])
