@@ -38,8 +38,8 @@ VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
 def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=9)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=10000, help="ciphertexts per step per GPU")
     ap.add_argument("--key-length", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")

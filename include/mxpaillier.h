@@ -95,6 +95,16 @@ int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* h_m
                        int n_parties, int64_t groups, int64_t n_slots, void* d_workspace,
                        int64_t workspace_bytes, void* stream);
 
+/* ---- modular multiplication ------------------------------------------------------------
+ * d_out[e] = d_a[e] * d_b[e] mod h_mod.  The glue around the modexps: (1 + mN) * r^N of Paillier
+ * encryption (the un-vendored tno.mpc.encryption_schemes.paillier used by the reference's tests,
+ * test_distributed_keygen.py:125), homomorphic addition, and the product tree of the batched
+ * modular inversion that replaces `mod_inv(ciphertext_value, n_square)` per ciphertext (PSK:89-91).
+ * d_out may alias d_a or d_b. */
+int64_t mx_mulmod_workspace_bytes(int limbs);
+int mx_mulmod_shared(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, const uint32_t* h_mod,
+                     int limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Jacobi symbol ---------------------------------------------------------------------
  * d_out[g*group_size + k] = Jacobi symbol (d_values[g*group_size + k] / h_mods[g]) in {-1, 0, +1}.
  * Replaces the filter `sympy.jacobi_symbol(g, modulus) != 1` of the biprimality test (DK:1089),

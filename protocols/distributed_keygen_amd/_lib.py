@@ -26,6 +26,8 @@ SYMBOLS = {
     "mx_combine": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_verdict_workspace_bytes": (c_int64, [c_int, c_int, c_int64, c_int64]),
     "mx_biprime_verdict": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_mulmod_workspace_bytes": (c_int64, [c_int]),
+    "mx_mulmod_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_jacobi_workspace_bytes": (c_int64, [c_int, c_int64]),
     "mx_jacobi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_set_limbs_per_lane": (c_int, [c_int]),

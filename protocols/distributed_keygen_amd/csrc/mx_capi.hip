@@ -5,6 +5,7 @@
 #include "mx_combine.hpp"
 #include "mx_verdict.hpp"
 #include "mx_jacobi.hpp"
+#include "mx_mulmod.hpp"
 #include <cstring>
 #include <algorithm>
 
@@ -476,4 +477,52 @@ extern "C" int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t
   if (limbs <= 33) return launch_jacobi<33>(a, s);
   if (limbs <= 65) return launch_jacobi<65>(a, s);
   return launch_jacobi<129>(a, s);
+}
+
+// ---- modular multiplication ------------------------------------------------------------------
+namespace {
+template <int K>
+int launch_mulmod_k(const mx::MulmodArgs& a, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE, LIMB_BITS, true>;
+  int gpw = 64 / K;
+  int64_t nblocks = (a.batch + gpw - 1) / gpw;
+  size_t lds = (size_t)gpw * M_t::LDS_WORDS * 4;
+  hipLaunchKernelGGL((mx::mulmod_kernel<K, LIMBS_PER_LANE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+}  // namespace
+
+extern "C" int64_t mx_mulmod_workspace_bytes(int limbs) {
+  if (limbs <= 0) return MX_ERR_ARG;
+  return align256((int64_t)2 * limbs * 4);
+}
+
+extern "C" int mx_mulmod_shared(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, const uint32_t* h_mod,
+                                int limbs, int64_t batch, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_a || !d_b || !d_out || !h_mod || !d_ws || limbs <= 0 || batch <= 0) return MX_ERR_ARG;
+  if (!(h_mod[0] & 1u)) return MX_ERR_MODULUS;
+  int bits = bit_length(h_mod, limbs);
+  if (bits < 2) return MX_ERR_MODULUS;
+  Geometry geo;
+  if (!choose_geometry(bits, geo)) return MX_ERR_SIZE;
+  if (align256((int64_t)2 * limbs * 4) > ws_bytes) return MX_ERR_WORKSPACE;
+  std::vector<u32> c((size_t)2 * limbs);
+  std::memcpy(c.data(), h_mod, (size_t)limbs * 4);
+  two_pow_mod(c.data() + limbs, h_mod, limbs, geo.W * geo.L * geo.nblk);
+  hipStream_t s = (hipStream_t)stream;
+  MX_TRY(upload_words(d_ws, c.data(), c.size(), s));
+  mx::MulmodArgs a;
+  a.a = d_a; a.b = d_b; a.out = d_out; a.mod = (const u32*)d_ws; a.rmodn = (const u32*)d_ws + limbs;
+  a.batch = batch; a.limbs = limbs; a.nblk = geo.nblk;
+  switch (geo.K) {
+    case 1: return launch_mulmod_k<1>(a, s);
+    case 2: return launch_mulmod_k<2>(a, s);
+    case 4: return launch_mulmod_k<4>(a, s);
+    case 8: return launch_mulmod_k<8>(a, s);
+    case 16: return launch_mulmod_k<16>(a, s);
+    case 32: return launch_mulmod_k<32>(a, s);
+    case 64: return launch_mulmod_k<64>(a, s);
+  }
+  return MX_ERR_SIZE;
 }

@@ -159,6 +159,84 @@ class Engine:
         return [vals[g * gsize : g * gsize + len(bases[g])] for g in range(groups)]
 
 
+    # ------------------------------------------------------------------ modular multiplication / inversion / encryption
+    def mulmod_t(self, a_t, b_t, mod: int, out_t=None):
+        """out[e] = a[e]*b[e] mod `mod`; int32 rows [batch, limbs]; out_t may alias an input."""
+        batch, limbs = a_t.shape
+        if tuple(b_t.shape) != (batch, limbs):
+            raise ValueError("operands must have the same shape")
+        h_mod = _limbs.pack_one(mod, limbs)
+        if out_t is None:
+            out_t = self.torch.empty_like(a_t)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_mulmod_workspace_bytes(limbs))
+            rc = self.lib.mx_mulmod_shared(
+                a_t.data_ptr(), b_t.data_ptr(), out_t.data_ptr(), h_mod.ctypes.data, limbs, batch,
+                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_mulmod_shared")
+        return out_t
+
+    def mulmod_batch(self, a: Sequence[int], b: Sequence[int], mod: int) -> List[int]:
+        if len(a) != len(b):
+            raise ValueError("operands must have the same length")
+        if len(a) == 0:
+            return []
+        _check_modulus(mod)
+        limbs = _limbs.limbs_for(mod)
+        at = self.to_device(_limbs.pack([_reduce(x, mod) for x in a], limbs))
+        bt = self.to_device(_limbs.pack([_reduce(x, mod) for x in b], limbs))
+        return _limbs.unpack(self.to_host(self.mulmod_t(at, bt, mod)))
+
+    def modinv_t(self, x_t, mod: int):
+        """Row-wise modular inverse by Montgomery's trick as a product tree on the device: 3 modular
+        multiplications per element in ~2 log2(batch) launches plus ONE host inversion of the root.
+        Raises ValueError (like ``pow(v, -1, m)``) if some row is not invertible."""
+        torch = self.torch
+        levels = [x_t.contiguous()]
+        while levels[-1].shape[0] > 1:
+            cur = levels[-1]
+            m = cur.shape[0]
+            prod = self.mulmod_t(cur[0 : m - (m & 1) : 2].contiguous(), cur[1:m:2].contiguous(), mod)
+            if m & 1:
+                prod = torch.cat([prod, cur[m - 1 : m]], dim=0)
+            levels.append(prod)
+        root = _limbs.unpack(self.to_host(levels[-1]))[0]
+        inv = self.to_device(_limbs.pack([pow(root, -1, mod)], x_t.shape[1]))   # ValueError if not invertible
+        for cur in reversed(levels[:-1]):
+            m = cur.shape[0]
+            half = m // 2
+            left, right = cur[0 : 2 * half : 2].contiguous(), cur[1 : 2 * half : 2].contiguous()
+            nxt = torch.empty_like(cur)
+            nxt[0 : 2 * half : 2] = self.mulmod_t(inv[:half].contiguous(), right, mod)
+            nxt[1 : 2 * half : 2] = self.mulmod_t(inv[:half].contiguous(), left, mod)
+            if m & 1:
+                nxt[m - 1] = inv[half]
+            inv = nxt
+        return inv
+
+    def modinv_batch(self, values: Sequence[int], mod: int) -> List[int]:
+        """[mod_inv(v, mod) for v in values] (PSK:90 over a batch)."""
+        if len(values) == 0:
+            return []
+        _check_modulus(mod)
+        limbs = _limbs.limbs_for(mod)
+        x_t = self.to_device(_limbs.pack([_reduce(v, mod) for v in values], limbs))
+        return _limbs.unpack(self.to_host(self.modinv_t(x_t, mod)))
+
+    def encrypt_batch(self, messages: Sequence[int], randomness: Sequence[int], n: int) -> List[int]:
+        """Paillier encryption with g = n + 1:  c = (1 + m n) * r^n mod n^2 for every (m, r)."""
+        if len(messages) != len(randomness):
+            raise ValueError("one randomness per message expected")
+        if len(messages) == 0:
+            return []
+        _check_modulus(n)
+        n2 = n * n
+        limbs = _limbs.limbs_for(n2)
+        rn_t = self.powmod_shared_t(self.to_device(_limbs.pack([_reduce(r, n2) for r in randomness], limbs)), n2, n)
+        g_t = self.to_device(_limbs.pack([(1 + (m % n) * n) % n2 for m in messages], limbs))
+        return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, g_t, n2, out_t=rn_t)))
+
     # ------------------------------------------------------------------ Jacobi symbol
     def jacobi_t(self, values_t, mods: Sequence[int], group_size: int, out_t=None):
         """int8 [groups*group_size]: Jacobi symbol (values[g*group_size+k] / mods[g]) (DK:1089)."""

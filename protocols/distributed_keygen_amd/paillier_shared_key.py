@@ -117,8 +117,8 @@ class GpuPaillierSharedKey:
         if not values:
             return []
         exp = self.lagrange_exponent()
-        if exp < 0:  # PSK:89-91
-            values = batch_mod_inv([v % self.n_square for v in values], self.n_square)
+        if exp < 0:  # PSK:89-91, as one product-tree inversion on the device
+            values = self.engine.modinv_batch(values, self.n_square)
             exp = -exp
         return self.engine.powmod_batch(values, exp, self.n_square)  # PSK:92
 

@@ -23,6 +23,10 @@ class FakeEngine:
         self.calls.append(("powmod_batch_multi", sum(len(b) for b in bases)))
         return [[oracle.pow_mod(b, e, m) for b in bs] for bs, e, m in zip(bases, exps, mods)]
 
+    def modinv_batch(self, values, mod):
+        self.calls.append(("modinv_batch", len(values)))
+        return [oracle.mod_inv(v, mod) for v in values]
+
     def jacobi_batch(self, values, mods):
         self.calls.append(("jacobi_batch", sum(len(v) for v in values)))
         return [[oracle.jacobi_symbol(v, m) for v in vs] for vs, m in zip(values, mods)]

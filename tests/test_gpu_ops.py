@@ -156,3 +156,43 @@ def test_jacobi_special_cases(eng):
     assert eng.jacobi_batch([pw], [big]) == [[oracle.jacobi_symbol(v, big) for v in pw]]
     with pytest.raises(ValueError):
         eng.jacobi_batch([[1]], [8])
+
+
+# ------------------------------------------------------------------ mulmod / batched inverse / encryption
+@pytest.mark.parametrize("bits,batch", [(136, 33), (2053, 40), (4102, 257), (8206, 9)])
+def test_mulmod_and_modinv(eng, bits, batch):
+    rng = random.Random(bits + batch)
+    p, q = rng.getrandbits(bits // 2) | 1, rng.getrandbits(bits - bits // 2) | (1 << (bits - bits // 2 - 1)) | 1
+    mod = p * q | 1
+    a = [rng.randrange(mod) for _ in range(batch)]
+    b = [rng.randrange(mod) for _ in range(batch)]
+    a[0], b[0], a[1], b[1] = 0, 5, mod - 1, mod - 1
+    assert eng.mulmod_batch(a, b, mod) == [x * y % mod for x, y in zip(a, b)]
+    import math
+    units = [v for v in b if math.gcd(v, mod) == 1]
+    assert eng.modinv_batch(units, mod) == [pow(v, -1, mod) for v in units]
+    assert eng.modinv_batch(units[:1], mod) == [pow(units[0], -1, mod)]
+    with pytest.raises(ValueError):
+        eng.modinv_batch(units[:3] + [0] + units[3:], mod)
+
+
+def test_encrypt_batch_and_negative_exponent_party(eng, golden_decrypt_synth):
+    from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+
+    grp = golden_decrypt_synth["k2048_n3_t1"]
+    n = unhex(grp["n"])
+    rng = random.Random(8)
+    msgs = [rng.randrange(n) for _ in range(20)]
+    rs = [rng.randrange(1, n) for _ in range(20)]
+    cts = eng.encrypt_batch(msgs, rs, n)
+    assert cts == [(1 + m * n) % (n * n) * pow(r, n, n * n) % (n * n) for m, r in zip(msgs, rs)]
+    keys = {
+        int(i): GpuPaillierSharedKey(n, grp["t"], int(i), ShareView({int(i): unhex(s)}, grp["degree"], unhex(grp["n_fac"])),
+                                     unhex(grp["theta"]), engine=eng)
+        for i, s in grp["shares"].items()
+    }
+    assert any(k.lagrange_exponent() < 0 for k in keys.values())      # exercises the device inversion
+    partials = {i: k.partial_decrypt_batch([PlainCiphertext(c, n) for c in cts]) for i, k in keys.items()}
+    for i, k in keys.items():
+        assert partials[i][3] == oracle.partial_decrypt(cts[3], n, i, grp["degree"], unhex(grp["n_fac"]), k.share.shares[i])
+    assert keys[1].decrypt_batch([{i: partials[i][e] for i in keys} for e in range(20)]) == msgs

@@ -27,8 +27,16 @@ def main():
     eng = Engine()
     rng = random.Random(args.key_length)
     half = args.key_length // 2
-    shares = [synthetic.candidate_shares(rng, args.parties, half) for _ in range(args.cands)]
-    mods = [sum(p) * sum(q) for p, q in shares]
+    primes = oracle.small_prime_list(2000)
+    shares, mods = [], []
+    while len(mods) < args.cands:                      # candidates that survive the sieve, as in DK:1288-1292
+        cand = [synthetic.candidate_shares(rng, args.parties, half) for _ in range(args.cands * 8)]
+        cm = [sum(p) * sum(q) for p, q in cand]
+        keep = eng.sieve_batch(cm, primes)
+        for sh, m, bad in zip(cand, cm, keep):
+            if not bad and len(mods) < args.cands:
+                shares.append(sh)
+                mods.append(m)
     exps = [(m - p[0] - q[0] + 1) // 4 for m, (p, q) in zip(mods, shares)]
     limbs = L.limbs_for_bits(max(m.bit_length() for m in mods))
     g_all = [[rng.randrange(m) for _ in range(160)] for m in mods]
@@ -42,8 +50,8 @@ def main():
     kept = []
     for c in range(args.cands):
         row = [g_all[c][k] for k in range(160) if jac[c, k] == 1][:40]
-        assert len(row) == 40
-        kept.append(row)
+        assert len(row) >= 20
+        kept.append((row * 2)[:40])
     b_t = eng.to_device(L.pack([g for row in kept for g in row], limbs))
     out_t = torch.empty_like(b_t)
     eng.powmod_multi_t(b_t, mods, exps, 40, out_t=out_t)
@@ -55,7 +63,6 @@ def main():
     assert rows == [pow(kept[c][k], exps[c], mods[c]) for c in range(2) for k in range(40)]
     assert int(jac[0, 5]) == oracle.jacobi_symbol(g_all[0][5], mods[0])
     # sieve
-    primes = oracle.small_prime_list(2000)
     c_t = eng.to_device(L.pack(mods * 16, limbs))
     eng.sieve_t(c_t, primes)
     torch.cuda.synchronize(); t0 = time.perf_counter()
