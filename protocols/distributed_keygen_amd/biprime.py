@@ -14,8 +14,7 @@ values and error behaviour follow the reference; the batch forms take one entry 
 modulus (the loops DK:1288-1292, DK:1313-1329, DK:1339-1360).
 
 The Jacobi-symbol filter of DK:1089 (sympy.jacobi_symbol in the reference) runs on the device too
-(``Engine.jacobi_batch``: all generators of all candidates in one launch); ``jacobi_symbol`` below
-is the scalar host form kept for callers that need a single symbol.
+(``Engine.jacobi_batch``: all generators of all candidates in one launch).
 """
 
 from __future__ import annotations
@@ -29,24 +28,6 @@ def _engine(engine: Any) -> Any:
     from .engine import default_engine
 
     return default_engine()
-
-
-def jacobi_symbol(m: int, n: int) -> int:
-    """Jacobi symbol (m/n) for odd positive n — the value sympy.jacobi_symbol returns at DK:1089."""
-    if n <= 0 or n % 2 == 0:
-        raise ValueError("n should be an odd positive integer")
-    m %= n
-    sign = 1
-    while m:
-        tz = (m & -m).bit_length() - 1
-        if tz:
-            m >>= tz
-            if tz & 1 and n & 7 in (3, 5):
-                sign = -sign
-        if m & 3 == 3 and n & 3 == 3:
-            sign = -sign
-        m, n = n % m, m
-    return sign if n == 1 else 0
 
 
 # ------------------------------------------------------------------ DK:1197-1209

@@ -12,8 +12,8 @@ forms the reference's loops (distributed_keygen.py:463-466 and 510-515) are repl
 a ciphertext is anything with ``.get_value()`` and ``.scheme.public_key.n`` (the reference's
 ``PaillierCiphertext``; when that class is importable the reference's isinstance check is applied
 verbatim).  ``engine`` is injected so the host logic is testable without a GPU; the default is the
-process-wide HIP engine, and there is no CPU arithmetic path in this module beyond the two one-off
-modular inverses the reference also does on the host side of its API (PSK:50, PSK:90).
+process-wide HIP engine, and there is no CPU arithmetic path in this module beyond ``theta_inv``,
+the one-off modular inverse per key the reference also computes in its constructor (PSK:50).
 """
 
 from __future__ import annotations
@@ -42,26 +42,6 @@ def _mult_list(values: Iterable[int]) -> int:
     out = 1
     for v in values:
         out *= v
-    return out
-
-
-def batch_mod_inv(values: Sequence[int], modulus: int) -> List[int]:
-    """[mod_inv(v, modulus) for v in values] with ONE modular inversion (Montgomery's trick);
-    raises ValueError like ``pow(v, -1, m)`` when some value is not invertible."""
-    n = len(values)
-    if n == 0:
-        return []
-    prefix = [0] * n
-    acc = 1
-    for i, v in enumerate(values):
-        acc = acc * v % modulus
-        prefix[i] = acc
-    inv = pow(acc, -1, modulus)
-    out = [0] * n
-    for i in range(n - 1, 0, -1):
-        out[i] = inv * prefix[i - 1] % modulus
-        inv = inv * values[i] % modulus
-    out[0] = inv
     return out
 
 

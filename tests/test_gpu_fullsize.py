@@ -23,13 +23,11 @@ def eng():
 
 
 def _decrypt_all(eng, key, cts):
-    from protocols.distributed_keygen_amd.paillier_shared_key import batch_mod_inv
-
     n2 = key.n_square
     partials = []
     for i in range(1, key.degree + 2):
         e = key.exponent(i)
-        bases = cts if e >= 0 else batch_mod_inv(cts, n2)
+        bases = cts if e >= 0 else eng.modinv_batch(cts, n2)
         partials.append(eng.powmod_batch(bases, abs(e), n2))
     rows = [[partials[i][k] for i in range(key.degree + 1)] for k in range(len(cts))]
     msgs, ok = eng.combine_batch(rows, key.n, key.theta_inv)
@@ -53,6 +51,14 @@ def test_c3_10k_ciphertexts_roundtrip_key2048(eng):
     cts = [(1 + m * n) % n2 * x % n2 for m, x in zip(msgs, rn)]
     partials, got, ok = _decrypt_all(eng, key, cts)
     assert all(ok) and got == msgs                                     # decrypt(encrypt(m)) == m, all 10 000
+    # one party's partial decryptions, every 4th ciphertext, bit-exact vs pow() on all host cores
+    import multiprocessing as mp
+
+    i_pos = next(i for i in (1, 2, 3) if key.exponent(i) >= 0)
+    idx = list(range(0, batch, 4))
+    with mp.Pool() as pool:
+        want = pool.starmap(pow, [(cts[k], key.exponent(i_pos), n2) for k in idx], chunksize=8)
+    assert [partials[i_pos - 1][k] for k in idx] == want
     for k in (3, 4999, 9999):                                          # samples bit-exact vs the oracle
         for i in (1, 2, 3):
             assert partials[i - 1][k] == oracle.partial_decrypt(cts[k], n, i, key.degree, key.n_fac, key.shares[i])

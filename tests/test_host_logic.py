@@ -77,19 +77,6 @@ def test_pack_unpack_roundtrip():
     assert limbs.limbs_for(1) == 1 and limbs.limbs_for((1 << 32)) == 2 and limbs.limbs_for(0) == 1
 
 
-def test_batch_mod_inv():
-    from protocols.distributed_keygen_amd.paillier_shared_key import batch_mod_inv
-
-    rng = random.Random(5)
-    m = (rng.getrandbits(300) | 1) * (rng.getrandbits(300) | 1)
-    vals = [rng.randrange(1, m) for _ in range(50)]
-    vals = [v for v in vals if oracle.jacobi_symbol(1, 3) and __import__("math").gcd(v, m) == 1]
-    assert batch_mod_inv(vals, m) == [pow(v, -1, m) for v in vals]
-    assert batch_mod_inv([], m) == [] and batch_mod_inv([vals[0]], m) == [pow(vals[0], -1, m)]
-    with pytest.raises(ValueError):
-        batch_mod_inv([vals[0], 0, vals[1]], m)
-
-
 # ------------------------------------------------------------------ PaillierSharedKey mirror
 def _keys(grp, engine):
     from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, ShareView
@@ -153,19 +140,6 @@ def test_shared_key_mirror_error_behaviour(golden_decrypt_synth):
 
 
 # ------------------------------------------------------------------ keygen mirrors
-def test_jacobi_mirror_matches_oracle():
-    from protocols.distributed_keygen_amd.biprime import jacobi_symbol
-
-    rng = random.Random(11)
-    for bits in (3, 8, 64, 131, 2051):
-        for _ in range(80):
-            n = rng.getrandbits(bits) | 1
-            a = rng.randrange(-5, 3 * n)
-            assert jacobi_symbol(a, n) == oracle.jacobi_symbol(a, n)
-    with pytest.raises(ValueError):
-        jacobi_symbol(3, 8)
-
-
 def test_biprime_mirrors_match_reference_outputs(golden_biprime):
     from protocols.distributed_keygen_amd import biprime
 
