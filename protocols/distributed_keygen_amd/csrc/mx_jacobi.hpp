@@ -64,30 +64,24 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
       const uint32_t n8 = n[0] & 7u;
       if ((z & 1) && (n8 == 3u || n8 == 5u)) t = -t;
     }
-    // ---- a < n ?  (borrow of a - n, nothing stored)
-    uint64_t borrow = 0;
+    // ---- a < n ?  (borrow chain of a - n: v_sub_co / v_subb_co, nothing stored)
+    unsigned int borrow = 0;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) borrow = (((uint64_t)a[j] - n[j] - borrow) >> 63) & 1u;
+    for (int j = 0; j < NL; ++j) (void)__builtin_subc(a[j], n[j], borrow, &borrow);
     if (borrow) {
       // (a, n) <- (n - a, a), quadratic reciprocity for the swap
       if ((a[0] & 3u) == 3u && (n[0] & 3u) == 3u) t = -t;
-      uint64_t b = 0;
+      unsigned int b = 0;
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
         const uint32_t x = a[j];
-        const uint64_t y = (uint64_t)n[j] - x - b;
-        a[j] = (uint32_t)y;
-        b = (y >> 63) & 1u;
+        a[j] = __builtin_subc(n[j], x, b, &b);
         n[j] = x;
       }
     } else {
-      uint64_t b = 0;
+      unsigned int b = 0;
 #pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const uint64_t y = (uint64_t)a[j] - n[j] - b;
-        a[j] = (uint32_t)y;
-        b = (y >> 63) & 1u;
-      }
+      for (int j = 0; j < NL; ++j) a[j] = __builtin_subc(a[j], n[j], b, &b);
     }
   }
   uint32_t hi = 0;

@@ -134,11 +134,58 @@ def install_dependency_standins() -> None:
         def n_fac(self) -> int:
             return math.factorial(self.scheme.number_of_parties)
 
-    class ShamirShares:
-        pass
-
     class ShamirSecretSharingScheme:
-        pass
+        """Functional stand-in (prime-field Shamir) for the un-vendored scheme: enough for the
+        reference's ShamirVariable (utils.py:175-298) to share, add, multiply and reconstruct."""
+
+        def __init__(self, modulus: int, number_of_parties: int, polynomial_degree: int) -> None:
+            self.modulus = modulus
+            self.number_of_parties = number_of_parties
+            self.polynomial_degree = polynomial_degree
+
+        def share_secret(self, secret: int) -> "ShamirShares":
+            import secrets as _s
+
+            coeffs = [secret % self.modulus] + [_s.randbelow(self.modulus) for _ in range(self.polynomial_degree)]
+            shares = {
+                i: sum(c * pow(i, k, self.modulus) for k, c in enumerate(coeffs)) % self.modulus
+                for i in range(1, self.number_of_parties + 1)
+            }
+            return ShamirShares(self, shares)
+
+    class ShamirShares:
+        def __init__(self, scheme: Any, shares: dict) -> None:
+            self.scheme = scheme
+            self.shares = shares
+
+        def __add__(self, other: "ShamirShares") -> "ShamirShares":
+            m = self.scheme.modulus
+            keys = self.shares.keys() & other.shares.keys()
+            deg = max(self.scheme.polynomial_degree, other.scheme.polynomial_degree)
+            scheme = ShamirSecretSharingScheme(m, self.scheme.number_of_parties, deg)
+            return ShamirShares(scheme, {k: (self.shares[k] + other.shares[k]) % m for k in keys})
+
+        def __mul__(self, other: "ShamirShares") -> "ShamirShares":
+            m = self.scheme.modulus
+            keys = self.shares.keys() & other.shares.keys()
+            scheme = ShamirSecretSharingScheme(
+                m, self.scheme.number_of_parties, self.scheme.polynomial_degree + other.scheme.polynomial_degree
+            )
+            return ShamirShares(scheme, {k: (self.shares[k] * other.shares[k]) % m for k in keys})
+
+        def reconstruct_secret(self) -> int:
+            m = self.scheme.modulus
+            pts = sorted(self.shares.items())[: self.scheme.polynomial_degree + 1]
+            assert len(pts) == self.scheme.polynomial_degree + 1, "not enough shares"
+            total = 0
+            for i, y in pts:
+                num = den = 1
+                for j, _ in pts:
+                    if j != i:
+                        num = num * j % m
+                        den = den * (j - i) % m
+                total = (total + y * num * pow(den, -1, m)) % m
+            return total
 
     class ShamirSecretSharingIntegers:
         pass

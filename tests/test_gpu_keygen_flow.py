@@ -1,0 +1,80 @@
+"""End-to-end keygen hot path on the GPU (BASELINE.json configs[0] shape, key_length 128, 3 parties):
+rounds of candidate batches -> sieve -> Jacobi filter -> v-values of every party -> verdict, exactly
+the compute steps of compute_modulus (distributed_keygen.py:1252-1360) with the message exchanges
+replaced by local variables, until a biprime is found; then a threshold-decryption round trip with a
+key built on that modulus.  Every step runs through the batched mirrors on the device; the result
+is checked with independent host primality tests and against the oracle's verdict."""
+
+from __future__ import annotations
+
+import math
+import random
+
+import pytest
+
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def test_three_party_keygen_hot_path_finds_a_biprime():
+    from protocols.distributed_keygen_amd import Engine, biprime, synthetic
+    from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+
+    eng = Engine()
+    rng = random.Random(128)
+    n_parties, key_length, nbip, batch = 3, 128, 40, 768
+    primes = oracle.small_prime_list(2000)
+    found = None
+    tested = sieved = 0
+    for _round in range(40):
+        shares = [synthetic.candidate_shares(rng, n_parties, key_length // 2) for _ in range(batch)]
+        moduli = [sum(p) * sum(q) for p, q in shares]
+        has_div = biprime.small_prime_divisors_test_batch(primes, moduli, eng)          # DK:1288-1292
+        surv = [k for k, bad in enumerate(has_div) if not bad]
+        sieved += batch - len(surv)
+        if not surv:
+            continue
+        mods = [moduli[k] for k in surv]
+        # jointly random g: every party draws 4*40 values, summed mod N (DK:1028-1053)
+        g_values = [[sum(rng.randint(0, m) for _ in range(n_parties)) % m for _ in range(4 * nbip)] for m in mods]
+        v_all = [dict() for _ in surv]
+        for i in range(1, n_parties + 1):                                                 # DK:1313-1329 per party
+            vs = biprime.biprime_test_v_calculation_batch(
+                g_values, i, mods, [shares[k][0][i - 1] for k in surv], [shares[k][1][i - 1] for k in surv], nbip, eng
+            )
+            for slot, v in zip(v_all, vs):
+                slot[i] = v
+        verdicts = biprime.biprime_test_with_v_i_batch(v_all, mods, nbip, eng, errors="return")   # DK:1339-1360
+        tested += len(surv)
+        for k, verdict, vd in zip(surv, verdicts, v_all):
+            if isinstance(verdict, Exception):
+                continue
+            assert verdict == oracle.biprime_test_with_v_i(vd, moduli[k], nbip)
+            if verdict:
+                found = (shares[k], moduli[k])
+                break
+        if found:
+            break
+    assert found is not None, f"no biprime in {tested} tested / {sieved} sieved candidates"
+    (p_parts, q_parts), n = found
+    p, q = sum(p_parts), sum(q_parts)
+    assert p * q == n and synthetic.is_probable_prime(p, rng) and synthetic.is_probable_prime(q, rng)
+    assert sieved > 5 * tested                      # the sieve removes the bulk, as in the reference's counters
+
+    # threshold decryption on the freshly generated modulus (structure of DK:1364-1500)
+    n_fac = math.factorial(n_parties)
+    lam, beta = n - p - q + 1, rng.randrange(n)
+    bound = n_fac**2 * (1 << 40) * n * n_parties
+    fl = [n_fac * lam, rng.randrange(-bound, bound)]
+    fb = [n_fac * beta, rng.randrange(-bound, bound)]
+    ev = lambda f, x: f[0] + f[1] * x  # noqa: E731
+    share_vals = {i: ev(fl, i) * ev(fb, i) for i in (1, 2, 3)}
+    theta = lam * beta * n_fac**3 % n
+    if math.gcd(theta, n) != 1:
+        pytest.skip("theta not invertible for this seed")
+    keys = {i: GpuPaillierSharedKey(n, 1, i, ShareView({i: share_vals[i]}, 2, n_fac), theta, engine=eng) for i in (1, 2, 3)}
+    msgs = [0, 1, n - 1, 31337, rng.randrange(n)]
+    cts = eng.encrypt_batch(msgs, [rng.randrange(1, n) for _ in msgs], n)
+    parts = {i: k.partial_decrypt_batch([PlainCiphertext(c, n) for c in cts]) for i, k in keys.items()}
+    assert keys[2].decrypt_batch([{i: parts[i][e] for i in keys} for e in range(len(cts))]) == msgs

@@ -178,3 +178,73 @@ def test_patched_keygen_classmethods_match_originals(ref, golden_biprime):
     finally:
         patch.uninstall()
     assert getattr(DP, "_DistributedPaillier__small_prime_divisors_test")([3], 9) is True
+
+
+class FullPool(FakePool):
+    """+ the point-to-point call the keygen path uses (utils.py:528-553)."""
+
+    def asend(self, party, message, msg_id=None):
+        self.hub.box[party].setdefault(msg_id, []).append((self.me, message))
+
+
+def _run_compute_modulus(ref, seed, batch_size):
+    """Three in-process parties run the reference class-method DistributedPaillier.compute_modulus
+    (patched or not) over an in-memory pool with seeded randomness."""
+    import random as _random
+    import secrets as _secrets
+
+    _, dk, _ = ref
+    DP = dk.DistributedPaillier
+    rng = _random.Random(seed)
+    saved = (_secrets.randbits, _secrets.randbelow, dk.randint)
+    _secrets.randbits = rng.getrandbits
+    _secrets.randbelow = lambda n: rng.randrange(n)
+    dk.secrets.randbits = rng.getrandbits
+    dk.randint = rng.randint
+    try:
+        names = ["p1", "p2", "p3"]
+        hub = Hub(names)
+        key_length, t = 64, 1
+
+        async def party(i, me):
+            pool = FullPool(hub, me)
+            party_indices = {("self" if n == me else n): k for k, n in enumerate(names, start=1)}
+            n_players, prime_length, prime_list, sh_t, sh_2t, shares = DP.setup_input(pool, key_length, 200, t)
+            return await DP.compute_modulus(
+                shares, i, pool, prime_list, party_indices, prime_length, sh_t, sh_2t, 20, 7, batch_size
+            )
+
+        async def run():
+            return await asyncio.gather(*[party(i, me) for i, me in enumerate(names, start=1)])
+
+        return asyncio.run(run())
+    finally:
+        _secrets.randbits, _secrets.randbelow, dk.randint = saved
+        dk.secrets.randbits = saved[0]
+
+
+def test_compute_modulus_is_drop_in(ref):
+    """The reference's own keygen loop (compute_modulus, DK:1211-1362) with and without the patch:
+    same seeded candidates -> the same biprime modulus, found with one launch per step and round."""
+    import sympy
+
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import patch
+
+    base = _run_compute_modulus(ref, seed=11, batch_size=40)
+    assert len(set(base)) == 1
+    n = base[0]
+    f = sympy.factorint(n)
+    assert len(f) == 2 and all(e == 1 for e in f.values())            # a true biprime
+    eng = FakeEngine()
+    patch.install(engine=eng)
+    try:
+        got = _run_compute_modulus(ref, seed=11, batch_size=40)
+    finally:
+        patch.uninstall()
+    assert got == base
+    kinds = {c[0] for c in eng.calls}
+    assert {"sieve_batch", "jacobi_batch", "powmod_batch_multi", "biprime_verdict_batch"} <= kinds
+    rounds = sum(1 for c in eng.calls if c[0] == "sieve_batch") // 3
+    assert all(c[1] == 40 for c in eng.calls if c[0] == "sieve_batch")      # whole round in one call
+    assert sum(1 for c in eng.calls if c[0] == "powmod_batch_multi") <= 3 * rounds
