@@ -33,6 +33,11 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # measured on MI355X: v_mad_u64_u32, 8 waves/SIMD, 2.085 ns per wave-instruction per SIMD
 # (profiles/r01_ubench_valu_rates.txt)  ->  1024 SIMDs * 64 lanes / 2.085 ns
 VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
+# HBM bytes per powmod launch of the default workload, from the rocprofv3 --pmc passes committed in
+# profiles/r01_bench_default_3inflight_rocprof_summary.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB
+# (FETCH_SIZE counts half of wide coalesced reads on gfx950, MI355X guide).  It is the window
+# table: 737 MB written once and ~3.3 GB of coalesced digit look-ups per 10 000 modexps.
+MEASURED_TRAFFIC_DEFAULT = (2 * 1586450 + 768345) * 1024
 
 
 def parse() -> argparse.Namespace:
@@ -103,12 +108,19 @@ def main() -> None:
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+    # one process per GPU; MX_BENCH_BACKEND=gloo lets several ranks share one GPU (single-GPU smoke
+    # test of the multi-rank code path; RCCL refuses two ranks on one device)
+    backend = os.environ.get("MX_BENCH_BACKEND", "nccl")
+    local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist  # type: ignore
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
@@ -241,7 +253,9 @@ def main() -> None:
                 "bound": "hbm",
                 "kernel": "mx::powmod_kernel<%d,%d,29>" % tuple(eng.geometry(n2.bit_length())[:2]),
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS, "traffic": None,
+                "frac": achieved_gbs / HBM_PEAK_GBS,
+                "traffic": MEASURED_TRAFFIC_DEFAULT if (batch == 10000 and args.key_length == 2048) else None,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/ (not collected live)",
                 "kernel_ms": powmod_ms, "concurrent_launches": nstreams,
                 "algorithmic_bytes_per_launch": alg_bytes,
                 "note": "integer-VALU-bound path (north_star: no MFMA); the HBM fraction is reported as asked "

@@ -29,14 +29,12 @@ enum : int {
   DPP_QUAD_0000 = 0x00,   // quad_perm:[0,0,0,0]
   DPP_QUAD_0022 = 0xA0,   // quad_perm:[0,0,2,2]
   DPP_QUAD_1133 = 0xF5,   // quad_perm:[1,1,3,3]
-  DPP_QUAD_0022s = 0xA0,
   DPP_ROW_SHL1 = 0x101,   // lane i <- lane i+1 within a row
   DPP_ROW_SHR1 = 0x111,   // lane i <- lane i-1 within a row
   DPP_ROW_SHR4 = 0x114,
   DPP_WAVE_SHL1 = 0x130,  // lane i <- lane i+1 across the wave
   DPP_WAVE_SHR1 = 0x138,  // lane i <- lane i-1 across the wave
   DPP_ROW_BCAST15 = 0x142,  // lane 15 of each row -> every lane of the next row
-  DPP_ROW_BCAST31 = 0x143,  // lane 31 -> rows 2,3
   DPP_ROW_NEWBCAST0 = 0x150,  // lane 0 of each row -> every lane of the row (gfx90a+)
 };
 
