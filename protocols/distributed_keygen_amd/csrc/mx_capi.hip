@@ -61,8 +61,9 @@ struct PowmodPlan {
   Geometry geo;
   int win = 1;
   int64_t nblocks = 0, nlanes = 0;
-  int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_table = 0, total = 0;
+  int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_ops = 0, off_table = 0, total = 0;
 };
+constexpr int MAX_SLIDING_OPS = 16384;   // covers exponents up to 16384 bits
 
 bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p,
                  int limbs_per_lane = 0) {
@@ -76,6 +77,7 @@ bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t 
   p.off_mods = o;  o += align256((int64_t)groups * limbs * 4);
   p.off_rmodn = o; o += align256((int64_t)groups * limbs * 4);
   p.off_exps = o;  o += align256((int64_t)groups * (exp_limbs + 1) * 4);
+  p.off_ops = o;   o += align256((int64_t)MAX_SLIDING_OPS * 4);
   p.off_table = o; o += align256(((int64_t)1 << p.win) * p.geo.L * p.nlanes * 4);
   p.total = o;
   return true;
@@ -144,6 +146,19 @@ int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods
   a.table = (u32*)(ws + p.off_table);
   a.batch = batch; a.group_size = group_size;
   a.limbs = limbs; a.elimbs = exp_limbs; a.ndigits = ndigits; a.win = p.win; a.nblk = p.geo.nblk;
+  a.ops = nullptr; a.nops = 0;
+  if (groups == 1 && max_ebits > 0) {
+    // one exponent for the whole launch: sliding window (odd powers only)
+    int w = sliding_window(max_ebits);
+    if (w > p.win) w = p.win;                       // the table region was sized for 2^win entries
+    std::vector<u32> ops = sliding_schedule(h_exps, exp_limbs, w);
+    if ((int)ops.size() <= MAX_SLIDING_OPS) {
+      MX_TRY(upload_words(ws + p.off_ops, ops.data(), ops.size(), s));
+      a.ops = (const u32*)(ws + p.off_ops);
+      a.nops = (int)ops.size();
+      a.win = w;
+    }
+  }
   switch (p.geo.K) {
     case 1: return launch_powmod_k<1>(a, p.nblocks, p.geo.L, s);
     case 2: return launch_powmod_k<2>(a, p.nblocks, p.geo.L, s);

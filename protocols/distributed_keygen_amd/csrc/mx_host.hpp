@@ -102,6 +102,39 @@ inline int fixed_window(int exp_bits) {
   return best;
 }
 
+inline int sliding_window(int exp_bits) {
+  // minimise 2^(w-1) table products + bits/(w+1) expected multiplications
+  int best = 1;
+  double bestc = -1;
+  for (int w = 1; w <= 8; ++w) {
+    double c = (double)(1L << (w - 1)) + (double)exp_bits / (w + 1);
+    if (bestc < 0 || c < bestc) { bestc = c; best = w; }
+  }
+  return best;
+}
+
+// Left-to-right sliding-window schedule of a non-zero exponent: ops[k] = (squarings << 16) |
+// (index of the odd power + 1), index + 1 == 0 for the trailing squarings.  ops[0] only loads.
+inline std::vector<u32> sliding_schedule(const u32* e, int limbs, int w) {
+  std::vector<u32> ops;
+  int bits = bit_length(e, limbs);
+  auto bit = [&](int i) { return (e[i >> 5] >> (i & 31)) & 1u; };
+  int i = bits - 1, pending = 0;
+  while (i >= 0) {
+    if (!bit(i)) { ++pending; --i; continue; }
+    int l = (i + 1 < w) ? i + 1 : w;
+    while (!bit(i - l + 1)) --l;
+    u32 val = 0;
+    for (int k = 0; k < l; ++k) val = (val << 1) | bit(i - k);
+    u32 idx1 = (val - 1) / 2 + 1;
+    ops.push_back(ops.empty() ? idx1 : (((u32)(pending + l) << 16) | idx1));
+    pending = 0;
+    i -= l;
+  }
+  if (pending) ops.push_back((u32)pending << 16);
+  return ops;
+}
+
 // Which limbs-per-lane to run a modexp batch with.  The wide geometry spends a larger share of its
 // instructions on multiply-accumulates (the per-limb bookkeeping is amortised over 2L MACs) but
 // puts half as many lanes on the machine; it pays once the batch still fills every SIMD with

@@ -28,6 +28,11 @@ struct PowmodArgs {
   int ndigits;        // ceil(max exponent bits / win), >= 1
   int win;            // window width in bits
   int nblk;
+  // Sliding-window schedule (shared exponent only, i.e. one group): nops > 0 selects it.
+  // ops[k] = (squarings << 16) | (table index + 1); table index + 1 == 0: no multiplication.
+  // The table then holds the odd powers x^(2k+1), k < 2^(win-1).
+  const u32* ops;
+  int nops;
 };
 
 template <int K, int L, int W>
@@ -55,8 +60,45 @@ __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs 
   M.load(x, A.bases + elem * A.limbs, A.limbs);
   M.mul(x, x, r2);                                   // x = base * R mod N (lazy)
 
-  // window table: tbl[0] = 1, tbl[1] = x, tbl[k] = tbl[k-1] * x
   u32* tbl = A.table + gl;
+  if (A.nops > 0) {
+    // ---- sliding window over a shared exponent: odd powers only, multiplications only where
+    // the exponent has a window (the schedule is the same for every lane: uniform control flow)
+    u32 x2[L], y[L];
+    M.mul(x2, x, x);
+#pragma unroll
+    for (int j = 0; j < L; ++j) { y[j] = x[j]; tbl[(i64)j * nlanes] = x[j]; }
+    const int nodd = 1 << (A.win - 1);
+    for (int k = 1; k < nodd; ++k) {
+      M.mul(y, y, x2);
+#pragma unroll
+      for (int j = 0; j < L; ++j) tbl[((i64)k * L + j) * nlanes] = y[j];
+    }
+    u32 acc[L];
+    {
+      const u32 first = A.ops[0] & 0xFFFFu;
+#pragma unroll
+      for (int j = 0; j < L; ++j) acc[j] = tbl[((i64)(first - 1) * L + j) * nlanes];
+    }
+    for (int k = 1; k < A.nops; ++k) {
+      const u32 op = A.ops[k];
+      const int nsq = (int)(op >> 16);
+      const u32 idx1 = op & 0xFFFFu;
+      u32 f[L];
+      if (idx1) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) f[j] = tbl[((i64)(idx1 - 1) * L + j) * nlanes];
+      }
+      for (int s = 0; s < nsq; ++s) M.mul(acc, acc, acc);
+      if (idx1) M.mul(acc, acc, f);
+    }
+    u32 res[L];
+    M.from_mont_canonical(res, acc);
+    M.store(A.out + elem * A.limbs, A.limbs, res, valid);
+    return;
+  }
+
+  // ---- fixed window (per-group exponents): tbl[0] = 1, tbl[1] = x, tbl[k] = tbl[k-1] * x
   const int nent = 1 << A.win;
 #pragma unroll
   for (int j = 0; j < L; ++j) tbl[(i64)j * nlanes] = one_m[j];
