@@ -206,7 +206,15 @@ struct Mont {
   // r = a * b / R mod N (lazy: r < 2N when a, b < 4N).  r may alias a or b.
   // If RECORD_Q, the quotient digits q_i are kept (limb i of Q lives in the lane/slot that owns
   // limb i) — used by the exact division in the share-combine kernel.
-  template <bool RECORD_Q = false>
+  //
+  // SQUARE (b is a): the product part uses the symmetry a_u a_v = a_v a_u without moving any data.
+  // At the unrolled step i of a block (multiplier limb u with u mod L == i) a lane only multiplies
+  // its slots j whose cyclic distance d = (j - i) mod L is <= L/2: with weight 2 for 0 < d < L/2 and
+  // weight 1 for d == 0 (and d == L/2 when L is even).  For u != v exactly one of the two orders
+  // has distance < L/2 (weight 2), or both have distance 0 or L/2 (weight 1 + 1); u == v is met once
+  // with weight 1 — so every term of a^2 gets its coefficient, the selection is the same in every
+  // lane (compile-time register indices), and floor(L/2)+1 instead of L product MACs are issued.
+  template <bool RECORD_Q = false, bool SQUARE = false>
   __device__ __forceinline__ void mul(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], u32* qrec = nullptr) {
     // stage b where every lane of the group can read any limb of it
     __syncthreads();
@@ -228,14 +236,24 @@ struct Mont {
 #pragma unroll
       for (int i = 0; i < L; ++i) {
         const u32 bi = bb[i];
-        t[0] += (u64)a[0] * bi;
+        const u32 bi2 = bi << 1;                       // only used by SQUARE
+        // weight of slot j at step i: 0 = skip, 1 = a_j * b_i, 2 = a_j * 2 b_i
+        auto weight = [](int j, int i_) constexpr -> int {
+          if constexpr (!SQUARE) return 1;
+          int d = (j - i_ + L) % L;
+          if (d == 0 || (L % 2 == 0 && d == L / 2)) return 1;
+          return (2 * d < L) ? 2 : 0;
+        };
+        if (weight(0, i) == 1) t[0] += (u64)a[0] * bi;
+        if (weight(0, i) == 2) t[0] += (u64)a[0] * bi2;
         // the mask is applied after the broadcast so that it folds into the DPP move (v_and_b32_dpp)
         const u32 q = LN::bcast0((u32)t[0] * n0inv) & maskv;
         if constexpr (RECORD_Q) qr[i] = (blk == p) ? q : qr[i];
         t[0] += (u64)n[0] * q;
 #pragma unroll
         for (int j = 1; j < L; ++j) {
-          t[j] += (u64)a[j] * bi;
+          if (weight(j, i) == 1) t[j] += (u64)a[j] * bi;
+          if (weight(j, i) == 2) t[j] += (u64)a[j] * bi2;
           t[j] += (u64)n[j] * q;
         }
         // divide by 2^W: column 0 leaves; its low W bits belong to the lower neighbour's top
@@ -255,6 +273,9 @@ struct Mont {
     }
   }
 
+  // r = a^2 / R mod N (lazy), with the symmetric product
+  __device__ __forceinline__ void sqr(u32 (&r)[L], const u32 (&a)[L]) { mul<false, true>(r, a, a); }
+
   // ------------------------------------------------------------------ constants
   // one: the integer 1 (limb 0 of the group's lane 0)
   __device__ __forceinline__ void set_small(u32 (&x)[L], u32 v) const {
@@ -272,7 +293,7 @@ struct Mont {
     for (int j = 0; j < L; ++j) x[j] = rmodn[j];
     int top = 31 - __builtin_clz((unsigned)m);
     for (int bit = top; bit >= 0; --bit) {
-      if (bit != top) mul(x, x, x);
+      if (bit != top) sqr(x, x);
       if ((m >> bit) & 1) add(x, x, x);
     }
 #pragma unroll

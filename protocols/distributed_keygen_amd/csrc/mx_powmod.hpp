@@ -65,7 +65,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs 
     // ---- sliding window over a shared exponent: odd powers only, multiplications only where
     // the exponent has a window (the schedule is the same for every lane: uniform control flow)
     u32 x2[L], y[L];
-    M.mul(x2, x, x);
+    M.sqr(x2, x);
 #pragma unroll
     for (int j = 0; j < L; ++j) { y[j] = x[j]; tbl[(i64)j * nlanes] = x[j]; }
     const int nodd = 1 << (A.win - 1);
@@ -89,7 +89,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs 
 #pragma unroll
         for (int j = 0; j < L; ++j) f[j] = tbl[((i64)(idx1 - 1) * L + j) * nlanes];
       }
-      for (int s = 0; s < nsq; ++s) M.mul(acc, acc, acc);
+      for (int s = 0; s < nsq; ++s) M.sqr(acc, acc);
       if (idx1) M.mul(acc, acc, f);
     }
     u32 res[L];
@@ -135,7 +135,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs 
     u32 y[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) y[j] = tbl[((i64)dg * L + j) * nlanes];   // issued early, used after the squarings
-    for (int s = 0; s < A.win; ++s) M.mul(acc, acc, acc);
+    for (int s = 0; s < A.win; ++s) M.sqr(acc, acc);
     M.mul(acc, acc, y);
   }
 
