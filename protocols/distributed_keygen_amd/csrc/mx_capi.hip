@@ -87,7 +87,10 @@ template <int K, int L>
 int launch_powmod_kl(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
   using M_t = mx::Mont<K, L, LIMB_BITS, true>;
   size_t lds = (size_t)(64 / K) * M_t::LDS_WORDS * 4;
-  hipLaunchKernelGGL((mx::powmod_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  if (a.nops > 0)
+    hipLaunchKernelGGL((mx::powmod_kernel<K, L, LIMB_BITS, true>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  else
+    hipLaunchKernelGGL((mx::powmod_kernel<K, L, LIMB_BITS, false>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
 }

@@ -35,7 +35,9 @@ struct PowmodArgs {
   int nops;
 };
 
-template <int K, int L, int W>
+// SLIDING = the shared-exponent schedule (A.ops), otherwise the fixed window with per-group digits;
+// two kernels rather than one branch so that neither carries the other's register pressure.
+template <int K, int L, int W, bool SLIDING>
 __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs A) {
   using M_t = Mont<K, L, W, true>;
   extern __shared__ u32 smem[];
@@ -61,7 +63,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs 
   M.mul(x, x, r2);                                   // x = base * R mod N (lazy)
 
   u32* tbl = A.table + gl;
-  if (A.nops > 0) {
+  if constexpr (SLIDING) {
     // ---- sliding window over a shared exponent: odd powers only, multiplications only where
     // the exponent has a window (the schedule is the same for every lane: uniform control flow)
     u32 x2[L], y[L];
@@ -84,20 +86,25 @@ __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs 
       const u32 op = A.ops[k];
       const int nsq = (int)(op >> 16);
       const u32 idx1 = op & 0xFFFFu;
+      // narrow geometry: the table row is requested before the squarings and used after them
+      // (latency fully hidden); wide geometry: registers are the scarcer resource, so the row is
+      // fetched after the squarings (one exposed L2/HBM round trip per ~8 Montgomery products)
       u32 f[L];
-      if (idx1) {
+      if (L <= 9 && idx1) {
 #pragma unroll
         for (int j = 0; j < L; ++j) f[j] = tbl[((i64)(idx1 - 1) * L + j) * nlanes];
       }
       for (int s = 0; s < nsq; ++s) M.sqr(acc, acc);
+      if (L > 9 && idx1) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) f[j] = tbl[((i64)(idx1 - 1) * L + j) * nlanes];
+      }
       if (idx1) M.mul(acc, acc, f);
     }
     u32 res[L];
     M.from_mont_canonical(res, acc);
     M.store(A.out + elem * A.limbs, A.limbs, res, valid);
-    return;
-  }
-
+  } else {
   // ---- fixed window (per-group exponents): tbl[0] = 1, tbl[1] = x, tbl[k] = tbl[k-1] * x
   const int nent = 1 << A.win;
 #pragma unroll
@@ -142,6 +149,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs 
   u32 res[L];
   M.from_mont_canonical(res, acc);
   M.store(A.out + elem * A.limbs, A.limbs, res, valid);
+  }
 }
 
 }  // namespace mx
