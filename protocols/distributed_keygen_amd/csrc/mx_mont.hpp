@@ -26,6 +26,7 @@
 // (reference: distributed_keygen.py:1094,1097; paillier_shared_key.py:92,115-125).
 #pragma once
 #include "mx_lanes.hpp"
+#include <utility>
 
 namespace mx {
 
@@ -202,6 +203,66 @@ struct Mont {
     normalize_weak(r, t);
   }
 
+  // ------------------------------------------------------------------ one block of L limbs, unrolled by templates
+  // weight of slot J at step I of a block: 0 = skip, 1 = a_J * b_I, 2 = a_J * 2 b_I (see SQUARE below)
+  template <bool SQUARE, int I, int J>
+  static constexpr int slot_weight() {
+    if (!SQUARE) return 1;
+    constexpr int d = (J - I + L) % L;
+    if (d == 0 || (L % 2 == 0 && d == L / 2)) return 1;
+    return (2 * d < L) ? 2 : 0;
+  }
+
+  template <bool SQUARE, int I, int J>
+  __device__ __forceinline__ void product_mac(u64 (&t)[L], const u32 (&a)[L], u32 bi, u32 bi2) const {
+    constexpr int w = slot_weight<SQUARE, I, J>();
+    if constexpr (w == 1) t[J] += (u64)a[J] * bi;
+    if constexpr (w == 2) t[J] += (u64)a[J] * bi2;
+  }
+
+  // slot J >= 1 of step I: product term (if selected) and reduction term
+  template <bool SQUARE, int I, int J>
+  __device__ __forceinline__ void slot_macs(u64 (&t)[L], const u32 (&a)[L], u32 bi, u32 bi2, u32 q) const {
+    if constexpr (J != 0) {
+      product_mac<SQUARE, I, J>(t, a, bi, bi2);
+      t[J] += (u64)n[J] * q;
+    }
+  }
+
+  template <bool SQUARE, int I, int... Js>
+  __device__ __forceinline__ void row_macs(u64 (&t)[L], const u32 (&a)[L], u32 bi, u32 bi2, u32 q,
+                                           std::integer_sequence<int, Js...>) const {
+    (slot_macs<SQUARE, I, Js>(t, a, bi, bi2, q), ...);
+  }
+
+  template <bool RECORD_Q, bool SQUARE, int I>
+  __device__ __forceinline__ void limb_step(u64 (&t)[L], const u32 (&a)[L], const u32 (&bb)[L],
+                                            const u32 (&bb2)[L], u32 (&qr)[L], int blk) const {
+    const u32 bi = bb[I];
+    const u32 bi2 = bb2[I];
+    product_mac<SQUARE, I, 0>(t, a, bi, bi2);
+    // the mask is applied after the broadcast so that it folds into the DPP move (v_and_b32_dpp)
+    const u32 q = LN::bcast0((u32)t[0] * n0inv) & maskv;
+    if constexpr (RECORD_Q) qr[I] = (blk == p) ? q : qr[I];
+    t[0] += (u64)n[0] * q;
+    row_macs<SQUARE, I>(t, a, bi, bi2, q, std::make_integer_sequence<int, L>{});
+    // divide by 2^W: column 0 leaves; its low W bits belong to the lower neighbour's top column
+    // (zero for the group's lane 0 by construction of q), the rest carries into column 1
+    const u64 carry = t[0] >> W;
+    const u32 recv = LN::from_next_raw((u32)t[0]) & next_mask;
+    t[0] = t[1] + carry;
+#pragma unroll
+    for (int j = 1; j < L - 1; ++j) t[j] = t[j + 1];
+    t[L - 1] = recv;
+  }
+
+  template <bool RECORD_Q, bool SQUARE, int... Is>
+  __device__ __forceinline__ void block_steps(u64 (&t)[L], const u32 (&a)[L], const u32 (&bb)[L],
+                                              const u32 (&bb2)[L], u32 (&qr)[L], int blk,
+                                              std::integer_sequence<int, Is...>) const {
+    (limb_step<RECORD_Q, SQUARE, Is>(t, a, bb, bb2, qr, blk), ...);
+  }
+
   // ------------------------------------------------------------------ Montgomery product
   // r = a * b / R mod N (lazy: r < 2N when a, b < 4N).  r may alias a or b.
   // If RECORD_Q, the quotient digits q_i are kept (limb i of Q lives in the lane/slot that owns
@@ -225,46 +286,17 @@ struct Mont {
 #pragma unroll
     for (int j = 0; j < L; ++j) t[j] = 0;
     u32 qr[L];
-    if constexpr (RECORD_Q) {
 #pragma unroll
-      for (int j = 0; j < L; ++j) qr[j] = 0;
-    }
+    for (int j = 0; j < L; ++j) qr[j] = 0;
     for (int blk = 0; blk < nblk; ++blk) {
-      u32 bb[L];
+      u32 bb[L], bb2[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];
+      // doubled multiplier limbs for the weight-2 products of a squaring (a shift is cheaper than a
+      // second LDS copy of b: measured)
 #pragma unroll
-      for (int i = 0; i < L; ++i) {
-        const u32 bi = bb[i];
-        const u32 bi2 = bi << 1;                       // only used by SQUARE
-        // weight of slot j at step i: 0 = skip, 1 = a_j * b_i, 2 = a_j * 2 b_i
-        auto weight = [](int j, int i_) constexpr -> int {
-          if constexpr (!SQUARE) return 1;
-          int d = (j - i_ + L) % L;
-          if (d == 0 || (L % 2 == 0 && d == L / 2)) return 1;
-          return (2 * d < L) ? 2 : 0;
-        };
-        if (weight(0, i) == 1) t[0] += (u64)a[0] * bi;
-        if (weight(0, i) == 2) t[0] += (u64)a[0] * bi2;
-        // the mask is applied after the broadcast so that it folds into the DPP move (v_and_b32_dpp)
-        const u32 q = LN::bcast0((u32)t[0] * n0inv) & maskv;
-        if constexpr (RECORD_Q) qr[i] = (blk == p) ? q : qr[i];
-        t[0] += (u64)n[0] * q;
-#pragma unroll
-        for (int j = 1; j < L; ++j) {
-          if (weight(j, i) == 1) t[j] += (u64)a[j] * bi;
-          if (weight(j, i) == 2) t[j] += (u64)a[j] * bi2;
-          t[j] += (u64)n[j] * q;
-        }
-        // divide by 2^W: column 0 leaves; its low W bits belong to the lower neighbour's top
-        // column (zero for the group's lane 0 by construction of q), the rest carries into column 1
-        u64 carry = t[0] >> W;
-        const u32 recv = LN::from_next_raw((u32)t[0]) & next_mask;
-        t[0] = t[1] + carry;
-#pragma unroll
-        for (int j = 1; j < L - 1; ++j) t[j] = t[j + 1];
-        t[L - 1] = recv;
-      }
+      for (int j = 0; j < L; ++j) bb2[j] = SQUARE ? (bb[j] << 1) : 0u;
+      block_steps<RECORD_Q, SQUARE>(t, a, bb, bb2, qr, blk, std::make_integer_sequence<int, L>{});
     }
     normalize_weak(r, t);
     if constexpr (RECORD_Q) {
