@@ -34,10 +34,11 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # (profiles/r01_ubench_valu_rates.txt)  ->  1024 SIMDs * 64 lanes / 2.085 ns
 VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
 # HBM bytes per powmod launch of the default workload, from the rocprofv3 --pmc passes committed in
-# profiles/r01_bench_default_3inflight_rocprof_summary.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB
+# profiles/r01_bench_single_stream_rocprof_summary.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB
 # (FETCH_SIZE counts half of wide coalesced reads on gfx950, MI355X guide).  It is the window
-# table: 737 MB written once and ~3.3 GB of coalesced digit look-ups per 10 000 modexps.
-MEASURED_TRAFFIC_DEFAULT = (2 * 1586450 + 768345) * 1024
+# table (64 odd powers per ciphertext): 369 MB written once and ~2.5 GB of coalesced look-ups per
+# 10 000 modexps; the wide and the narrow geometry move the same bytes.
+MEASURED_TRAFFIC_DEFAULT = (2 * 1214063 + 365078) * 1024
 
 
 def parse() -> argparse.Namespace:
