@@ -22,7 +22,7 @@ def main() -> None:
     ap.add_argument("--count", type=int, default=1000)
     args = ap.parse_args()
     from protocols.distributed_keygen_amd import Engine, synthetic
-    from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
 
     eng = Engine()
     key = synthetic.make_key(args.key_length, 3, 1)

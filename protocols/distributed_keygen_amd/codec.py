@@ -88,7 +88,7 @@ def load_stored_key(blob: bytes, engine: Any = None) -> Tuple[Any, Dict[str, Any
     corruption_threshold)."""
     import msgpack
 
-    from .paillier_shared_key import GpuPaillierSharedKey, ShareView
+    from .shared_key import GpuPaillierSharedKey, ShareView
 
     obj = decode_tree(msgpack.unpackb(blob, strict_map_key=False)["object"])
     pk = obj["priv_key"]

@@ -27,7 +27,7 @@ import importlib
 from typing import Any, Dict, Iterable, List, Optional
 
 from . import biprime
-from .paillier_shared_key import GpuPaillierSharedKey
+from .shared_key import GpuPaillierSharedKey
 
 DEFAULT_PACKAGE = "tno.mpc.protocols.distributed_keygen"
 _saved: Dict[Any, Dict[str, Any]] = {}

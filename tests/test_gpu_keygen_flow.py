@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 
 def test_three_party_keygen_hot_path_finds_a_biprime():
     from protocols.distributed_keygen_amd import Engine, biprime, synthetic
-    from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
 
     eng = Engine()
     rng = random.Random(128)

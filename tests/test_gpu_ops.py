@@ -177,7 +177,7 @@ def test_mulmod_and_modinv(eng, bits, batch):
 
 
 def test_encrypt_batch_and_negative_exponent_party(eng, golden_decrypt_synth):
-    from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
 
     grp = golden_decrypt_synth["k2048_n3_t1"]
     n = unhex(grp["n"])

@@ -79,7 +79,7 @@ def test_pack_unpack_roundtrip():
 
 # ------------------------------------------------------------------ PaillierSharedKey mirror
 def _keys(grp, engine):
-    from protocols.distributed_keygen_amd.paillier_shared_key import GpuPaillierSharedKey, ShareView
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, ShareView
 
     n = unhex(grp["n"])
     return {
@@ -93,7 +93,7 @@ def _keys(grp, engine):
 
 
 def test_shared_key_mirror_matches_reference_outputs(golden_ref_keys, golden_decrypt_synth):
-    from protocols.distributed_keygen_amd.paillier_shared_key import PlainCiphertext
+    from protocols.distributed_keygen_amd.shared_key import PlainCiphertext
 
     eng = FakeEngine()
     for src in (golden_ref_keys, golden_decrypt_synth):
@@ -120,7 +120,7 @@ def test_shared_key_mirror_matches_reference_outputs(golden_ref_keys, golden_dec
 
 
 def test_shared_key_mirror_error_behaviour(golden_decrypt_synth):
-    from protocols.distributed_keygen_amd.paillier_shared_key import PlainCiphertext
+    from protocols.distributed_keygen_amd.shared_key import PlainCiphertext
 
     grp = golden_decrypt_synth["k128_n3_t1"]
     keys = _keys(grp, FakeEngine())
@@ -209,7 +209,7 @@ def test_load_stored_reference_keys_and_decrypt(golden_ref_keys):
     """The reference's own stored test keys (tests/golden/ref_keys/*.obj) load into the mirror and
     decrypt the recorded ciphertexts."""
     from protocols.distributed_keygen_amd import codec
-    from protocols.distributed_keygen_amd.paillier_shared_key import PlainCiphertext
+    from protocols.distributed_keygen_amd.shared_key import PlainCiphertext
 
     eng = FakeEngine()
     keydir = ROOT / "tests" / "golden" / "ref_keys"
