@@ -225,3 +225,37 @@ def test_load_stored_reference_keys_and_decrypt(golden_ref_keys):
         partials = {i: k.partial_decrypt_batch(cts) for i, k in keys.items()}
         dicts = [{i: partials[i][e] for i in keys} for e in range(len(cts))]
         assert keys[1].decrypt_batch(dicts) == [unhex(m) for m in grp["plaintexts"]]
+
+
+# ------------------------------------------------------------------ C ABI argument validation (returns before any HIP call)
+def test_c_abi_status_codes_without_gpu():
+    import ctypes
+
+    from protocols.distributed_keygen_amd import _lib, limbs
+
+    lib = _lib.lib()
+    fake = ctypes.c_void_p(0x1000)          # never dereferenced: every case below fails validation first
+    mod = limbs.pack_one((1 << 200) + 235, 8)
+    even = limbs.pack_one(1 << 200, 8)
+    exp = limbs.pack_one(65537, 1)
+    p = lambda a: a.ctypes.data  # noqa: E731
+    assert lib.mx_powmod_shared(None, fake, p(mod), p(exp), 8, 1, 4, fake, 1 << 30, None) == -1          # MX_ERR_ARG
+    assert lib.mx_powmod_shared(fake, fake, p(mod), p(exp), 0, 1, 4, fake, 1 << 30, None) == -1
+    assert lib.mx_powmod_shared(fake, fake, p(even), p(exp), 8, 1, 4, fake, 1 << 30, None) == -3         # MX_ERR_MODULUS
+    assert lib.mx_powmod_shared(fake, fake, p(mod), p(exp), 8, 1, 4, fake, 16, None) == -4               # MX_ERR_WORKSPACE
+    huge = limbs.pack_one((1 << 16800) + 1, 526)
+    assert lib.mx_powmod_shared(fake, fake, p(huge), p(exp), 526, 1, 4, fake, 1 << 40, None) == -2       # MX_ERR_SIZE
+    assert lib.mx_powmod_multi(fake, fake, p(mod), p(exp), 8, 1, 1, 0, fake, 1 << 30, None) == -1
+    primes = np.array([3, 5, 2], dtype=np.uint32)
+    assert lib.mx_sieve(fake, fake, p(primes), 3, 8, 4, fake, 1 << 30, None) == -1                       # even "prime"
+    assert lib.mx_sieve(fake, fake, p(primes), 2, 8, 4, fake, 8, None) == -4
+    assert lib.mx_combine(fake, fake, fake, p(even), p(mod), 8, 16, 3, 4, fake, 1 << 30, None) == -3
+    assert lib.mx_combine(fake, fake, fake, p(mod), p(mod), 8, 8, 3, 4, fake, 1 << 30, None) == -1       # rows too narrow for N^2
+    assert lib.mx_biprime_verdict(fake, fake, p(even), 8, 3, 1, 40, fake, 1 << 30, None) == -3
+    assert lib.mx_jacobi(fake, fake, p(even), 8, 1, 4, fake, 1 << 30, None) == -3
+    assert lib.mx_jacobi(fake, fake, p(mod), 130, 1, 4, fake, 1 << 30, None) == -2
+    assert lib.mx_mulmod_shared(fake, fake, fake, p(even), 8, 4, fake, 1 << 30, None) == -3
+    assert lib.mx_set_limbs_per_lane(7) == -1 and lib.mx_set_limbs_per_lane(0) == 0
+    assert lib.mx_sieve_workspace_bytes(65, 302) > 0 and lib.mx_combine_workspace_bytes(65, 129, 3, 10) > 0
+    assert lib.mx_verdict_workspace_bytes(65, 3, 10, 40) > 0 and lib.mx_jacobi_workspace_bytes(65, 10) > 0
+    assert lib.mx_mulmod_workspace_bytes(129) > 0
