@@ -1,0 +1,78 @@
+"""Adversarial / randomized differential tests of the modexp engine on the GPU: operands built to
+stress the lazy-carry machinery (all-ones limbs in radix 2^29 and 2^32, moduli 2^k +- small, sparse
+exponents, dense exponents) across every lane geometry, both limb widths per lane, bit-exact vs pow."""
+
+from __future__ import annotations
+
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from protocols.distributed_keygen_amd import Engine
+
+    e = Engine()
+    yield e
+    e.set_limbs_per_lane(0)
+
+
+def _special_moduli(bits):
+    m = [
+        (1 << bits) - 1,                       # all ones
+        (1 << bits) - 3,
+        (1 << (bits - 1)) + 1,                 # sparse
+        (1 << bits) - (1 << (bits // 2)) - 1,
+        ((1 << bits) - 1) // 3 | 1,            # 0101... pattern
+        int("1" + "0" * (bits - 30) + "1" * 29, 2),
+    ]
+    return [x | 1 for x in m if x > 2]
+
+
+def _special_bases(mod, rng):
+    bits = mod.bit_length()
+    vals = [0, 1, 2, mod - 1, mod - 2, mod // 2, mod // 2 + 1, (1 << (bits - 1)) - 1, (1 << (bits - 1)),
+            int("1" * 29 + "0" * 29, 2) % mod]
+    pat29 = sum(((1 << 29) - 1) << (29 * k) for k in range(0, bits // 29 + 1, 2)) % mod      # alternating full limbs
+    pat32 = sum(0xFFFFFFFF << (32 * k) for k in range(0, bits // 32 + 1, 2)) % mod
+    vals += [pat29, pat32, (mod - pat29) % mod, (mod - pat32) % mod]
+    vals += [rng.randrange(mod) for _ in range(6)]
+    return [v % mod for v in vals]
+
+
+@pytest.mark.parametrize("lpl", [9, 18])
+@pytest.mark.parametrize("bits", [61, 257, 258, 522, 1028, 2053, 4106])
+def test_special_operands(eng, lpl, bits):
+    eng.set_limbs_per_lane(lpl)
+    rng = random.Random(bits * 31 + lpl)
+    exps = [(1 << min(bits, 300)) - 1, (1 << min(bits, 300)), rng.getrandbits(min(bits, 400)) | 1, 0x10001, 3]
+    for mod in _special_moduli(bits):
+        bases = _special_bases(mod, rng)
+        for e in exps[: 3 if bits > 2000 else 5]:
+            assert eng.powmod_batch(bases, e, mod) == [pow(b, e, mod) for b in bases], (bits, hex(mod)[:20], e.bit_length())
+    # per-group exponents / moduli through the fixed-window kernel
+    mods = _special_moduli(bits)[:4]
+    es = [rng.getrandbits(min(bits, 350)) for _ in mods]
+    rows = [_special_bases(m, rng)[:12] for m in mods]
+    assert eng.powmod_batch_multi(rows, es, mods) == [[pow(b, e, m) for b in r] for r, e, m in zip(rows, es, mods)]
+
+
+def test_randomized_differential(eng):
+    eng.set_limbs_per_lane(0)
+    rng = random.Random(20260102)
+    for trial in range(60):
+        bits = rng.choice([rng.randint(2, 260), rng.randint(261, 1100), rng.randint(1100, 4200)])
+        mod = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        if mod < 3:
+            mod = 3
+        ebits = rng.choice([1, 2, 17, 64, 65, rng.randint(1, 600)])
+        exp = rng.getrandbits(ebits)
+        batch = rng.choice([1, 2, 3, 5, 17, 64, 65])
+        bases = [rng.randrange(mod) for _ in range(batch)]
+        eng.set_limbs_per_lane(rng.choice([0, 9, 18]))
+        assert eng.powmod_batch(bases, exp, mod) == [pow(b, exp, mod) for b in bases], (trial, bits, ebits, batch)
+        a = [rng.randrange(mod) for _ in range(batch)]
+        assert eng.mulmod_batch(a, bases, mod) == [x * y % mod for x, y in zip(a, bases)]
