@@ -114,6 +114,15 @@ int64_t mx_jacobi_workspace_bytes(int limbs, int64_t groups);
 int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
               int64_t group_size, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- selection of the generators -------------------------------------------------------
+ * For every group, copies the first `keep` rows whose flag is 1 (in order) to d_out[g][0..keep) and
+ * stores how many were found in d_counts[g]; unfilled rows are zero.  With d_flags = the output of
+ * mx_jacobi this is `if jacobi_symbol(g, N) != 1: continue` + `stop at correct_param_biprime` of
+ * the v-calculation loop (DK:1084-1099), so the generators never leave the device between the
+ * Jacobi filter and mx_powmod_multi. */
+int mx_select_first(const uint32_t* d_rows, const int8_t* d_flags, uint32_t* d_out, int32_t* d_counts,
+                    int limbs, int64_t groups, int group_size, int keep, void* stream);
+
 /* ---- diagnostics -----------------------------------------------------------------------
  * Runs the DPP cross-lane primitives against their ds_bpermute reference forms for every group
  * width on the current device; returns the number of mismatching lanes (0 = pass) or MX_ERR_*. */

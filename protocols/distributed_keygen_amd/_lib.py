@@ -30,6 +30,7 @@ SYMBOLS = {
     "mx_mulmod_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_jacobi_workspace_bytes": (c_int64, [c_int, c_int64]),
     "mx_jacobi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_select_first": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
     "mx_set_limbs_per_lane": (c_int, [c_int]),
     "mx_selftest_lanes": (c_int, [c_void_p]),
     "mx_geometry": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),

@@ -85,9 +85,13 @@ def biprime_test_v_calculation_batch(
         raise ValueError("one g list, p share and q share per candidate modulus expected")
     if len(moduli) == 0:
         return []
-    kept = select_generators_batch(g_values, moduli, correct_param_biprime, engine)
     exps = [biprime_exponent(index, n, p, q) for n, p, q in zip(moduli, p_shares, q_shares)]
-    return _engine(engine).powmod_batch_multi(kept, exps, list(moduli))
+    eng = _engine(engine)
+    if hasattr(eng, "biprime_v_batch"):
+        # Jacobi filter -> selection -> modexps without leaving the device
+        return eng.biprime_v_batch(g_values, exps, list(moduli), correct_param_biprime)
+    kept = select_generators_batch(g_values, moduli, correct_param_biprime, eng)
+    return eng.powmod_batch_multi(kept, exps, list(moduli))
 
 
 def biprime_test_v_calculation(

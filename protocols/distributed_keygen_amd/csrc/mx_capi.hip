@@ -6,6 +6,7 @@
 #include "mx_verdict.hpp"
 #include "mx_jacobi.hpp"
 #include "mx_mulmod.hpp"
+#include "mx_select.hpp"
 #include <cstring>
 #include <algorithm>
 
@@ -543,4 +544,17 @@ extern "C" int mx_mulmod_shared(const uint32_t* d_a, const uint32_t* d_b, uint32
     case 64: return launch_mulmod_k<64>(a, s);
   }
   return MX_ERR_SIZE;
+}
+
+// ---- selection of the Jacobi-1 generators ---------------------------------------------------
+extern "C" int mx_select_first(const uint32_t* d_rows, const int8_t* d_flags, uint32_t* d_out, int32_t* d_counts,
+                               int limbs, int64_t groups, int group_size, int keep, void* stream) {
+  if (!d_rows || !d_flags || !d_out || !d_counts || limbs <= 0 || groups <= 0 || group_size <= 0 || keep <= 0)
+    return MX_ERR_ARG;
+  mx::SelectArgs a;
+  a.rows = d_rows; a.flags = (const signed char*)d_flags; a.out = d_out; a.counts = d_counts;
+  a.groups = groups; a.group_size = group_size; a.keep = keep; a.limbs = limbs;
+  hipLaunchKernelGGL(mx::select_first_kernel, dim3((unsigned)groups), dim3(64), 0, (hipStream_t)stream, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
 }

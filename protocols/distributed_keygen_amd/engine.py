@@ -276,6 +276,48 @@ class Engine:
         arr = out.cpu().numpy()
         return [[int(x) for x in arr[g * gsize : g * gsize + len(values[g])]] for g in range(groups)]
 
+    def select_first_t(self, rows_t, flags_t, group_size: int, keep: int):
+        """rows_t int32 [groups*group_size, limbs], flags_t int8 [groups*group_size] -> (int32
+        [groups*keep, limbs] with the first `keep` flag==1 rows of every group, int32 counts [groups])."""
+        total, limbs = rows_t.shape
+        groups = total // group_size
+        out_t = self.torch.empty((groups * keep, limbs), dtype=self.torch.int32, device=self.device)
+        cnt_t = self.torch.empty(groups, dtype=self.torch.int32, device=self.device)
+        with self.torch.cuda.device(self.device):
+            rc = self.lib.mx_select_first(
+                rows_t.data_ptr(), flags_t.data_ptr(), out_t.data_ptr(), cnt_t.data_ptr(), limbs, groups,
+                group_size, keep, self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_select_first")
+        return out_t, cnt_t
+
+    def biprime_v_batch(
+        self, g_values: Sequence[Sequence[int]], exps: Sequence[int], mods: Sequence[int], keep: int
+    ) -> List[List[int]]:
+        """The whole v-calculation of DK:1084-1099 for many candidates on the device: Jacobi symbols of
+        all generators, selection of the first `keep` with symbol 1, v = g^exp mod N for those.
+        Returns per candidate the list of v values (shorter than `keep` if fewer symbols were 1)."""
+        groups = len(mods)
+        if groups == 0:
+            return []
+        for m in mods:
+            _check_modulus(m)
+        gsize = max(len(g) for g in g_values)
+        if gsize == 0 or keep == 0:
+            return [[] for _ in mods]
+        limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
+        flat = []
+        for gs, m in zip(g_values, mods):
+            flat.extend(_reduce(x, m) for x in gs)
+            flat.extend([0] * (gsize - len(gs)))          # padding: symbol (0/N) = 0, never selected
+        g_t = self.to_device(_limbs.pack(flat, limbs))
+        j_t = self.jacobi_t(g_t, list(mods), gsize)
+        sel_t, cnt_t = self.select_first_t(g_t, j_t, gsize, keep)
+        v_t = self.powmod_multi_t(sel_t, list(mods), list(exps), keep)
+        counts = cnt_t.cpu().numpy()
+        vals = _limbs.unpack(self.to_host(v_t))
+        return [vals[g * keep : g * keep + int(counts[g])] for g in range(groups)]
+
     # ------------------------------------------------------------------ sieve
     def sieve_t(self, cands_t, primes: Sequence[int], out_t=None):
         """uint8 [batch]: 1 iff some prime divides candidate e (distributed_keygen.py:1197-1209)."""

@@ -196,3 +196,34 @@ def test_encrypt_batch_and_negative_exponent_party(eng, golden_decrypt_synth):
     for i, k in keys.items():
         assert partials[i][3] == oracle.partial_decrypt(cts[3], n, i, grp["degree"], unhex(grp["n_fac"]), k.share.shares[i])
     assert keys[1].decrypt_batch([{i: partials[i][e] for i in keys} for e in range(20)]) == msgs
+
+
+# ------------------------------------------------------------------ device-side selection + fused v-calculation
+def test_select_first_and_fused_v_calculation(eng, golden_biprime):
+    import numpy as np
+    import torch
+
+    from protocols.distributed_keygen_amd import limbs as L
+
+    rng = random.Random(77)
+    groups, gsize, keep, limbs = 5, 150, 40, 7
+    rows = [rng.getrandbits(200) for _ in range(groups * gsize)]
+    flags = np.array([rng.choice([-1, 0, 1, 1]) for _ in range(groups * gsize)], dtype=np.int8)
+    flags[2 * gsize : 3 * gsize] = 0
+    flags[2 * gsize + 149] = 1                               # a group with a single hit, in the last slot
+    flags[3 * gsize : 3 * gsize + 64] = -1                   # first wave-pass empty
+    out_t, cnt_t = eng.select_first_t(eng.to_device(L.pack(rows, limbs)), torch.from_numpy(flags).to(eng.device), gsize, keep)
+    out = L.unpack(eng.to_host(out_t))
+    cnt = cnt_t.cpu().numpy().tolist()
+    for g in range(groups):
+        want = [rows[g * gsize + k] for k in range(gsize) if flags[g * gsize + k] == 1][:keep]
+        assert cnt[g] == len(want)
+        assert out[g * keep : g * keep + keep] == want + [0] * (keep - len(want))
+    # the fused device path reproduces the reference's v lists, including the short ones
+    for cand in golden_biprime["candidates"]:
+        modulus = unhex(cand["modulus"])
+        gs = [unhex(g) for g in cand["g_values"]]
+        for i in (1, 2):
+            e = oracle.biprime_exponent(i, modulus, unhex(cand["p_parts"][i - 1]), unhex(cand["q_parts"][i - 1]))
+            got = eng.biprime_v_batch([gs], [e], [modulus], cand["correct_param_biprime"])
+            assert got == [[unhex(v) for v in cand["v"][str(i)]]], (cand["label"], i)
