@@ -28,8 +28,15 @@ struct JacobiArgs {
   int limbs;
 };
 
+// Limbs are processed in chunks of JC; chunks above the highest limb that is non-zero in ANY lane of
+// the wavefront (for a or n) are skipped with a wave-uniform branch.  Both operands shrink steadily,
+// so on average about half of the chunks are live; `live` is refreshed every JREFRESH passes.
+constexpr int JC = 8;
+constexpr int JREFRESH = 16;
+
 template <int NL>
 __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
+  constexpr int NCH = (NL + JC - 1) / JC;
   const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
   const bool valid = idx < A.count;
   const long long e = valid ? idx : A.count - 1;
@@ -42,14 +49,32 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
     n[j] = j < A.limbs ? pn[j] : 0u;
   }
   int t = 1;
+  int live = NCH;            // wave-uniform number of live chunks
   // Every pass removes at least one bit from a or n, so 64*NL passes always suffice; the bound
   // makes the kernel terminate on ANY input (an even "modulus" would otherwise never finish).
   bool done = false;
   for (int pass = 0; pass < 64 * NL + 2; ++pass) {
+    if ((pass % JREFRESH) == 0) {
+      int top = 0;           // 1 + index of this lane's highest non-zero limb of a | n
+#pragma unroll
+      for (int j = 0; j < NL; ++j) top = (a[j] | n[j]) ? j + 1 : top;
+      // wave maximum, made uniform
+      for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off));
+      live = __builtin_amdgcn_readfirstlane((top + JC - 1) / JC);
+    }
     uint32_t nz = 0;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) nz |= a[j];
-    if (nz == 0) { done = true; break; }
+    for (int c = 0; c < NCH; ++c) {
+      if (c < live) {
+#pragma unroll
+        for (int j = c * JC; j < (c + 1) * JC && j < NL; ++j) nz |= a[j];
+      }
+    }
+    // Lanes whose a has reached 0 idle until the whole wavefront is finished: the exit must be
+    // wave-uniform because the refresh above reduces over all 64 lanes.
+    const bool active = nz != 0;
+    if (!__any(active)) { done = true; break; }
+    if (!active) continue;
     // ---- strip trailing zeros (whole limbs first, then bits)
     while (a[0] == 0) {            // a != 0, so this terminates; 32 zero bits: even count, no sign change
 #pragma unroll
@@ -59,34 +84,57 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
     const int z = __builtin_ctz(a[0]);
     if (z) {
 #pragma unroll
-      for (int j = 0; j < NL - 1; ++j) a[j] = __builtin_amdgcn_alignbit(a[j + 1], a[j], z);
-      a[NL - 1] >>= z;
+      for (int c = 0; c < NCH; ++c) {
+        if (c < live) {
+#pragma unroll
+          for (int j = c * JC; j < (c + 1) * JC && j < NL; ++j)
+            a[j] = (j + 1 < NL) ? __builtin_amdgcn_alignbit(a[j + 1], a[j], z) : (a[j] >> z);
+        }
+      }
       const uint32_t n8 = n[0] & 7u;
       if ((z & 1) && (n8 == 3u || n8 == 5u)) t = -t;
     }
     // ---- a < n ?  (borrow chain of a - n: v_sub_co / v_subb_co, nothing stored)
     unsigned int borrow = 0;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) (void)__builtin_subc(a[j], n[j], borrow, &borrow);
+    for (int c = 0; c < NCH; ++c) {
+      if (c < live) {
+#pragma unroll
+        for (int j = c * JC; j < (c + 1) * JC && j < NL; ++j) (void)__builtin_subc(a[j], n[j], borrow, &borrow);
+      }
+    }
     if (borrow) {
       // (a, n) <- (n - a, a), quadratic reciprocity for the swap
       if ((a[0] & 3u) == 3u && (n[0] & 3u) == 3u) t = -t;
       unsigned int b = 0;
 #pragma unroll
-      for (int j = 0; j < NL; ++j) {
-        const uint32_t x = a[j];
-        a[j] = __builtin_subc(n[j], x, b, &b);
-        n[j] = x;
+      for (int c = 0; c < NCH; ++c) {
+        if (c < live) {
+#pragma unroll
+          for (int j = c * JC; j < (c + 1) * JC && j < NL; ++j) {
+            const uint32_t x = a[j];
+            a[j] = __builtin_subc(n[j], x, b, &b);
+            n[j] = x;
+          }
+        }
       }
     } else {
       unsigned int b = 0;
 #pragma unroll
-      for (int j = 0; j < NL; ++j) a[j] = __builtin_subc(a[j], n[j], b, &b);
+      for (int c = 0; c < NCH; ++c) {
+        if (c < live) {
+#pragma unroll
+          for (int j = c * JC; j < (c + 1) * JC && j < NL; ++j) a[j] = __builtin_subc(a[j], n[j], b, &b);
+        }
+      }
     }
   }
-  uint32_t hi = 0;
+  uint32_t hi = 0, az = 0;
 #pragma unroll
   for (int j = 1; j < NL; ++j) hi |= n[j];
+#pragma unroll
+  for (int j = 0; j < NL; ++j) az |= a[j];
+  done = done && (az == 0);
   const bool n_is_one = done && (hi == 0) && (n[0] == 1u);
   if (valid) A.out[idx] = (signed char)(n_is_one ? t : 0);
 }

@@ -227,3 +227,18 @@ def test_select_first_and_fused_v_calculation(eng, golden_biprime):
             e = oracle.biprime_exponent(i, modulus, unhex(cand["p_parts"][i - 1]), unhex(cand["q_parts"][i - 1]))
             got = eng.biprime_v_batch([gs], [e], [modulus], cand["correct_param_biprime"])
             assert got == [[unhex(v) for v in cand["v"][str(i)]]], (cand["label"], i)
+
+
+def test_jacobi_lanes_finishing_at_very_different_times(eng):
+    """Regression: lanes whose numerator reaches 0 early must not disturb the wave-wide bookkeeping
+    (live-limb tracking) of the lanes still running."""
+    rng = random.Random(4)
+    big = (1 << 2050) + 1234567
+    big |= 1
+    vals = []
+    for k in range(192):
+        vals.append([0, 1, 2, 3, 5, rng.getrandbits(20), rng.getrandbits(300), rng.randrange(big)][k % 8])
+    mods = [big, (1 << 1500) + 7 | 1, (1 << 600) + 3 | 1]
+    rows = [vals[:64], vals[64:128], vals[128:]]
+    got = eng.jacobi_batch(rows, mods)
+    assert got == [[oracle.jacobi_symbol(v, m) for v in r] for r, m in zip(rows, mods)]
