@@ -21,13 +21,13 @@ def main():
     ap.add_argument("--steps", type=int, default=3)
     args = ap.parse_args()
     import torch
-    from oracle import oracle
+    import sympy
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
     eng = Engine()
     rng = random.Random(args.key_length)
     half = args.key_length // 2
-    primes = oracle.small_prime_list(2000)
+    primes = [int(p) for p in sympy.primerange(3, 2001)]
     shares, mods = [], []
     while len(mods) < args.cands:                      # candidates that survive the sieve, as in DK:1288-1292
         cand = [synthetic.candidate_shares(rng, args.parties, half) for _ in range(args.cands * 8)]
@@ -61,7 +61,7 @@ def main():
     torch.cuda.synchronize(); pm_s = (time.perf_counter() - t0) / args.steps
     rows = L.unpack(eng.to_host(out_t[:80]))
     assert rows == [pow(kept[c][k], exps[c], mods[c]) for c in range(2) for k in range(40)]
-    assert int(jac[0, 5]) == oracle.jacobi_symbol(g_all[0][5], mods[0])
+    assert int(jac[0, 5]) == sympy.jacobi_symbol(g_all[0][5], mods[0])
     # sieve
     c_t = eng.to_device(L.pack(mods * 16, limbs))
     eng.sieve_t(c_t, primes)
