@@ -68,7 +68,11 @@ constexpr int MAX_SLIDING_OPS = 16384;   // covers exponents up to 16384 bits
 
 bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p,
                  int limbs_per_lane = 0) {
-  if (limbs_per_lane == 0) limbs_per_lane = pick_limbs_per_lane(mod_bits, batch);
+  // the wide geometry pays in the shared-exponent (sliding-window) kernel; with per-group exponents
+  // the narrow one measured faster at every size (profiles/r01_biprime_*.json), unless forced
+  if (limbs_per_lane == 0)
+    limbs_per_lane = (groups > 1 && g_limbs_per_lane == 0 && !getenv("MX_LIMBS_PER_LANE"))
+                         ? LIMBS_PER_LANE : pick_limbs_per_lane(mod_bits, batch);
   if (!choose_geometry(mod_bits, p.geo, limbs_per_lane)) return false;
   p.win = fixed_window(32 * exp_limbs);
   int gpw = 64 / p.geo.K;
