@@ -55,7 +55,9 @@ def parse() -> argparse.Namespace:
                     help="independent steps (10k-ciphertext batches) kept in flight, one HIP stream each; "
                          "1 = strictly one batch at a time")
     ap.add_argument("--limbs-per-lane", type=int, default=-1,
-                    help="modexp lane geometry 9|18, 0 = library heuristic; default: 18 when >= 3 steps are in flight")
+                    help="lane geometry 9|18 of the generic kernel, 0 = library heuristic; default: 18 when >= 3 steps are in flight")
+    ap.add_argument("--generic-modulus", action="store_true",
+                    help="time mx_powmod_shared on the modulus N^2 instead of mx_powmod_nsquare (pairs modulo N)")
     return ap.parse_args()
 
 
@@ -126,7 +128,7 @@ def main() -> None:
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
     eng = Engine(local_rank)
-    lpl = args.limbs_per_lane if args.limbs_per_lane >= 0 else (18 if args.streams >= 3 else 0)
+    lpl = args.limbs_per_lane if args.limbs_per_lane >= 0 else (18 if (args.streams >= 3 and args.generic_modulus) else 0)
     eng.set_limbs_per_lane(lpl)
     key = synthetic.make_key(args.key_length, 3, 1)
     n, n2 = key.n, key.n_square
@@ -173,7 +175,10 @@ def main() -> None:
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
             e0.record()
-            ln["eng"].powmod_shared_t(own_in_t, n2, own_exp, out_t=ln["partials"][own_slot])
+            if args.generic_modulus:
+                ln["eng"].powmod_shared_t(own_in_t, n2, own_exp, out_t=ln["partials"][own_slot])
+            else:
+                ln["eng"].powmod_nsquare_t(own_in_t, n, own_exp, out_t=ln["partials"][own_slot])
             e1.record()
             if world > 1:
                 dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][own_slot].reshape(-1))
@@ -249,12 +254,14 @@ def main() -> None:
                             "partial-decrypt c^exp mod N^2 + share-combine (BASELINE.json configs[2])",
                 "batch_per_gpu": batch, "mod_bits": n2.bit_length(), "exp_bits": e_bits,
                 "limbs_u32": s_limbs, "party": own, "parallelism": f"dp{world}", "steps_in_flight": nstreams,
-                "geometry_K_L_W_blocks": list(eng.geometry(n2.bit_length())),
+                "geometry_K_L_W_blocks": list(eng.geometry(n2.bit_length() if args.generic_modulus else n.bit_length())),
+                "algorithm": "Montgomery modulo N^2" if args.generic_modulus else "N-adic pairs, two Montgomery passes modulo N per product",
                 "verified": check_note,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "mx::powmod_kernel<%d,%d,29>" % tuple(eng.geometry(n2.bit_length())[:2]),
+                "kernel": ("mx::powmod_kernel<%d,%d,29,true>" % tuple(eng.geometry(n2.bit_length())[:2])) if args.generic_modulus
+                          else ("mx::powmod_n2_kernel<%d,9,29>" % eng.geometry(n.bit_length())[0]),
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
                 "traffic": MEASURED_TRAFFIC_DEFAULT if (batch == 10000 and args.key_length == 2048) else None,

@@ -20,6 +20,8 @@ SYMBOLS = {
     "mx_powmod_workspace_bytes": (c_int64, [c_int, c_int, c_int64, c_int64]),
     "mx_powmod_shared": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_powmod_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_nsquare_workspace_bytes": (c_int64, [c_int, c_int, c_int64]),
+    "mx_powmod_nsquare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_sieve_workspace_bytes": (c_int64, [c_int, c_int]),
     "mx_sieve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_combine_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int64]),

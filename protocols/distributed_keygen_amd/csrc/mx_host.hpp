@@ -77,6 +77,42 @@ inline void two_pow_mod(u32* out, const u32* n, int limbs, int m) {
   for (int i = 0; i < limbs; ++i) out[i] = x[i];
 }
 
+// out[0..limbs) = 2^m mod n for any m >= 0 (n odd, >= 3)
+inline void pow2_mod(u32* out, const u32* n, int limbs, int m) {
+  int bits = bit_length(n, limbs);
+  if (m < bits - 1) {
+    for (int i = 0; i < limbs; ++i) out[i] = 0;
+    out[m / 32] = 1u << (m % 32);
+    return;
+  }
+  two_pow_mod(out, n, limbs, m);
+}
+
+// q[0..la) , r[0..lb) = divmod(a[0..la), b[0..lb)), b != 0; binary long division (host constants only)
+inline void divmod_words(u32* q, u32* r, const u32* a, int la, const u32* b, int lb) {
+  std::vector<u32> rem(lb + 1, 0u);
+  for (int i = 0; i < la; ++i) q[i] = 0;
+  for (int bit = bit_length(a, la) - 1; bit >= 0; --bit) {
+    u32 carry = (a[bit >> 5] >> (bit & 31)) & 1u;
+    for (int i = 0; i <= lb; ++i) {
+      u32 v = rem[i];
+      rem[i] = (v << 1) | carry;
+      carry = v >> 31;
+    }
+    if (geq(rem, b, lb)) {
+      u64 borrow = 0;
+      for (int i = 0; i < lb; ++i) {
+        u64 d = (u64)rem[i] - b[i] - borrow;
+        rem[i] = (u32)d;
+        borrow = (d >> 63) & 1;
+      }
+      rem[lb] -= (u32)borrow;
+      q[bit >> 5] |= 1u << (bit & 31);
+    }
+  }
+  for (int i = 0; i < lb; ++i) r[i] = rem[i];
+}
+
 // x*y for small host-side products (schoolbook); out has la+lb words
 inline void mul_words(u32* out, const u32* a, int la, const u32* b, int lb) {
   for (int i = 0; i < la + lb; ++i) out[i] = 0;

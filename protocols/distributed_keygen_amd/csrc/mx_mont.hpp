@@ -39,7 +39,8 @@ struct Mont {
   using LN = Lanes<K, USE_DPP>;
   static constexpr u32 MASK = (1u << W) - 1u;
   static constexpr int S = K * L;              // capacity in limbs
-  static constexpr int LDS_WORDS = S + 4;      // per-group scratch (32-bit words)
+  static constexpr int LDS_WORDS = 2 * S + 8;  // per-group scratch (32-bit words): multiplier b, second multiplier d
+  static constexpr int LDS_D = S + 4;          // offset of the second multiplier
 
   u32 n[L];      // modulus slice (exact W-bit limbs)
   u32 n0inv;     // -N^-1 mod 2^W
@@ -169,7 +170,8 @@ struct Mont {
 
   // x (exact limbs, x <= 2N-ish but < 2^(W*S)) -> x mod N for x < 2N: one conditional subtraction,
   // done as x + (2^(W*S) - N) and a test of the carry out of the top limb.
-  __device__ __forceinline__ void cond_sub(u32 (&x)[L]) const {
+  // Returns 1 (in every lane of the group) when N was subtracted.
+  __device__ __forceinline__ u32 cond_sub(u32 (&x)[L]) const {
     u64 t[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) t[j] = (u64)x[j] + (u64)(MASK - n[j]);
@@ -179,6 +181,7 @@ struct Mont {
     u32 ge = LN::bcast_from((u32)(top != 0), K - 1);
 #pragma unroll
     for (int j = 0; j < L; ++j) x[j] = ge ? u[j] : x[j];
+    return ge;
   }
 
   // true (group-uniform) iff x == y limb for limb; both exact
@@ -220,32 +223,51 @@ struct Mont {
     if constexpr (w == 2) t[J] += (u64)a[J] * bi2;
   }
 
-  // slot J >= 1 of step I: product term (if selected) and reduction term
-  template <bool SQUARE, int I, int J>
-  __device__ __forceinline__ void slot_macs(u64 (&t)[L], const u32 (&a)[L], u32 bi, u32 bi2, u32 q) const {
+  // Compile-time options of the word-serial product (bit mask F):
+  //   F_RECORD_Q  keep the quotient digits q_i (limb i in the lane/slot that owns limb i)
+  //   F_SQUARE    b is a: symmetric product (see below)
+  //   F_TWO       two product rows per limb: t += a*b_i + c*d_i   (d staged next to b in LDS)
+  //   F_INIT      the accumulator starts from `init` (lazy limbs) instead of 0
+  //   F_PLAIN     no reduction: plain product; the limb leaving the group's lane 0 at every step
+  //               is the next low limb of the result and is written to `emit` (LDS), the value left
+  //               in the accumulator is the high part
+  static constexpr int F_RECORD_Q = 1, F_SQUARE = 2, F_TWO = 4, F_INIT = 8, F_PLAIN = 16;
+
+  template <int F, int I, int J>
+  __device__ __forceinline__ void slot_macs(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], u32 bi, u32 bi2,
+                                            u32 di, u32 q) const {
     if constexpr (J != 0) {
-      product_mac<SQUARE, I, J>(t, a, bi, bi2);
-      t[J] += (u64)n[J] * q;
+      product_mac<(F & F_SQUARE) != 0, I, J>(t, a, bi, bi2);
+      if constexpr (F & F_TWO) t[J] += (u64)c[J] * di;
+      if constexpr (!(F & F_PLAIN)) t[J] += (u64)n[J] * q;
     }
   }
 
-  template <bool SQUARE, int I, int... Js>
-  __device__ __forceinline__ void row_macs(u64 (&t)[L], const u32 (&a)[L], u32 bi, u32 bi2, u32 q,
-                                           std::integer_sequence<int, Js...>) const {
-    (slot_macs<SQUARE, I, Js>(t, a, bi, bi2, q), ...);
+  template <int F, int I, int... Js>
+  __device__ __forceinline__ void row_macs(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], u32 bi, u32 bi2, u32 di,
+                                           u32 q, std::integer_sequence<int, Js...>) const {
+    (slot_macs<F, I, Js>(t, a, c, bi, bi2, di, q), ...);
   }
 
-  template <bool RECORD_Q, bool SQUARE, int I>
-  __device__ __forceinline__ void limb_step(u64 (&t)[L], const u32 (&a)[L], const u32 (&bb)[L],
-                                            const u32 (&bb2)[L], u32 (&qr)[L], int blk) const {
+  template <int F, int I>
+  __device__ __forceinline__ void limb_step(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], const u32 (&bb)[L],
+                                            const u32 (&bb2)[L], const u32 (&dd)[L], u32 (&qr)[L], int blk,
+                                            u32* emit) const {
     const u32 bi = bb[I];
     const u32 bi2 = bb2[I];
-    product_mac<SQUARE, I, 0>(t, a, bi, bi2);
-    // the mask is applied after the broadcast so that it folds into the DPP move (v_and_b32_dpp)
-    const u32 q = LN::bcast0((u32)t[0] * n0inv) & maskv;
-    if constexpr (RECORD_Q) qr[I] = (blk == p) ? q : qr[I];
-    t[0] += (u64)n[0] * q;
-    row_macs<SQUARE, I>(t, a, bi, bi2, q, std::make_integer_sequence<int, L>{});
+    const u32 di = dd[I];
+    product_mac<(F & F_SQUARE) != 0, I, 0>(t, a, bi, bi2);
+    if constexpr (F & F_TWO) t[0] += (u64)c[0] * di;
+    u32 q = 0;
+    if constexpr (F & F_PLAIN) {
+      if (p == 0) emit[blk * L + I] = (u32)t[0] & MASK;
+    } else {
+      // the mask is applied after the broadcast so that it folds into the DPP move (v_and_b32_dpp)
+      q = LN::bcast0((u32)t[0] * n0inv) & maskv;
+      if constexpr (F & F_RECORD_Q) qr[I] = (blk == p) ? q : qr[I];
+      t[0] += (u64)n[0] * q;
+    }
+    row_macs<F, I>(t, a, c, bi, bi2, di, q, std::make_integer_sequence<int, L>{});
     // divide by 2^W: column 0 leaves; its low W bits belong to the lower neighbour's top column
     // (zero for the group's lane 0 by construction of q), the rest carries into column 1
     const u64 carry = t[0] >> W;
@@ -256,53 +278,64 @@ struct Mont {
     t[L - 1] = recv;
   }
 
-  template <bool RECORD_Q, bool SQUARE, int... Is>
-  __device__ __forceinline__ void block_steps(u64 (&t)[L], const u32 (&a)[L], const u32 (&bb)[L],
-                                              const u32 (&bb2)[L], u32 (&qr)[L], int blk,
-                                              std::integer_sequence<int, Is...>) const {
-    (limb_step<RECORD_Q, SQUARE, Is>(t, a, bb, bb2, qr, blk), ...);
+  template <int F, int... Is>
+  __device__ __forceinline__ void block_steps(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], const u32 (&bb)[L],
+                                              const u32 (&bb2)[L], const u32 (&dd)[L], u32 (&qr)[L], int blk,
+                                              u32* emit, std::integer_sequence<int, Is...>) const {
+    (limb_step<F, Is>(t, a, c, bb, bb2, dd, qr, blk, emit), ...);
   }
 
   // ------------------------------------------------------------------ Montgomery product
-  // r = a * b / R mod N (lazy: r < 2N when a, b < 4N).  r may alias a or b.
-  // If RECORD_Q, the quotient digits q_i are kept (limb i of Q lives in the lane/slot that owns
-  // limb i) — used by the exact division in the share-combine kernel.
+  // r = (a*b [+ c*d] [+ init]) / R mod N   (lazy: r < 2N for operands < 4N, R >= 16 N); r may alias
+  // any operand.  With F_PLAIN: r = high part of a*b [+ c*d] [+ init], low limbs in `emit`.
   //
-  // SQUARE (b is a): the product part uses the symmetry a_u a_v = a_v a_u without moving any data.
+  // F_SQUARE (b is a): the product part uses the symmetry a_u a_v = a_v a_u without moving any data.
   // At the unrolled step i of a block (multiplier limb u with u mod L == i) a lane only multiplies
   // its slots j whose cyclic distance d = (j - i) mod L is <= L/2: with weight 2 for 0 < d < L/2 and
   // weight 1 for d == 0 (and d == L/2 when L is even).  For u != v exactly one of the two orders
   // has distance < L/2 (weight 2), or both have distance 0 or L/2 (weight 1 + 1); u == v is met once
   // with weight 1 — so every term of a^2 gets its coefficient, the selection is the same in every
   // lane (compile-time register indices), and floor(L/2)+1 instead of L product MACs are issued.
-  template <bool RECORD_Q = false, bool SQUARE = false>
-  __device__ __forceinline__ void mul(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], u32* qrec = nullptr) {
-    // stage b where every lane of the group can read any limb of it
+  template <int F>
+  __device__ __forceinline__ void mulx(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], const u32 (&c)[L],
+                                       const u32 (&d)[L], const u32 (&init)[L], u32* qrec, u32* emit, int nsteps_blk) {
+    // stage the multiplier(s) where every lane of the group can read any limb
     __syncthreads();
 #pragma unroll
     for (int j = 0; j < L; ++j) lds[p * L + j] = b[j];
+    if constexpr (F & F_TWO) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) lds[LDS_D + p * L + j] = d[j];
+    }
     __syncthreads();
     u64 t[L];
 #pragma unroll
-    for (int j = 0; j < L; ++j) t[j] = 0;
+    for (int j = 0; j < L; ++j) t[j] = (F & F_INIT) ? (u64)init[j] : 0;
     u32 qr[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) qr[j] = 0;
-    for (int blk = 0; blk < nblk; ++blk) {
-      u32 bb[L], bb2[L];
+    for (int blk = 0; blk < nsteps_blk; ++blk) {
+      u32 bb[L], bb2[L], dd[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];
       // doubled multiplier limbs for the weight-2 products of a squaring (a shift is cheaper than a
       // second LDS copy of b: measured)
 #pragma unroll
-      for (int j = 0; j < L; ++j) bb2[j] = SQUARE ? (bb[j] << 1) : 0u;
-      block_steps<RECORD_Q, SQUARE>(t, a, bb, bb2, qr, blk, std::make_integer_sequence<int, L>{});
+      for (int j = 0; j < L; ++j) bb2[j] = (F & F_SQUARE) ? (bb[j] << 1) : 0u;
+#pragma unroll
+      for (int j = 0; j < L; ++j) dd[j] = (F & F_TWO) ? lds[LDS_D + blk * L + j] : 0u;
+      block_steps<F>(t, a, c, bb, bb2, dd, qr, blk, emit, std::make_integer_sequence<int, L>{});
     }
     normalize_weak(r, t);
-    if constexpr (RECORD_Q) {
+    if constexpr (F & F_RECORD_Q) {
 #pragma unroll
       for (int j = 0; j < L; ++j) qrec[j] = qr[j];
     }
+  }
+
+  template <bool RECORD_Q = false, bool SQUARE = false>
+  __device__ __forceinline__ void mul(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], u32* qrec = nullptr) {
+    mulx<(RECORD_Q ? F_RECORD_Q : 0) | (SQUARE ? F_SQUARE : 0)>(r, a, b, a, a, a, qrec, nullptr, nblk);
   }
 
   // r = a^2 / R mod N (lazy), with the symmetric product

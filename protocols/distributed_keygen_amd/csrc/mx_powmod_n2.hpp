@@ -1,0 +1,236 @@
+// Batched modular exponentiation modulo a SQUARE:  out[e] = bases[e]^exp mod N^2,  one (N, exp) per
+// launch — the partial decryption of threshold Paillier, pow_mod(c, exp, n_square)
+// (paillier_shared_key.py:92 looped at distributed_keygen.py:463-466).
+//
+// Arithmetic modulo N^2 with operations of the size of N only.  Let R = 2^(W*L*nblk) >= 16 N be the
+// Montgomery radix for N and rho = R^-1 mod N^2.  A residue x is held as a pair (X0, X1) of lazy
+// residues modulo N with
+//                         x = rho * (X0 + X1 * N)   (mod N^2).
+// For two such pairs, x*y = rho^2 * (X0*Y0 + (X0*Y1 + X1*Y0) * N) because N^2 = 0.  A Montgomery
+// pass of X0*Y0 modulo N gives t0 and the quotient Q with  X0*Y0 = t0*R - Q*N  EXACTLY (integers), so
+//       x*y = rho * ( t0 + rho * (X0*Y1 + X1*Y0 - Q) * N )
+// and, since only  rho * (...) mod N  matters in front of N, a second Montgomery pass gives
+//       Z0 = t0,     Z1 = REDC_N( X0*Y1 + X1*Y0 + (C - Q) ),        C = N * ceil(R / N)  (C = 0 mod N, C >= Q)
+// i.e. two half-size passes (3 half-size products + 2 half-size reductions; 2 + 2 for a squaring, one
+// of them symmetric) instead of one full-size product and reduction: ~1.8x fewer multiply-accumulates
+// than Montgomery modulo N^2 directly, with HALF the lanes per element.  C - Q is formed limb-wise as
+// C' + (R - 1 - Q), C' = C - R + 1, i.e. (MASK - q_i) + c'_i: no borrow anywhere.
+//
+// Conversions (once per exponentiation): x = x_lo + 2^k x_hi is brought into pair form by two pair
+// products with the constants that represent R and 2^k R; the result pair is multiplied by (1, 0)
+// (which represents rho) so that its plain N-adic value Y0 + Y1*N IS the residue, both digits are
+// reduced to [0, N), and Y0 + Y1*N is formed by a plain (reduction-free) product whose low limbs
+// leave through the group's lane 0.
+#pragma once
+#include "mx_mont.hpp"
+
+namespace mx {
+
+// The kernel is an interpreter of a short "tape" built by the host (the same for every lane, so
+// control flow is uniform): conversion into pair form, the table of odd powers and the
+// sliding-window exponentiation are all sequences of five operations on one pair register `acc`
+// and pair slots in device memory.  This keeps ONE squaring and ONE multiplication call site in
+// the kernel (each is two inlined Montgomery passes), which is what bounds code size and registers.
+enum : u32 { N2_SQR = 0, N2_MUL = 1, N2_ADD = 2, N2_LOAD = 3, N2_STORE = 4 };
+// tape word = (op << 28) | argument   (argument: repeat count for SQR, slot index otherwise)
+// slots: 0 K1 (represents R), 1 K2 (represents 2^k R), 2 E = (1, 0), 3 ONE, 4 (x_lo, 0), 5 (x_hi, 0),
+//        6 scratch, 7 x^2, 8.. odd powers x^(2k+1)
+constexpr int N2_SLOT_K1 = 0, N2_SLOT_K2 = 1, N2_SLOT_E = 2, N2_SLOT_ONE = 3, N2_SLOT_LO = 4, N2_SLOT_HI = 5,
+              N2_SLOT_TMP = 6, N2_SLOT_SQ = 7, N2_SLOT_TABLE = 8;
+
+struct PowmodN2Args {
+  const u32* bases;   // [batch][limbs2] device
+  u32* out;           // [batch][limbs2] device
+  const u32* consts;  // [8][limbsn] device: N, ONE0, ONE1, K1_0, K1_1, K2_0, K2_1, C'
+  const u32* tape;    // [ntape] device
+  u32* slots;         // [nslots][2][L][nlanes] device
+  i64 batch;
+  int limbsn, limbs2;
+  int ntape, nblk;
+  int ksplit;         // x = x_lo + 2^ksplit * x_hi, ksplit = bits(N) - 1
+};
+
+template <int K, int L, int W>
+struct PairArith {
+  using M_t = Mont<K, L, W, true>;
+  static constexpr u32 MASK = M_t::MASK;
+  M_t& M;
+  u32 cp[L];          // this lane's limbs of C' = C - R + 1
+
+  __device__ __forceinline__ explicit PairArith(M_t& m) : M(m) {}
+
+  // accumulator start of the second pass: C' + (R - 1 - Q), limb-wise
+  __device__ __forceinline__ void second_pass_init(u32 (&init)[L], const u32 (&q)[L]) const {
+    const bool has_q = M.p < M.nblk;
+#pragma unroll
+    for (int j = 0; j < L; ++j) init[j] = cp[j] + (has_q ? (MASK - q[j]) : 0u);
+  }
+
+  // (z0, z1) = (x0, x1) * (y0, y1); outputs may alias inputs
+  __device__ __forceinline__ void mul(u32 (&z0)[L], u32 (&z1)[L], const u32 (&x0)[L], const u32 (&x1)[L],
+                                      const u32 (&y0)[L], const u32 (&y1)[L]) {
+    u32 t0[L], q[L], init[L];
+    M.template mulx<M_t::F_RECORD_Q>(t0, x0, y0, x0, x0, x0, q, nullptr, M.nblk);
+    second_pass_init(init, q);
+    M.template mulx<M_t::F_TWO | M_t::F_INIT>(z1, x0, y1, x1, y0, init, nullptr, nullptr, M.nblk);
+#pragma unroll
+    for (int j = 0; j < L; ++j) z0[j] = t0[j];
+  }
+
+  // (z0, z1) = (x0, x1)^2
+  __device__ __forceinline__ void sqr(u32 (&z0)[L], u32 (&z1)[L], const u32 (&x0)[L], const u32 (&x1)[L]) {
+    u32 t0[L], q[L], init[L], x1d[L];
+    M.template mulx<M_t::F_RECORD_Q | M_t::F_SQUARE>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
+    second_pass_init(init, q);
+#pragma unroll
+    for (int j = 0; j < L; ++j) x1d[j] = x1[j] << 1;              // 2 * X0 * X1
+    M.template mulx<M_t::F_INIT>(z1, x0, x1d, x0, x0, init, nullptr, nullptr, M.nblk);
+#pragma unroll
+    for (int j = 0; j < L; ++j) z0[j] = t0[j];
+  }
+};
+
+// W-bit field of a little-endian word array starting at bit `bitpos` (words zero padded by the caller)
+__device__ __forceinline__ u32 extract_field(const u32* words, int bitpos, int nbits) {
+  const int w = bitpos >> 5, off = bitpos & 31;
+  const u64 v = (u64)words[w] | ((u64)words[w + 1] << 32);
+  return (u32)(v >> off) & (nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
+}
+
+template <int K, int L, int W>
+__global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2Args A) {
+  using M_t = Mont<K, L, W, true>;
+  constexpr int S = M_t::S;
+  constexpr int WIDE = 2 * S + 8;                 // words: input row staging / output limbs
+  constexpr int GROUP_WORDS = M_t::LDS_WORDS + WIDE;
+  extern __shared__ u32 smem[];
+  constexpr int GPW = 64 / K;
+  const int lane = threadIdx.x;
+  const int gw = lane / K;
+  const i64 elem_raw = (i64)blockIdx.x * GPW + gw;
+  const bool valid = elem_raw < A.batch;
+  const i64 elem = valid ? elem_raw : A.batch - 1;
+  const i64 nlanes = (i64)gridDim.x * 64;
+  const i64 gl = (i64)blockIdx.x * 64 + lane;
+  u32* wide = smem + gw * GROUP_WORDS + M_t::LDS_WORDS;
+
+  M_t M;
+  M.init(smem + gw * GROUP_WORDS, A.nblk);
+  M.load(M.n, A.consts, A.limbsn);
+  M.setup_modulus();
+  PairArith<K, L, W> P(M);
+  M.load(P.cp, A.consts + 7 * A.limbsn, A.limbsn);
+  const int p = M.p;
+
+  u32* slots = A.slots + gl;
+  auto slot_at = [&](int slot, int half, int j) -> u32& { return slots[(((i64)slot * 2 + half) * L + j) * nlanes]; };
+
+  // ---- prologue: constant pairs and the two halves of x into their slots (no arithmetic)
+  {
+    u32 v[L];
+    const int rows[4][3] = {{N2_SLOT_K1, 3, 4}, {N2_SLOT_K2, 5, 6}, {N2_SLOT_ONE, 1, 2}, {N2_SLOT_E, -1, -1}};
+    for (int r = 0; r < 4; ++r) {
+      for (int half = 0; half < 2; ++half) {
+        const int row = rows[r][1 + half];
+        if (row >= 0) {
+          M.load(v, A.consts + (i64)row * A.limbsn, A.limbsn);
+        } else {
+          M.set_small(v, half == 0 ? 1u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < L; ++j) slot_at(rows[r][0], half, j) = v[j];
+      }
+    }
+    __syncthreads();
+    const u32* src = A.bases + elem * A.limbs2;
+    for (int k = p; k < WIDE; k += K) wide[k] = (k < A.limbs2) ? src[k] : 0u;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      const int bit = W * (p * L + j);
+      const int room = A.ksplit - bit;                       // bits of this limb that belong to x_lo
+      const u32 lo = room <= 0 ? 0u : extract_field(wide, bit, room < W ? room : W);
+      const int hbit = A.ksplit + bit;
+      const u32 hi = (hbit + W + 32 <= 32 * WIDE) ? extract_field(wide, hbit, W) : 0u;
+      slot_at(N2_SLOT_LO, 0, j) = lo;
+      slot_at(N2_SLOT_LO, 1, j) = 0;
+      slot_at(N2_SLOT_HI, 0, j) = hi;
+      slot_at(N2_SLOT_HI, 1, j) = 0;
+    }
+  }
+
+  // ---- the tape
+  u32 acc0[L], acc1[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) { acc0[j] = 0; acc1[j] = 0; }
+  for (int k = 0; k < A.ntape; ++k) {
+    const u32 word = A.tape[k];
+    const u32 op = word >> 28;
+    const int arg = (int)(word & 0x0FFFFFFFu);
+    if (op == N2_SQR) {
+      for (int s = 0; s < arg; ++s) P.sqr(acc0, acc1, acc0, acc1);
+    } else if (op == N2_STORE) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) { slot_at(arg, 0, j) = acc0[j]; slot_at(arg, 1, j) = acc1[j]; }
+    } else {
+      u32 f0[L], f1[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) { f0[j] = slot_at(arg, 0, j); f1[j] = slot_at(arg, 1, j); }
+      if (op == N2_MUL) {
+        P.mul(acc0, acc1, acc0, acc1, f0, f1);
+      } else if (op == N2_ADD) {
+        M.add(acc0, acc0, f0);
+        M.add(acc1, acc1, f1);
+      } else {   // N2_LOAD
+#pragma unroll
+        for (int j = 0; j < L; ++j) { acc0[j] = f0[j]; acc1[j] = f1[j]; }
+      }
+    }
+  }
+
+  // ---- epilogue: acc already is the pair whose N-adic value Y0 + Y1*N is the residue (the tape ends
+  // with a multiplication by E = (1, 0)).  Digits into [0, N) — a lazy Y0 >= N carries one unit into
+  // Y1 (Y0 <= N and Y1 <= N + 1 after that last product) — then z = Y0 + Y1 * N by a plain product.
+  {
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = acc0[j];
+    M.normalize_full(acc0, t);
+    const u32 carry = M.cond_sub(acc0);
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = acc1[j];
+    if (p == 0) t[0] += carry;
+    M.normalize_full(acc1, t);
+    M.cond_sub(acc1);
+  }
+  u32 hi[L];
+  __syncthreads();
+  M.template mulx<M_t::F_INIT | M_t::F_PLAIN>(hi, acc1, M.n, acc1, acc1, acc0, nullptr, wide, A.nblk);
+  {
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = hi[j];
+    M.normalize_full(hi, t);
+  }
+  const int it = A.nblk * L;
+#pragma unroll
+  for (int j = 0; j < L; ++j) wide[it + p * L + j] = hi[j];
+  if (p == 0) { wide[it + S] = 0; wide[it + S + 1] = 0; wide[it + S + 2] = 0; wide[it + S + 3] = 0; }
+  __syncthreads();
+  u32* dst = A.out + elem * A.limbs2;
+  const int nl = it + S;
+  for (int k = p; k < A.limbs2; k += K) {
+    const int bit = 32 * k;
+    const int g = bit / W, off = bit - g * W;
+    u32 o = 0;
+    if (g < nl) {
+      u64 v = (u64)wide[g] >> off;
+      v |= (u64)wide[g + 1] << (W - off);
+      if (2 * W - off < 32) v |= (u64)wide[g + 2] << (2 * W - off);
+      o = (u32)v;
+    }
+    if (valid) dst[k] = o;
+  }
+}
+
+}  // namespace mx

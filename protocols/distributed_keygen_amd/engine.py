@@ -123,6 +123,40 @@ class Engine:
         _lib.check(rc, "mx_powmod_multi")
         return out_t
 
+    def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None):
+        """out[e] = bases[e]^exp mod n^2 (rows of the width of n^2), computed through pairs modulo n
+        (include/mxpaillier.h: mx_powmod_nsquare) — the fast path of the partial decryption PSK:92."""
+        if exp < 0:
+            raise ValueError("negative exponent: invert the base first (paillier_shared_key.py:89-91)")
+        batch, limbs2 = bases_t.shape
+        _check_modulus(n)
+        limbs_n = _limbs.limbs_for(n)
+        if _limbs.limbs_for(n * n) > limbs2:
+            raise ValueError("rows narrower than N^2")
+        elimbs = _limbs.limbs_for(exp)
+        h_n = _limbs.pack_one(n, limbs_n)
+        h_exp = _limbs.pack_one(exp, elimbs)
+        if out_t is None:
+            out_t = self.torch.empty_like(bases_t)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_powmod_nsquare_workspace_bytes(limbs_n, elimbs, batch))
+            rc = self.lib.mx_powmod_nsquare(
+                bases_t.data_ptr(), out_t.data_ptr(), h_n.ctypes.data, h_exp.ctypes.data,
+                limbs_n, limbs2, elimbs, batch, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_powmod_nsquare")
+        return out_t
+
+    def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int) -> List[int]:
+        """[pow_mod(b, exp, n*n) for b in bases] through the N-adic pair kernel."""
+        if len(bases) == 0:
+            return []
+        _check_modulus(n)
+        n2 = n * n
+        limbs2 = _limbs.limbs_for(n2)
+        rows = _limbs.pack([_reduce(b, n2) for b in bases], limbs2)
+        return _limbs.unpack(self.to_host(self.powmod_nsquare_t(self.to_device(rows), n, exp)))
+
     # ------------------------------------------------------------------ modexp, int level
     def powmod_batch(self, bases: Sequence[int], exp: int, mod: int) -> List[int]:
         """[pow_mod(b, exp, mod) for b in bases] on the GPU (exp >= 0)."""

@@ -100,7 +100,8 @@ class GpuPaillierSharedKey:
         if exp < 0:  # PSK:89-91, as one product-tree inversion on the device
             values = self.engine.modinv_batch(values, self.n_square)
             exp = -exp
-        return self.engine.powmod_batch(values, exp, self.n_square)  # PSK:92
+        # PSK:92, pow_mod(c, exp, n_square): modulo N^2 through pairs modulo N (mx_powmod_nsquare)
+        return self.engine.powmod_nsquare_batch(values, exp, self.n)
 
     def partial_decrypt(self, ciphertext: Any) -> int:
         """PSK:52-93."""

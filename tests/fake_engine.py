@@ -19,6 +19,12 @@ class FakeEngine:
             raise ValueError("negative exponent")
         return [oracle.pow_mod(b, exp, mod) for b in bases]
 
+    def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int) -> List[int]:
+        self.calls.append(("powmod_batch", len(bases)))
+        if exp < 0:
+            raise ValueError("negative exponent")
+        return [oracle.pow_mod(b, exp, n * n) for b in bases]
+
     def powmod_batch_multi(self, bases, exps, mods):
         self.calls.append(("powmod_batch_multi", sum(len(b) for b in bases)))
         return [[oracle.pow_mod(b, e, m) for b in bs] for bs, e, m in zip(bases, exps, mods)]

@@ -125,3 +125,51 @@ def test_golden_biprime_v_values(eng, golden_biprime):
     for items in by_shape.values():
         got = eng.powmod_batch_multi([k for k, _, _, _ in items], [e for _, e, _, _ in items], [m for _, _, m, _ in items])
         assert got == [w for _, _, _, w in items]
+
+
+# ------------------------------------------------------------------ modulus N^2 through pairs modulo N
+@pytest.mark.parametrize("n_bits,exp_bits,batch", [(20, 45, 9), (68, 150, 33), (131, 300, 20), (257, 600, 7),
+                                                   (515, 64, 5), (1028, 2100, 6), (2051, 700, 17), (4099, 128, 3)])
+def test_powmod_nsquare_random(eng, n_bits, exp_bits, batch):
+    rng = random.Random(n_bits * 7 + exp_bits)
+    n = rng.getrandbits(n_bits) | (1 << (n_bits - 1)) | 1
+    n2 = n * n
+    exp = rng.getrandbits(exp_bits) | (1 << (exp_bits - 1))
+    bases = [rng.randrange(n2) for _ in range(batch)]
+    bases[0], bases[1], bases[2] = 0, 1, n2 - 1
+    if batch > 4:
+        bases[3], bases[4] = n, n + 1                      # multiples of N / the Paillier generator
+    assert eng.powmod_nsquare_batch(bases, exp, n) == [pow(b, exp, n2) for b in bases]
+
+
+@pytest.mark.parametrize("exp", [0, 1, 2, 3, 255, 256, (1 << 64) + 1])
+def test_powmod_nsquare_edge_exponents(eng, exp):
+    rng = random.Random(exp % 997)
+    n = rng.getrandbits(300) | (1 << 299) | 1
+    n2 = n * n
+    bases = [0, 1, 2, n - 1, n, n + 1, n2 - 1, n2 - n] + [rng.randrange(n2) for _ in range(9)]
+    assert eng.powmod_nsquare_batch(bases, exp, n) == [pow(b, exp, n2) for b in bases]
+
+
+def test_powmod_nsquare_special_moduli(eng):
+    rng = random.Random(12)
+    for n in (3, 5, (1 << 29) - 1, (1 << 29) + 1, (1 << 261) - 1, (1 << 2050) + 1, (1 << 2053) - 1):
+        n2 = n * n
+        bases = [0, 1, 2, n2 - 1, n2 // 2, (1 << (n2.bit_length() - 1)) - 1] + [rng.randrange(n2) for _ in range(6)]
+        bases = [b % n2 for b in bases]
+        e = rng.getrandbits(90) | 1
+        assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], n.bit_length()
+
+
+def test_powmod_nsquare_golden_partial_decryptions(eng, golden_decrypt_synth, golden_ref_keys):
+    for src in (golden_ref_keys, golden_decrypt_synth):
+        for name, grp in src.items():
+            if "corrupt" in name:
+                continue
+            n = unhex(grp["n"])
+            n2 = n * n
+            cs = [unhex(c["c"]) for c in grp["cases"]]
+            for i, share in grp["shares"].items():
+                exp = oracle.partial_decrypt_exponent(int(i), grp["degree"], unhex(grp["n_fac"]), unhex(share))
+                bases = cs if exp >= 0 else [oracle.mod_inv(c, n2) for c in cs]
+                assert eng.powmod_nsquare_batch(bases, abs(exp), n) == [unhex(c["partials"][i]) for c in grp["cases"]], (name, i)
