@@ -10,7 +10,7 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libmxpaillier.so"
-SOURCES = [CSRC / "mx_capi.hip"]
+SOURCES = [CSRC / "mx_capi.hip", CSRC / "mx_capi_n2.hip", CSRC / "mx_capi_n2w.hip"]
 HEADERS = sorted(CSRC.glob("*.hpp")) + [PKG.parent.parent / "include" / "mxpaillier.h"]
 
 
@@ -32,14 +32,27 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the shared library for gfx950; returns its path."""
     if not force and not needs_build():
         return LIB
-    cmd = [
-        _hipcc(), "-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-shared",
-        "-Wno-unused-value", "-Wno-pass-failed",
-        *[str(s) for s in SOURCES], "-o", str(LIB),
-    ]
+    from concurrent.futures import ThreadPoolExecutor
+
+    hipcc = _hipcc()
+    objdir = PKG / "build"
+    objdir.mkdir(exist_ok=True)
+    flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed"]
+
+    def compile_one(src: Path) -> Path:
+        obj = objdir / (src.stem + ".o")
+        cmd = [hipcc, *flags, "-c", str(src), "-o", str(obj)]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.run(cmd, check=True, cwd=str(CSRC))
+        return obj
+
+    with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:      # translation units in parallel
+        objs = list(pool.map(compile_one, SOURCES))
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", *[str(o) for o in objs], "-o", str(LIB)]
     if verbose:
-        print(" ".join(cmd))
-    subprocess.run(cmd, check=True, cwd=str(CSRC))
+        print(" ".join(link))
+    subprocess.run(link, check=True, cwd=str(CSRC))
     return LIB
 
 

@@ -1,0 +1,51 @@
+// Shared by the translation units of libmxpaillier.so: stream-ordered upload of small host operands
+// and a few launch-planning constants.
+#pragma once
+#include "mx_host.hpp"
+#include <cstring>
+#include <algorithm>
+
+using namespace mxh;
+
+// ---- stream-ordered upload of small host operands --------------------------------------------
+// Host operands (moduli, exponents, per-modulus constants) are a few KB.  Copying them with
+// hipMemcpyAsync from pageable memory would either block the host behind all earlier work of the
+// stream or leave the caller's buffer in use after return.  Instead they travel BY VALUE in the
+// kernel-argument block of a one-block copy kernel: the runtime captures the arguments at launch,
+// so the host buffer is free on return, nothing synchronises, and the copy is ordered in the stream.
+namespace {
+constexpr int UPLOAD_WORDS = 896;   // 3.5 KiB of the 4 KiB kernel-argument block
+struct UploadChunk { uint32_t w[UPLOAD_WORDS]; };
+
+__global__ void __launch_bounds__(256) upload_kernel(uint32_t* dst, UploadChunk c, int n) {
+  for (int i = threadIdx.x; i < n; i += 256) dst[i] = c.w[i];
+}
+
+int upload_words(void* d_dst, const uint32_t* h_src, size_t n, hipStream_t s) {
+  if (n <= (size_t)UPLOAD_WORDS * 32) {
+    UploadChunk c;
+    for (size_t off = 0; off < n; off += UPLOAD_WORDS) {
+      int m = (int)std::min<size_t>(UPLOAD_WORDS, n - off);
+      std::memcpy(c.w, h_src + off, (size_t)m * 4);
+      hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(256), 0, s, (uint32_t*)d_dst + off, c, m);
+      MX_HIP(hipGetLastError());
+    }
+    return MX_OK;
+  }
+  // large operand sets (thousands of candidate moduli): staged copy, then wait for it so that the
+  // caller may release h_src
+  MX_HIP(hipMemcpyAsync(d_dst, h_src, n * 4, hipMemcpyHostToDevice, s));
+  MX_HIP(hipStreamSynchronize(s));
+  return MX_OK;
+}
+#define MX_TRY(call) do { int rc__ = (call); if (rc__ != MX_OK) return rc__; } while (0)
+}  // namespace
+
+
+namespace {
+// Largest modulus the engine takes: R = 2^(W*L*64) >= 16 N.
+constexpr int MAX_MOD_BITS = LIMB_BITS * LIMBS_PER_LANE * 64 - 4;
+// Sizing queries only know the row width; assume the widest modulus that fits it.
+inline int sizing_bits(int limbs) { return 32 * limbs < MAX_MOD_BITS ? 32 * limbs : MAX_MOD_BITS; }
+constexpr int MAX_SLIDING_OPS = 16384;   // covers exponents up to 16384 bits
+}  // namespace
