@@ -35,10 +35,10 @@ HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
 # HBM bytes per powmod launch of the default workload, from the rocprofv3 --pmc passes committed in
 # profiles/r01_bench_single_stream_rocprof_summary.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB
-# (FETCH_SIZE counts half of wide coalesced reads on gfx950, MI355X guide).  It is the window
-# table (64 odd powers per ciphertext): 369 MB written once and ~2.5 GB of coalesced look-ups per
-# 10 000 modexps; the wide and the narrow geometry move the same bytes.
-MEASURED_TRAFFIC_DEFAULT = (2 * 1214063 + 365078) * 1024
+# (FETCH_SIZE counts half of wide coalesced reads on gfx950, MI355X guide).  It is the table of odd
+# powers (64 pairs per ciphertext, 72 slots in all): ~0.4 GB written once and ~2.7 GB of coalesced
+# look-ups per 10 000 modexps.
+MEASURED_TRAFFIC_DEFAULT = (2 * 1321248 + 430099) * 1024
 
 
 def parse() -> argparse.Namespace:
@@ -264,7 +264,7 @@ def main() -> None:
                           else ("mx::powmod_n2_kernel<%d,9,29>" % eng.geometry(n.bit_length())[0]),
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": MEASURED_TRAFFIC_DEFAULT if (batch == 10000 and args.key_length == 2048) else None,
+                "traffic": MEASURED_TRAFFIC_DEFAULT if (batch == 10000 and args.key_length == 2048 and not args.generic_modulus) else None,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/ (not collected live)",
                 "kernel_ms": powmod_ms, "concurrent_launches": nstreams,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -275,7 +275,10 @@ def main() -> None:
                     "achieved": agg_mac_rate / 1e12, "peak": VALU_MAC_PEAK / 1e12,
                     "unit": "T 32x32-bit MAC/s", "frac": agg_mac_rate / VALU_MAC_PEAK,
                     "algorithmic_macs_per_launch": alg_macs,
-                    "basis": "all launches of the timed region / wall time of the region, this GPU",
+                    "basis": "all launches of the timed region / wall time of the region, this GPU; the MAC count is "
+                             "SURVEY.md 8(d)'s figure for schoolbook Montgomery modulo N^2 — a fraction above 1 means "
+                             "the kernel needs fewer multiply-accumulates than that figure assumes (symmetric squaring, "
+                             "half-size passes modulo N)",
                 },
             },
         }
