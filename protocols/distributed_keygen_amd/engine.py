@@ -267,7 +267,7 @@ class Engine:
         _check_modulus(n)
         n2 = n * n
         limbs = _limbs.limbs_for(n2)
-        rn_t = self.powmod_shared_t(self.to_device(_limbs.pack([_reduce(r, n2) for r in randomness], limbs)), n2, n)
+        rn_t = self.powmod_nsquare_t(self.to_device(_limbs.pack([_reduce(r, n2) for r in randomness], limbs)), n, n)
         g_t = self.to_device(_limbs.pack([(1 + (m % n) * n) % n2 for m in messages], limbs))
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, g_t, n2, out_t=rn_t)))
 
