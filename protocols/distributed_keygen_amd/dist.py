@@ -70,6 +70,19 @@ def sharded_powmod_shared(engine: Any, bases_t, mod: int, exp: int, group: Any =
     return _gather_rows(local, world, group)[:batch]
 
 
+def sharded_powmod_nsquare(engine: Any, bases_t, n: int, exp: int, group: Any = None):
+    """Full-batch ``engine.powmod_nsquare_t`` (partial decryptions modulo n^2) as world slices + one
+    all-gather — the multi-GPU form of the loop distributed_keygen.py:463-466."""
+    rank, world = _world(group)
+    if world == 1:
+        return engine.powmod_nsquare_t(bases_t, n, exp)
+    batch = bases_t.shape[0]
+    per = -(-batch // world)
+    padded = _pad_rows(bases_t, per * world)
+    local = engine.powmod_nsquare_t(padded[rank * per : (rank + 1) * per].contiguous(), n, exp)
+    return _gather_rows(local, world, group)[:batch]
+
+
 def sharded_powmod_multi(
     engine: Any, bases_t, mods: Sequence[int], exps: Sequence[int], group_size: int, group: Any = None
 ):

@@ -21,6 +21,9 @@ class FakeTensorEngine:
     def powmod_shared_t(self, bases_t, mod, exp, out_t=None):
         return _rows([oracle.pow_mod(b, exp, mod) for b in _ints(bases_t)], bases_t.shape[1])
 
+    def powmod_nsquare_t(self, bases_t, n, exp, out_t=None):
+        return _rows([oracle.pow_mod(b, exp, n * n) for b in _ints(bases_t)], bases_t.shape[1])
+
     def powmod_multi_t(self, bases_t, mods, exps, group_size, out_t=None):
         vals = _ints(bases_t)
         out = [oracle.pow_mod(b, exps[k // group_size], mods[k // group_size]) for k, b in enumerate(vals)]

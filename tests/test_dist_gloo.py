@@ -44,6 +44,11 @@ def _worker(rank: int, world: int, port: int, ret) -> None:
         bases = [rng.randrange(mod) for _ in range(7)]
         got = mxdist.sharded_powmod_shared(eng, _rows(bases, L.limbs_for(mod)), mod, exp)
         assert _ints(got) == [pow(b, exp, mod) for b in bases]
+        # --- partial decryptions modulo n^2 (N-adic kernel entry), ragged batch
+        n_small = rng.getrandbits(100) | (1 << 99) | 1
+        cs = [rng.randrange(n_small * n_small) for _ in range(5)]
+        got = mxdist.sharded_powmod_nsquare(eng, _rows(cs, L.limbs_for(n_small * n_small)), n_small, exp)
+        assert _ints(got) == [pow(c, exp, n_small * n_small) for c in cs]
         # --- per-candidate modexp, 3 candidates x 5 bases over 2 ranks
         mods = [rng.getrandbits(131) | (1 << 130) | 1 for _ in range(3)]
         exps = [rng.getrandbits(129) for _ in mods]
