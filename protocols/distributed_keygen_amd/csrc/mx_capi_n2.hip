@@ -31,7 +31,7 @@ bool plan_n2(int n_bits, int limbs_n, int exp_bits, int64_t batch, N2Plan& p, in
 template <int K, int L>
 int launch_n2_kl(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   using M_t = mx::Mont<K, L, LIMB_BITS, true>;
-  size_t lds = (size_t)(64 / K) * (M_t::LDS_WORDS + 2 * M_t::S + 8) * 4;
+  size_t lds = (size_t)(64 / K) * (M_t::LDS_WORDS + 3 * M_t::S + 8) * 4;
   hipLaunchKernelGGL((mx::powmod_n2_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;

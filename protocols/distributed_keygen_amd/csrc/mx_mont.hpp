@@ -231,7 +231,8 @@ struct Mont {
   //   F_PLAIN     no reduction: plain product; the limb leaving the group's lane 0 at every step
   //               is the next low limb of the result and is written to `emit` (LDS), the value left
   //               in the accumulator is the high part
-  static constexpr int F_RECORD_Q = 1, F_SQUARE = 2, F_TWO = 4, F_INIT = 8, F_PLAIN = 16;
+  //   F_BDOUBLE   the multiplier staged in LDS is 2*b (used for the 2*X0*X1 row of a pair squaring)
+  static constexpr int F_RECORD_Q = 1, F_SQUARE = 2, F_TWO = 4, F_INIT = 8, F_PLAIN = 16, F_BDOUBLE = 32;
 
   template <int F, int I, int J>
   __device__ __forceinline__ void slot_macs(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], u32 bi, u32 bi2,
@@ -251,10 +252,11 @@ struct Mont {
 
   template <int F, int I>
   __device__ __forceinline__ void limb_step(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], const u32 (&bb)[L],
-                                            const u32 (&bb2)[L], const u32 (&dd)[L], u32 (&qr)[L], int blk,
-                                            u32* emit) const {
+                                            const u32 (&dd)[L], u32 (&qr)[L], int blk, u32* emit) const {
     const u32 bi = bb[I];
-    const u32 bi2 = bb2[I];
+    // doubled multiplier limb for the weight-2 products of a squaring (a shift is cheaper than a
+    // second LDS copy of b: measured)
+    const u32 bi2 = (F & F_SQUARE) ? (bi << 1) : 0u;
     const u32 di = dd[I];
     product_mac<(F & F_SQUARE) != 0, I, 0>(t, a, bi, bi2);
     if constexpr (F & F_TWO) t[0] += (u64)c[0] * di;
@@ -280,9 +282,9 @@ struct Mont {
 
   template <int F, int... Is>
   __device__ __forceinline__ void block_steps(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], const u32 (&bb)[L],
-                                              const u32 (&bb2)[L], const u32 (&dd)[L], u32 (&qr)[L], int blk,
+                                              const u32 (&dd)[L], u32 (&qr)[L], int blk,
                                               u32* emit, std::integer_sequence<int, Is...>) const {
-    (limb_step<F, Is>(t, a, c, bb, bb2, dd, qr, blk, emit), ...);
+    (limb_step<F, Is>(t, a, c, bb, dd, qr, blk, emit), ...);
   }
 
   // ------------------------------------------------------------------ Montgomery product
@@ -302,7 +304,7 @@ struct Mont {
     // stage the multiplier(s) where every lane of the group can read any limb
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < L; ++j) lds[p * L + j] = b[j];
+    for (int j = 0; j < L; ++j) lds[p * L + j] = (F & F_BDOUBLE) ? (b[j] << 1) : b[j];
     if constexpr (F & F_TWO) {
 #pragma unroll
       for (int j = 0; j < L; ++j) lds[LDS_D + p * L + j] = d[j];
@@ -315,16 +317,12 @@ struct Mont {
 #pragma unroll
     for (int j = 0; j < L; ++j) qr[j] = 0;
     for (int blk = 0; blk < nsteps_blk; ++blk) {
-      u32 bb[L], bb2[L], dd[L];
+      u32 bb[L], dd[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];
-      // doubled multiplier limbs for the weight-2 products of a squaring (a shift is cheaper than a
-      // second LDS copy of b: measured)
-#pragma unroll
-      for (int j = 0; j < L; ++j) bb2[j] = (F & F_SQUARE) ? (bb[j] << 1) : 0u;
 #pragma unroll
       for (int j = 0; j < L; ++j) dd[j] = (F & F_TWO) ? lds[LDS_D + blk * L + j] : 0u;
-      block_steps<F>(t, a, c, bb, bb2, dd, qr, blk, emit, std::make_integer_sequence<int, L>{});
+      block_steps<F>(t, a, c, bb, dd, qr, blk, emit, std::make_integer_sequence<int, L>{});
     }
     normalize_weak(r, t);
     if constexpr (F & F_RECORD_Q) {

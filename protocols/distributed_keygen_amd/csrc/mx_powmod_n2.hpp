@@ -55,36 +55,34 @@ struct PairArith {
   using M_t = Mont<K, L, W, true>;
   static constexpr u32 MASK = M_t::MASK;
   M_t& M;
-  u32 cp[L];          // this lane's limbs of C' = C - R + 1
+  const u32* cp;      // LDS: limbs of C' = C - R + 1 (this group's copy, slice of lane p at cp[p*L ..])
 
-  __device__ __forceinline__ explicit PairArith(M_t& m) : M(m) {}
+  __device__ __forceinline__ PairArith(M_t& m, const u32* cprime_lds) : M(m), cp(cprime_lds) {}
 
-  // accumulator start of the second pass: C' + (R - 1 - Q), limb-wise
-  __device__ __forceinline__ void second_pass_init(u32 (&init)[L], const u32 (&q)[L]) const {
+  // accumulator start of the second pass: C' + (R - 1 - Q), limb-wise (in place in q)
+  __device__ __forceinline__ void second_pass_init(u32 (&q)[L]) const {
     const bool has_q = M.p < M.nblk;
 #pragma unroll
-    for (int j = 0; j < L; ++j) init[j] = cp[j] + (has_q ? (MASK - q[j]) : 0u);
+    for (int j = 0; j < L; ++j) q[j] = cp[M.p * L + j] + (has_q ? (MASK - q[j]) : 0u);
   }
 
   // (z0, z1) = (x0, x1) * (y0, y1); outputs may alias inputs
   __device__ __forceinline__ void mul(u32 (&z0)[L], u32 (&z1)[L], const u32 (&x0)[L], const u32 (&x1)[L],
                                       const u32 (&y0)[L], const u32 (&y1)[L]) {
-    u32 t0[L], q[L], init[L];
+    u32 t0[L], q[L];
     M.template mulx<M_t::F_RECORD_Q>(t0, x0, y0, x0, x0, x0, q, nullptr, M.nblk);
-    second_pass_init(init, q);
-    M.template mulx<M_t::F_TWO | M_t::F_INIT>(z1, x0, y1, x1, y0, init, nullptr, nullptr, M.nblk);
+    second_pass_init(q);
+    M.template mulx<M_t::F_TWO | M_t::F_INIT>(z1, x0, y1, x1, y0, q, nullptr, nullptr, M.nblk);
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
 
   // (z0, z1) = (x0, x1)^2
   __device__ __forceinline__ void sqr(u32 (&z0)[L], u32 (&z1)[L], const u32 (&x0)[L], const u32 (&x1)[L]) {
-    u32 t0[L], q[L], init[L], x1d[L];
+    u32 t0[L], q[L];
     M.template mulx<M_t::F_RECORD_Q | M_t::F_SQUARE>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
-    second_pass_init(init, q);
-#pragma unroll
-    for (int j = 0; j < L; ++j) x1d[j] = x1[j] << 1;              // 2 * X0 * X1
-    M.template mulx<M_t::F_INIT>(z1, x0, x1d, x0, x0, init, nullptr, nullptr, M.nblk);
+    second_pass_init(q);
+    M.template mulx<M_t::F_INIT | M_t::F_BDOUBLE>(z1, x0, x1, x0, x0, q, nullptr, nullptr, M.nblk);   // 2 * X0 * X1
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
@@ -102,7 +100,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
   using M_t = Mont<K, L, W, true>;
   constexpr int S = M_t::S;
   constexpr int WIDE = 2 * S + 8;                 // words: input row staging / output limbs
-  constexpr int GROUP_WORDS = M_t::LDS_WORDS + WIDE;
+  constexpr int GROUP_WORDS = M_t::LDS_WORDS + WIDE + S;   // + this group's copy of C' (S limbs)
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;
   const int lane = threadIdx.x;
@@ -118,9 +116,16 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
   M.init(smem + gw * GROUP_WORDS, A.nblk);
   M.load(M.n, A.consts, A.limbsn);
   M.setup_modulus();
-  PairArith<K, L, W> P(M);
-  M.load(P.cp, A.consts + 7 * A.limbsn, A.limbsn);
   const int p = M.p;
+  u32* cp_lds = wide + WIDE;
+  {
+    u32 v[L];
+    M.load(v, A.consts + 7 * A.limbsn, A.limbsn);
+#pragma unroll
+    for (int j = 0; j < L; ++j) cp_lds[p * L + j] = v[j];
+    __syncthreads();
+  }
+  PairArith<K, L, W> P(M, cp_lds);
 
   u32* slots = A.slots + gl;
   auto slot_at = [&](int slot, int half, int j) -> u32& { return slots[(((i64)slot * 2 + half) * L + j) * nlanes]; };

@@ -76,3 +76,19 @@ def test_randomized_differential(eng):
         assert eng.powmod_batch(bases, exp, mod) == [pow(b, exp, mod) for b in bases], (trial, bits, ebits, batch)
         a = [rng.randrange(mod) for _ in range(batch)]
         assert eng.mulmod_batch(a, bases, mod) == [x * y % mod for x, y in zip(a, bases)]
+
+
+@pytest.mark.parametrize("lpl", [9, 18])
+def test_nsquare_pair_kernel_special_operands(eng, lpl):
+    """The N-adic pair kernel (mx_powmod_nsquare) in both lane geometries: bases that are multiples of
+    N (lazy digit carries in the final conversion), all-ones patterns, tiny and huge exponents."""
+    eng.set_limbs_per_lane(lpl)
+    rng = random.Random(99 + lpl)
+    for bits in (33, 261, 300, 1028, 2051):
+        for n in _special_moduli(bits)[:4]:
+            n2 = n * n
+            bases = [0, 1, n - 1, n, n + 1, 2 * n, n * (n - 1), n2 - 1, n2 - n, (n2 - 1) // 2]
+            bases += _special_bases(n2, rng)[9:]
+            for e in (0, 1, 2, 3, n, rng.getrandbits(200) | 1):
+                assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (bits, e.bit_length())
+    eng.set_limbs_per_lane(0)
