@@ -39,6 +39,10 @@ VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
 # powers (64 pairs per ciphertext, 72 slots in all): ~0.4 GB written once and ~2.7 GB of coalesced
 # look-ups per 10 000 modexps.
 MEASURED_TRAFFIC_DEFAULT = (2 * 1321248 + 430099) * 1024
+# VALU wave-instructions one powmod_n2_kernel launch of the default workload issues (SQ_INSTS_VALU of
+# the same profile), and the issue peak: 1024 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz.
+MEASURED_VALU_INSTS_DEFAULT = 2.2924e10
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4
 
 
 def parse() -> argparse.Namespace:
@@ -275,6 +279,10 @@ def main() -> None:
                     "achieved": agg_mac_rate / 1e12, "peak": VALU_MAC_PEAK / 1e12,
                     "unit": "T 32x32-bit MAC/s", "frac": agg_mac_rate / VALU_MAC_PEAK,
                     "algorithmic_macs_per_launch": alg_macs,
+                    "issue_utilization": (MEASURED_VALU_INSTS_DEFAULT * args.steps / elapsed / VALU_ISSUE_PEAK)
+                    if (batch == 10000 and args.key_length == 2048 and not args.generic_modulus) else None,
+                    "issue_utilization_basis": "SQ_INSTS_VALU per launch (profiles/, 2.29e10) x launches / wall time, over "
+                                               "1024 SIMDs x 2.4 GHz / 4 cycles per VALU instruction",
                     "basis": "all launches of the timed region / wall time of the region, this GPU; the MAC count is "
                              "SURVEY.md 8(d)'s figure for schoolbook Montgomery modulo N^2 — a fraction above 1 means "
                              "the kernel needs fewer multiply-accumulates than that figure assumes (symmetric squaring, "
