@@ -4,6 +4,7 @@ HIP library is missing, importing this module fails loudly."""
 from __future__ import annotations
 
 import ctypes
+import os
 from ctypes import c_char_p, c_int, c_int64, c_void_p, POINTER
 from pathlib import Path
 
@@ -48,6 +49,10 @@ class MxError(RuntimeError):
 
 
 def load() -> ctypes.CDLL:
+    global LIB_PATH
+    override = os.environ.get("MX_LIBRARY")      # developer knob: A/B runs of differently built kernels
+    if override:
+        LIB_PATH = Path(override)
     if not LIB_PATH.exists():
         raise ImportError(
             f"{LIB_PATH} is missing — build it with `python -m protocols.distributed_keygen_amd.build` "

@@ -30,8 +30,7 @@ bool plan_n2(int n_bits, int limbs_n, int exp_bits, int64_t batch, N2Plan& p, in
 
 template <int K, int L>
 int launch_n2_kl(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
-  using M_t = mx::Mont<K, L, LIMB_BITS, true>;
-  size_t lds = (size_t)(64 / K) * (M_t::LDS_WORDS + 3 * M_t::S + 8) * 4;
+  size_t lds = mx::powmod_n2_lds_bytes<K, L>();
   hipLaunchKernelGGL((mx::powmod_n2_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
@@ -47,13 +46,25 @@ int launch_n2_k(const mx::PowmodN2Args& a, int64_t nblocks, int lpl, hipStream_t
   return launch_n2_kl<K, LIMBS_PER_LANE>(a, nblocks, s);
 }
 
-int n2_limbs_per_lane() {
+// Geometry of the pair kernel.  Measured on MI355X (tools/ab_geometry.sh, tools/ab_streams.sh,
+// tools/sweep_keys.sh): the wide geometry issues ~23 % fewer instructions per element, but it runs 2
+// wavefronts per SIMD and puts twice the elements into a wavefront.  Saturated it is 11 % faster
+// (292 k vs 262 k modexps/s at key_length 2048); with launches that do not fill the machine on their
+// own (10 000 ciphertexts = 625 wide wavefronts for 2048 slots) its rate depends on how concurrent
+// launches happen to interleave (228 k or 263 k) while the narrow one is steady (240-256 k).  So: wide
+// only when one launch alone brings at least 1536 wavefronts.
+int n2_limbs_per_lane(int n_bits, int64_t batch) {
   if (g_limbs_per_lane == LIMBS_PER_LANE || g_limbs_per_lane == LIMBS_PER_LANE_WIDE) return g_limbs_per_lane;
   if (const char* e = getenv("MX_LIMBS_PER_LANE")) {
     int v = atoi(e);
     if (v == LIMBS_PER_LANE || v == LIMBS_PER_LANE_WIDE) return v;
   }
-  return LIMBS_PER_LANE;
+  Geometry narrow, wide;
+  if (!choose_geometry(n_bits, narrow, LIMBS_PER_LANE) || !choose_geometry(n_bits, wide, LIMBS_PER_LANE_WIDE))
+    return LIMBS_PER_LANE;
+  if (narrow.K < 8 || wide.K > 16) return LIMBS_PER_LANE;
+  const int64_t waves = (batch * wide.K + 63) / 64;
+  return waves >= 1536 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
 }
 }  // namespace
 
@@ -77,7 +88,7 @@ extern "C" int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const
   if (2 * bits - 1 > 32 * limbs2) return MX_ERR_ARG;          // rows too narrow for N^2
   const int ebits = bit_length(h_exp, exp_limbs);
   N2Plan p;
-  if (!plan_n2(bits, limbs_n, 32 * exp_limbs, batch, p, n2_limbs_per_lane())) return MX_ERR_SIZE;
+  if (!plan_n2(bits, limbs_n, 32 * exp_limbs, batch, p, n2_limbs_per_lane(bits, batch))) return MX_ERR_SIZE;
   if (p.total > ws_bytes) return MX_ERR_WORKSPACE;
   const int m = p.geo.W * p.geo.L * p.geo.nblk;                // R = 2^m
   const int k = bits - 1;                                      // x = x_lo + 2^k x_hi

@@ -5,8 +5,7 @@
 namespace mxw {
 template <int K>
 static int launch(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
-  using M_t = mx::Mont<K, LIMBS_PER_LANE_WIDE, LIMB_BITS, true>;
-  size_t lds = (size_t)(64 / K) * (M_t::LDS_WORDS + 3 * M_t::S + 8) * 4;
+  size_t lds = mx::powmod_n2_lds_bytes<K, LIMBS_PER_LANE_WIDE>();
   hipLaunchKernelGGL((mx::powmod_n2_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;

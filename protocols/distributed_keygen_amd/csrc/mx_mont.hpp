@@ -46,6 +46,7 @@ struct Mont {
   u32 n0inv;     // -N^-1 mod 2^W
   u32 keep_next, keep_prev;
   u32 maskv;     // MASK held in a VGPR (a DPP-modified VOP2 cannot take a literal operand)
+  u32 onev;      // 1 held in a VGPR the compiler cannot see through (see limb_step)
   u32 next_mask; // keep_next & MASK
   int p;         // lane position in the group
   int nblk;      // R = 2^(W*L*nblk)
@@ -58,6 +59,8 @@ struct Mont {
     keep_prev = LN::keep_prev_mask();
     maskv = MASK;
     asm volatile("" : "+v"(maskv));   // opaque: keeps the constant in a VGPR
+    onev = 1u;
+    asm volatile("" : "+v"(onev));
     next_mask = keep_next & maskv;
     lds = lds_group;
     nblk = nblk_;
@@ -232,7 +235,17 @@ struct Mont {
   //               is the next low limb of the result and is written to `emit` (LDS), the value left
   //               in the accumulator is the high part
   //   F_BDOUBLE   the multiplier staged in LDS is 2*b (used for the 2*X0*X1 row of a pair squaring)
-  static constexpr int F_RECORD_Q = 1, F_SQUARE = 2, F_TWO = 4, F_INIT = 8, F_PLAIN = 16, F_BDOUBLE = 32;
+  //   F_STAGED    the multiplier(s) are already in LDS (stage_multipliers): b and d are not read
+  static constexpr int F_RECORD_Q = 1, F_SQUARE = 2, F_TWO = 4, F_INIT = 8, F_PLAIN = 16, F_BDOUBLE = 32,
+                       F_STAGED = 64;
+
+  // b (and d) where every lane of the group can read any limb; they stay valid until the next staging
+  __device__ __forceinline__ void stage_multipliers(const u32 (&b)[L], const u32 (&d)[L]) {
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < L; ++j) { lds[p * L + j] = b[j]; lds[LDS_D + p * L + j] = d[j]; }
+    __syncthreads();
+  }
 
   template <int F, int I, int J>
   __device__ __forceinline__ void slot_macs(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], u32 bi, u32 bi2,
@@ -277,7 +290,9 @@ struct Mont {
     t[0] = t[1] + carry;
 #pragma unroll
     for (int j = 1; j < L - 1; ++j) t[j] = t[j + 1];
-    t[L - 1] = recv;
+    // the incoming word opens the new top column as recv * 1: one multiply-add wherever the
+    // compiler places it in the column's chain, instead of a zero-extension plus a 64-bit add
+    t[L - 1] = (u64)recv * onev;
   }
 
   template <int F, int... Is>
@@ -299,17 +314,21 @@ struct Mont {
   // with weight 1 — so every term of a^2 gets its coefficient, the selection is the same in every
   // lane (compile-time register indices), and floor(L/2)+1 instead of L product MACs are issued.
   template <int F>
-  __device__ __forceinline__ void mulx(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], const u32 (&c)[L],
+  // a and c are not const: their registers are passed through an empty asm once per block (see
+  // below); values are unchanged.
+  __device__ __forceinline__ void mulx(u32 (&r)[L], u32 (&a)[L], const u32 (&b)[L], u32 (&c)[L],
                                        const u32 (&d)[L], const u32 (&init)[L], u32* qrec, u32* emit, int nsteps_blk) {
     // stage the multiplier(s) where every lane of the group can read any limb
-    __syncthreads();
+    if constexpr (!(F & F_STAGED)) {
+      __syncthreads();
 #pragma unroll
-    for (int j = 0; j < L; ++j) lds[p * L + j] = (F & F_BDOUBLE) ? (b[j] << 1) : b[j];
-    if constexpr (F & F_TWO) {
+      for (int j = 0; j < L; ++j) lds[p * L + j] = (F & F_BDOUBLE) ? (b[j] << 1) : b[j];
+      if constexpr (F & F_TWO) {
 #pragma unroll
-      for (int j = 0; j < L; ++j) lds[LDS_D + p * L + j] = d[j];
+        for (int j = 0; j < L; ++j) lds[LDS_D + p * L + j] = d[j];
+      }
+      __syncthreads();
     }
-    __syncthreads();
     u64 t[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) t[j] = (F & F_INIT) ? (u64)init[j] : 0;
@@ -317,6 +336,16 @@ struct Mont {
 #pragma unroll
     for (int j = 0; j < L; ++j) qr[j] = 0;
     for (int blk = 0; blk < nsteps_blk; ++blk) {
+      // The multiplicand limbs are loop invariant, and the compiler would hoist their zero
+      // extension to 64 bits out of this loop — every limb then occupies a register PAIR for the
+      // whole product (v_mad_u64_u32 only reads the low half).  Opaque per block: the extension
+      // folds into the multiply-add and the limbs stay in single registers.
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        asm volatile("" : "+v"(a[j]));
+        if constexpr (F & F_TWO) asm volatile("" : "+v"(c[j]));
+        if constexpr (!(F & F_PLAIN)) asm volatile("" : "+v"(n[j]));
+      }
       u32 bb[L], dd[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];
@@ -333,7 +362,10 @@ struct Mont {
 
   template <bool RECORD_Q = false, bool SQUARE = false>
   __device__ __forceinline__ void mul(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L], u32* qrec = nullptr) {
-    mulx<(RECORD_Q ? F_RECORD_Q : 0) | (SQUARE ? F_SQUARE : 0)>(r, a, b, a, a, a, qrec, nullptr, nblk);
+    u32 av[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) av[j] = a[j];
+    mulx<(RECORD_Q ? F_RECORD_Q : 0) | (SQUARE ? F_SQUARE : 0)>(r, av, b, av, b, b, qrec, nullptr, nblk);
   }
 
   // r = a^2 / R mod N (lazy), with the symmetric product

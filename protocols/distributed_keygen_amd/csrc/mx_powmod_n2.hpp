@@ -38,6 +38,12 @@ enum : u32 { N2_SQR = 0, N2_MUL = 1, N2_ADD = 2, N2_LOAD = 3, N2_STORE = 4 };
 constexpr int N2_SLOT_K1 = 0, N2_SLOT_K2 = 1, N2_SLOT_E = 2, N2_SLOT_ONE = 3, N2_SLOT_LO = 4, N2_SLOT_HI = 5,
               N2_SLOT_TMP = 6, N2_SLOT_SQ = 7, N2_SLOT_TABLE = 8;
 
+// LDS of one workgroup (one wavefront): per group the Montgomery scratch (which the input row and
+// the output limbs reuse), plus ONE copy of C' for all groups.  Small enough that the register
+// file, not LDS, bounds occupancy: 10 KB per wavefront for <4,18>, 5 KB for <8,9>.
+template <int K, int L>
+constexpr size_t powmod_n2_lds_bytes() { return ((size_t)(64 / K) * (2 * K * L + 8) + (size_t)K * L) * 4; }
+
 struct PowmodN2Args {
   const u32* bases;   // [batch][limbs2] device
   u32* out;           // [batch][limbs2] device
@@ -55,7 +61,7 @@ struct PairArith {
   using M_t = Mont<K, L, W, true>;
   static constexpr u32 MASK = M_t::MASK;
   M_t& M;
-  const u32* cp;      // LDS: limbs of C' = C - R + 1 (this group's copy, slice of lane p at cp[p*L ..])
+  const u32* cp;      // LDS: limbs of C' = C - R + 1 (one copy per workgroup, slice of lane p at cp[p*L ..])
 
   __device__ __forceinline__ PairArith(M_t& m, const u32* cprime_lds) : M(m), cp(cprime_lds) {}
 
@@ -67,22 +73,24 @@ struct PairArith {
   }
 
   // (z0, z1) = (x0, x1) * (y0, y1); outputs may alias inputs
-  __device__ __forceinline__ void mul(u32 (&z0)[L], u32 (&z1)[L], const u32 (&x0)[L], const u32 (&x1)[L],
+  __device__ __forceinline__ void mul(u32 (&z0)[L], u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L],
                                       const u32 (&y0)[L], const u32 (&y1)[L]) {
+    // both multipliers go to LDS once: pass 1 reads y0, pass 2 reads y0 (row X1*Y0) and y1 (row X0*Y1)
+    M.stage_multipliers(y0, y1);
     u32 t0[L], q[L];
-    M.template mulx<M_t::F_RECORD_Q>(t0, x0, y0, x0, x0, x0, q, nullptr, M.nblk);
+    M.template mulx<M_t::F_RECORD_Q | M_t::F_STAGED>(t0, x0, y0, x0, y0, y0, q, nullptr, M.nblk);
     second_pass_init(q);
-    M.template mulx<M_t::F_TWO | M_t::F_INIT>(z1, x0, y1, x1, y0, q, nullptr, nullptr, M.nblk);
+    M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_STAGED>(z1, x1, y0, x0, y1, q, nullptr, nullptr, M.nblk);
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
 
   // (z0, z1) = (x0, x1)^2
-  __device__ __forceinline__ void sqr(u32 (&z0)[L], u32 (&z1)[L], const u32 (&x0)[L], const u32 (&x1)[L]) {
+  __device__ __forceinline__ void sqr(u32 (&z0)[L], u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L]) {
     u32 t0[L], q[L];
     M.template mulx<M_t::F_RECORD_Q | M_t::F_SQUARE>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
     second_pass_init(q);
-    M.template mulx<M_t::F_INIT | M_t::F_BDOUBLE>(z1, x0, x1, x0, x0, q, nullptr, nullptr, M.nblk);   // 2 * X0 * X1
+    M.template mulx<M_t::F_INIT | M_t::F_BDOUBLE>(z1, x0, x1, x0, x1, q, nullptr, nullptr, M.nblk);   // 2 * X0 * X1
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
@@ -99,8 +107,9 @@ template <int K, int L, int W>
 __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true>;
   constexpr int S = M_t::S;
-  constexpr int WIDE = 2 * S + 8;                 // words: input row staging / output limbs
-  constexpr int GROUP_WORDS = M_t::LDS_WORDS + WIDE + S;   // + this group's copy of C' (S limbs)
+  constexpr int WIDE = M_t::LDS_WORDS;            // words: input row staging / output limbs (reuses the scratch)
+  constexpr int GROUP_WORDS = M_t::LDS_WORDS;
+  static_assert(WIDE == 2 * S + 8, "row staging");
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;
   const int lane = threadIdx.x;
@@ -108,26 +117,26 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
   const i64 elem_raw = (i64)blockIdx.x * GPW + gw;
   const bool valid = elem_raw < A.batch;
   const i64 elem = valid ? elem_raw : A.batch - 1;
-  const i64 nlanes = (i64)gridDim.x * 64;
-  const i64 gl = (i64)blockIdx.x * 64 + lane;
-  u32* wide = smem + gw * GROUP_WORDS + M_t::LDS_WORDS;
+  u32* wide = smem + gw * GROUP_WORDS;            // same words as the Montgomery scratch M.lds
 
   M_t M;
   M.init(smem + gw * GROUP_WORDS, A.nblk);
   M.load(M.n, A.consts, A.limbsn);
   M.setup_modulus();
   const int p = M.p;
-  u32* cp_lds = wide + WIDE;
+  u32* cp_lds = smem + GPW * GROUP_WORDS;
   {
     u32 v[L];
     M.load(v, A.consts + 7 * A.limbsn, A.limbsn);
+    if (gw == 0) {
 #pragma unroll
-    for (int j = 0; j < L; ++j) cp_lds[p * L + j] = v[j];
+      for (int j = 0; j < L; ++j) cp_lds[p * L + j] = v[j];
+    }
     __syncthreads();
   }
   PairArith<K, L, W> P(M, cp_lds);
-
-  u32* slots = A.slots + gl;
+  const i64 nlanes = (i64)gridDim.x * 64;
+  u32* slots = A.slots + ((i64)blockIdx.x * 64 + lane);
   auto slot_at = [&](int slot, int half, int j) -> u32& { return slots[(((i64)slot * 2 + half) * L + j) * nlanes]; };
 
   // ---- prologue: constant pairs and the two halves of x into their slots (no arithmetic)
@@ -208,9 +217,11 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
     M.normalize_full(acc1, t);
     M.cond_sub(acc1);
   }
+  // the low limbs are written over the staged multiplier: block blk emits into the L words it has
+  // just read (LDS operations of a wavefront execute in order)
   u32 hi[L];
   __syncthreads();
-  M.template mulx<M_t::F_INIT | M_t::F_PLAIN>(hi, acc1, M.n, acc1, acc1, acc0, nullptr, wide, A.nblk);
+  M.template mulx<M_t::F_INIT | M_t::F_PLAIN>(hi, acc1, M.n, acc1, M.n, acc0, nullptr, wide, A.nblk);
   {
     u64 t[L];
 #pragma unroll

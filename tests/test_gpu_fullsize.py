@@ -59,6 +59,12 @@ def test_c3_10k_ciphertexts_roundtrip_key2048(eng):
     with mp.Pool() as pool:
         want = pool.starmap(pow, [(cts[k], key.exponent(i_pos), n2) for k in idx], chunksize=8)
     assert [partials[i_pos - 1][k] for k in idx] == want
+    # the N-adic pair kernel (mx_powmod_nsquare, what partial_decrypt_batch and bench.py launch), in
+    # both lane geometries, on all 10 000: identical to the generic-modulus kernel checked above
+    for lpl in (9, 18):
+        eng.set_limbs_per_lane(lpl)
+        assert eng.powmod_nsquare_batch(cts, key.exponent(i_pos), n) == partials[i_pos - 1], lpl
+    eng.set_limbs_per_lane(0)
     for k in (3, 4999, 9999):                                          # samples bit-exact vs the oracle
         for i in (1, 2, 3):
             assert partials[i - 1][k] == oracle.partial_decrypt(cts[k], n, i, key.degree, key.n_fac, key.shares[i])
