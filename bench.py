@@ -29,37 +29,44 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
+# The HIP runtime multiplexes streams onto 4 hardware queues by default; with more than 3 steps in
+# flight two streams then share a queue and serialise (measured: 4 streams 203 k modexps/s with 4
+# queues, 246-272 k with 8; tools/ab_queues.sh).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # measured on MI355X: v_mad_u64_u32, 8 waves/SIMD, 2.085 ns per wave-instruction per SIMD
 # (profiles/r01_ubench_valu_rates.txt)  ->  1024 SIMDs * 64 lanes / 2.085 ns
 VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
 # HBM bytes per powmod launch of the default workload, from the rocprofv3 --pmc passes committed in
-# profiles/r01_bench_single_stream_rocprof_summary.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB
+# profiles/r01_bench_single_stream_{wide,narrow}_rocprof_summary.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB
 # (FETCH_SIZE counts half of wide coalesced reads on gfx950, MI355X guide).  It is the table of odd
-# powers (64 pairs per ciphertext, 72 slots in all): ~0.4 GB written once and ~2.7 GB of coalesced
-# look-ups per 10 000 modexps.
-MEASURED_TRAFFIC_DEFAULT = (2 * 1321248 + 430099) * 1024
+# powers (64 pairs per ciphertext, 72 slots in all): ~0.4-0.5 GB written and ~2.7 GB of coalesced
+# look-ups per 10 000 modexps.  Keyed by limbs per lane (narrow, wide geometry).
+MEASURED_TRAFFIC_DEFAULT = {9: (2 * 1320544 + 410039) * 1024, 18: (2 * 1414452 + 501894) * 1024}
 # VALU wave-instructions one powmod_n2_kernel launch of the default workload issues (SQ_INSTS_VALU of
 # the same profile), and the issue peak: 1024 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz.
-MEASURED_VALU_INSTS_DEFAULT = 2.2924e10
+MEASURED_VALU_INSTS_DEFAULT = {9: 2.2432e10, 18: 1.8393e10}     # by limbs per lane (narrow, wide geometry)
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4
 
 
 def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=9)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=12)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--batch", type=int, default=10000, help="ciphertexts per step per GPU")
     ap.add_argument("--key-length", type=int, default=2048)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--check", type=int, default=6, help="elements verified against CPython pow after timing")
-    ap.add_argument("--streams", type=int, default=3,
+    ap.add_argument("--streams", type=int, default=0,
                     help="independent steps (10k-ciphertext batches) kept in flight, one HIP stream each; "
-                         "1 = strictly one batch at a time")
+                         "1 = strictly one batch at a time; 0 = automatic: 4, or the count in 5..8 (or 3) that "
+                         "divides --steps so that every stream runs the same number of steps")
     ap.add_argument("--limbs-per-lane", type=int, default=-1,
-                    help="lane geometry 9|18 of the generic kernel, 0 = library heuristic; default: 18 when >= 3 steps are in flight")
+                    help="lane geometry 9|18, 0 = library heuristic; default: 18 (wide) when at least 4 steps "
+                         "are in flight and the modulus has >= 2048 bits")
     ap.add_argument("--generic-modulus", action="store_true",
                     help="time mx_powmod_shared on the modulus N^2 instead of mx_powmod_nsquare (pairs modulo N)")
     return ap.parse_args()
@@ -132,7 +139,21 @@ def main() -> None:
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
     eng = Engine(local_rank)
-    lpl = args.limbs_per_lane if args.limbs_per_lane >= 0 else (18 if (args.streams >= 3 and args.generic_modulus) else 0)
+    if args.streams <= 0:
+        args.streams = next((d for d in (4, 5, 6, 7, 8, 3) if args.steps % d == 0), min(4, max(1, args.steps)))
+    # Lane geometry (mx_set_limbs_per_lane, part of the C ABI): the wide geometry issues 18 % fewer
+    # instructions per modexp; it is selected when the launches in flight together over-subscribe its
+    # 2048 wavefront slots, otherwise the library's per-launch heuristic decides.
+    if args.limbs_per_lane >= 0:
+        lpl = args.limbs_per_lane
+    elif args.generic_modulus:
+        lpl = 18 if args.streams >= 3 else 0
+    else:
+        wide_lanes = 1
+        while wide_lanes * 29 * 18 < args.key_length + 8:
+            wide_lanes *= 2
+        wide_waves_in_flight = args.streams * args.batch * wide_lanes // 64
+        lpl = 18 if (args.streams >= 4 and args.key_length >= 2048 and wide_waves_in_flight >= 2048) else 0
     eng.set_limbs_per_lane(lpl)
     key = synthetic.make_key(args.key_length, 3, 1)
     n, n2 = key.n, key.n_square
@@ -158,7 +179,6 @@ def main() -> None:
         own_in_t = eng.to_device(L.pack([pow(c, -1, n2) for c in cts], limbs2))
     own_slot = parties.index(own)
     theta_inv = key.theta_inv
-    kern_ms = []
     # one set of buffers (and one engine workspace) per in-flight step
     lanes = []
     for k in range(nstreams):
@@ -176,19 +196,13 @@ def main() -> None:
     def step(timed: bool, k: int = 0) -> None:
         ln = lanes[k % nstreams]
         with torch.cuda.stream(ln["stream"]):
-            e0 = torch.cuda.Event(enable_timing=True)
-            e1 = torch.cuda.Event(enable_timing=True)
-            e0.record()
             if args.generic_modulus:
                 ln["eng"].powmod_shared_t(own_in_t, n2, own_exp, out_t=ln["partials"][own_slot])
             else:
                 ln["eng"].powmod_nsquare_t(own_in_t, n, own_exp, out_t=ln["partials"][own_slot])
-            e1.record()
             if world > 1:
                 dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][own_slot].reshape(-1))
             ln["eng"].combine_t(ln["partials"], n, theta_inv, out_t=ln["msg"], status_t=ln["status"])
-            if timed:
-                kern_ms.append((e0, e1))
 
     def barrier() -> None:
         if world > 1:
@@ -198,16 +212,22 @@ def main() -> None:
     for k in range(args.warmup):
         step(False, k)
     barrier()
+    # HIP events around the modexp kernel itself, recorded by the library on the stream it launches
+    # on (mx_profile): the same interval rocprofv3 --kernel-trace reports for that kernel
+    eng.profile(True)
     t0 = time.perf_counter()
     for k in range(args.steps):
         step(True, k)
     barrier()
     elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    kernel_total_ms, kernel_launches = eng.profile_collect()
+    assert kernel_launches == args.steps, (kernel_launches, args.steps)
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    powmod_ms = sum(a.elapsed_time(b) for a, b in kern_ms) / max(1, len(kern_ms))
+    powmod_ms = kernel_total_ms / kernel_launches
 
     # ---- verification (outside the timed region)
     for ln in lanes:
@@ -258,17 +278,18 @@ def main() -> None:
                             "partial-decrypt c^exp mod N^2 + share-combine (BASELINE.json configs[2])",
                 "batch_per_gpu": batch, "mod_bits": n2.bit_length(), "exp_bits": e_bits,
                 "limbs_u32": s_limbs, "party": own, "parallelism": f"dp{world}", "steps_in_flight": nstreams,
-                "geometry_K_L_W_blocks": list(eng.geometry(n2.bit_length() if args.generic_modulus else n.bit_length())),
+                "geometry_K_L_W_blocks": list(eng.geometry(n2.bit_length()) if args.generic_modulus else eng.nsquare_geometry(n.bit_length(), batch)),
                 "algorithm": "Montgomery modulo N^2" if args.generic_modulus else "N-adic pairs, two Montgomery passes modulo N per product",
                 "verified": check_note,
             },
             "roofline": {
                 "bound": "hbm",
                 "kernel": ("mx::powmod_kernel<%d,%d,29,true>" % tuple(eng.geometry(n2.bit_length())[:2])) if args.generic_modulus
-                          else ("mx::powmod_n2_kernel<%d,9,29>" % eng.geometry(n.bit_length())[0]),
+                          else ("mx::powmod_n2_kernel<%d,%d,29>" % tuple(eng.nsquare_geometry(n.bit_length(), batch)[:2])),
                 "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": MEASURED_TRAFFIC_DEFAULT if (batch == 10000 and args.key_length == 2048 and not args.generic_modulus) else None,
+                "traffic": MEASURED_TRAFFIC_DEFAULT[eng.nsquare_geometry(n.bit_length(), batch)[1]]
+                if (batch == 10000 and args.key_length == 2048 and not args.generic_modulus) else None,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/ (not collected live)",
                 "kernel_ms": powmod_ms, "concurrent_launches": nstreams,
                 "algorithmic_bytes_per_launch": alg_bytes,
@@ -279,10 +300,10 @@ def main() -> None:
                     "achieved": agg_mac_rate / 1e12, "peak": VALU_MAC_PEAK / 1e12,
                     "unit": "T 32x32-bit MAC/s", "frac": agg_mac_rate / VALU_MAC_PEAK,
                     "algorithmic_macs_per_launch": alg_macs,
-                    "issue_utilization": (MEASURED_VALU_INSTS_DEFAULT * args.steps / elapsed / VALU_ISSUE_PEAK)
+                    "issue_utilization": (MEASURED_VALU_INSTS_DEFAULT[eng.nsquare_geometry(n.bit_length(), batch)[1]] * args.steps / elapsed / VALU_ISSUE_PEAK)
                     if (batch == 10000 and args.key_length == 2048 and not args.generic_modulus) else None,
-                    "issue_utilization_basis": "SQ_INSTS_VALU per launch (profiles/, 2.29e10) x launches / wall time, over "
-                                               "1024 SIMDs x 2.4 GHz / 4 cycles per VALU instruction",
+                    "issue_utilization_basis": "SQ_INSTS_VALU per launch (profiles/: 2.24e10 narrow, 1.84e10 wide geometry) x "
+                                               "launches / wall time, over 1024 SIMDs x 2.4 GHz / 4 cycles per VALU instruction",
                     "basis": "all launches of the timed region / wall time of the region, this GPU; the MAC count is "
                              "SURVEY.md 8(d)'s figure for schoolbook Montgomery modulo N^2 — a fraction above 1 means "
                              "the kernel needs fewer multiply-accumulates than that figure assumes (symmetric squaring, "

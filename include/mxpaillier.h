@@ -146,6 +146,17 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
 /* Engine geometry chosen for a modulus of `mod_bits` bits: lanes per element (K), limbs per lane
  * (L), limb width (W) and Montgomery blocks; returns MX_OK or MX_ERR_SIZE. */
 int mx_geometry(int mod_bits, int* lanes_per_element, int* limbs_per_lane, int* limb_bits, int* blocks);
+/* Kernel timing for benchmarks.  mx_profile(1): every following mx_powmod_shared / mx_powmod_multi /
+ * mx_powmod_nsquare call records two events on its stream around its modexp kernel (after the operand
+ * uploads).  mx_profile_collect waits for all recorded launches and returns the sum of their durations
+ * and their number, then forgets them.  mx_profile(0) stops recording.  Returns MX_OK / MX_ERR_HIP. */
+int mx_profile(int enable);
+int mx_profile_collect(double* total_ms, int* launches);
+/* Geometry mx_powmod_nsquare launches for a modulus N of `n_bits` bits and `batch` bases (it depends
+ * on the batch: the wide geometry is chosen when one launch brings enough wavefronts, see
+ * mx_set_limbs_per_lane); returns MX_OK or MX_ERR_SIZE. */
+int mx_nsquare_geometry(int n_bits, int64_t batch, int* lanes_per_element, int* limbs_per_lane, int* limb_bits,
+                        int* blocks);
 
 #ifdef __cplusplus
 }

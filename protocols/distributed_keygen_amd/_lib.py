@@ -37,6 +37,9 @@ SYMBOLS = {
     "mx_set_limbs_per_lane": (c_int, [c_int]),
     "mx_selftest_lanes": (c_int, [c_void_p]),
     "mx_geometry": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
+    "mx_profile": (c_int, [c_int]),
+    "mx_profile_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),
+    "mx_nsquare_geometry": (c_int, [c_int, c_int64, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
 }
 
 

@@ -14,6 +14,7 @@ namespace mxh {
 thread_local hipError_t g_last_hip = hipSuccess;
 int g_limbs_per_lane = 0;
 }
+MxProfile g_mx_profile;
 
 namespace {
 
@@ -52,6 +53,7 @@ template <int K, int L>
 int launch_powmod_kl(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
   using M_t = mx::Mont<K, L, LIMB_BITS, true>;
   size_t lds = (size_t)(64 / K) * M_t::LDS_WORDS * 4;
+  MxKernelTimer timer(s);
   if (a.nops > 0)
     hipLaunchKernelGGL((mx::powmod_kernel<K, L, LIMB_BITS, true>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   else
@@ -196,6 +198,34 @@ int mx_set_limbs_per_lane(int limbs_per_lane) {
   if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
   g_limbs_per_lane = limbs_per_lane;
   return MX_OK;
+}
+
+int mx_profile(int enable) {
+  std::lock_guard<std::mutex> lock(g_mx_profile.mu);
+  g_mx_profile.on = enable != 0;
+  return MX_OK;
+}
+
+int mx_profile_collect(double* total_ms, int* launches) {
+  if (!total_ms || !launches) return MX_ERR_ARG;
+  std::lock_guard<std::mutex> lock(g_mx_profile.mu);
+  double sum = 0;
+  int n = 0, rc = MX_OK;
+  for (auto& ev : g_mx_profile.events) {
+    float ms = 0;
+    if (hipEventSynchronize(ev.second) == hipSuccess && hipEventElapsedTime(&ms, ev.first, ev.second) == hipSuccess) {
+      sum += ms;
+      ++n;
+    } else {
+      rc = MX_ERR_HIP;
+    }
+    hipEventDestroy(ev.first);
+    hipEventDestroy(ev.second);
+  }
+  g_mx_profile.events.clear();
+  *total_ms = sum;
+  *launches = n;
+  return rc;
 }
 
 int mx_geometry(int mod_bits, int* k, int* l, int* w, int* blocks) {

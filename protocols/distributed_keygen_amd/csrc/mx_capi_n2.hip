@@ -31,6 +31,7 @@ bool plan_n2(int n_bits, int limbs_n, int exp_bits, int64_t batch, N2Plan& p, in
 template <int K, int L>
 int launch_n2_kl(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   size_t lds = mx::powmod_n2_lds_bytes<K, L>();
+  MxKernelTimer timer(s);
   hipLaunchKernelGGL((mx::powmod_n2_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
@@ -47,12 +48,13 @@ int launch_n2_k(const mx::PowmodN2Args& a, int64_t nblocks, int lpl, hipStream_t
 }
 
 // Geometry of the pair kernel.  Measured on MI355X (tools/ab_geometry.sh, tools/ab_streams.sh,
-// tools/sweep_keys.sh): the wide geometry issues ~23 % fewer instructions per element, but it runs 2
-// wavefronts per SIMD and puts twice the elements into a wavefront.  Saturated it is 11 % faster
-// (292 k vs 262 k modexps/s at key_length 2048); with launches that do not fill the machine on their
-// own (10 000 ciphertexts = 625 wide wavefronts for 2048 slots) its rate depends on how concurrent
-// launches happen to interleave (228 k or 263 k) while the narrow one is steady (240-256 k).  So: wide
-// only when one launch alone brings at least 1536 wavefronts.
+// tools/sweep_keys.sh, profiles/): the wide geometry issues 18 % fewer instructions per element, runs 2
+// wavefronts per SIMD and puts twice the elements into a wavefront.  At key_length 2048 it is faster
+// for a lone 10 000-element launch (164 k vs 144 k modexps/s), with four or more launches in flight
+// (262-272 k vs 241-255 k) and saturated (300 k vs 262 k); with exactly three 10 000-element launches
+// in flight (1875 wavefronts for 2048 slots) its rate depends on how they interleave (228 k or 263 k;
+// narrow 240-256 k), and for small launches the narrow geometry, which makes twice the wavefronts,
+// fills the machine better (2 000 elements: 80 k vs 55 k).  So: wide from ~480 wavefronts per launch.
 int n2_limbs_per_lane(int n_bits, int64_t batch) {
   if (g_limbs_per_lane == LIMBS_PER_LANE || g_limbs_per_lane == LIMBS_PER_LANE_WIDE) return g_limbs_per_lane;
   if (const char* e = getenv("MX_LIMBS_PER_LANE")) {
@@ -64,9 +66,17 @@ int n2_limbs_per_lane(int n_bits, int64_t batch) {
     return LIMBS_PER_LANE;
   if (narrow.K < 8 || wide.K > 16) return LIMBS_PER_LANE;
   const int64_t waves = (batch * wide.K + 63) / 64;
-  return waves >= 1536 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+  return waves >= 480 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
 }
 }  // namespace
+
+extern "C" int mx_nsquare_geometry(int n_bits, int64_t batch, int* k, int* l, int* w, int* blocks) {
+  if (!k || !l || !w || !blocks || batch <= 0) return MX_ERR_ARG;
+  Geometry g;
+  if (!choose_geometry(n_bits, g, n2_limbs_per_lane(n_bits, batch))) return MX_ERR_SIZE;
+  *k = g.K; *l = g.L; *w = g.W; *blocks = g.nblk;
+  return MX_OK;
+}
 
 extern "C" int64_t mx_powmod_nsquare_workspace_bytes(int limbs_n, int exp_limbs, int64_t batch) {
   if (limbs_n <= 0 || exp_limbs <= 0 || batch <= 0) return MX_ERR_ARG;

@@ -42,6 +42,33 @@ int upload_words(void* d_dst, const uint32_t* h_src, size_t n, hipStream_t s) {
 }  // namespace
 
 
+// ---- optional timing of the modexp kernels -------------------------------------------------------
+// mx_profile(1) makes every mx_powmod_* call bracket ITS KERNEL (not the operand uploads before it)
+// with two events on the caller's stream; mx_profile_collect waits for them and reports the sum.
+// This is what bench.py's roofline.kernel_ms is, and what rocprofv3 --kernel-trace reports per launch.
+#include <mutex>
+#include <utility>
+#include <vector>
+struct MxProfile {
+  std::mutex mu;
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> events;
+};
+extern MxProfile g_mx_profile;      // defined in mx_capi.hip
+struct MxKernelTimer {
+  hipStream_t s;
+  hipEvent_t stop = nullptr;
+  explicit MxKernelTimer(hipStream_t stream) : s(stream) {
+    std::lock_guard<std::mutex> lock(g_mx_profile.mu);
+    if (!g_mx_profile.on) return;
+    hipEvent_t start;
+    if (hipEventCreate(&start) != hipSuccess || hipEventCreate(&stop) != hipSuccess) { stop = nullptr; return; }
+    hipEventRecord(start, s);
+    g_mx_profile.events.emplace_back(start, stop);
+  }
+  ~MxKernelTimer() { if (stop) hipEventRecord(stop, s); }
+};
+
 namespace {
 // Largest modulus the engine takes: R = 2^(W*L*64) >= 16 N.
 constexpr int MAX_MOD_BITS = LIMB_BITS * LIMBS_PER_LANE * 64 - 4;

@@ -75,6 +75,26 @@ class Engine:
         _lib.check(self.lib.mx_geometry(mod_bits, k, l, w, b), "mx_geometry")
         return k.value, l.value, w.value, b.value
 
+    def profile(self, enable: bool) -> None:
+        """Start/stop recording events around every modexp kernel launch (process-wide)."""
+        _lib.check(self.lib.mx_profile(1 if enable else 0), "mx_profile")
+
+    def profile_collect(self) -> Tuple[float, int]:
+        """(sum of kernel durations in ms, launches) since the last collect; waits for the launches."""
+        import ctypes
+
+        total, n = ctypes.c_double(), ctypes.c_int()
+        _lib.check(self.lib.mx_profile_collect(total, n), "mx_profile_collect")
+        return total.value, n.value
+
+    def nsquare_geometry(self, n_bits: int, batch: int) -> Tuple[int, int, int, int]:
+        """(lanes per element, limbs per lane, limb bits, blocks) of a powmod_nsquare launch."""
+        import ctypes
+
+        k, l, w, b = (ctypes.c_int() for _ in range(4))
+        _lib.check(self.lib.mx_nsquare_geometry(n_bits, batch, k, l, w, b), "mx_nsquare_geometry")
+        return k.value, l.value, w.value, b.value
+
     # ------------------------------------------------------------------ modexp, tensor level
     def powmod_shared_t(self, bases_t, mod: int, exp: int, out_t=None):
         """out[e] = bases[e]^exp mod `mod`; bases_t: int32 [batch, limbs] on this device."""

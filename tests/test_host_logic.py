@@ -45,6 +45,19 @@ def test_geometry_query():
         assert (k.value, l.value, w.value) == (want_k, 9, 29)
         assert w.value * l.value * b.value >= bits + 4 and b.value <= k.value
     assert lib.mx_geometry(16701, k, l, w, b) == -2
+    # the pair kernel picks its geometry per launch: narrow for small launches, wide (half the lanes,
+    # twice the limbs per lane) from ~480 wavefronts, and only when the narrow one needs >= 8 lanes
+    for bits, batch, want in ((2051, 100, (8, 9)), (2051, 10000, (4, 18)), (2051, 7000, (8, 9)), (1028, 100000, (4, 9)),
+                              (4100, 4000, (8, 18)), (4100, 1000, (16, 9))):
+        assert lib.mx_nsquare_geometry(bits, batch, k, l, w, b) == 0
+        assert (k.value, l.value) == want, (bits, batch)
+        assert w.value * l.value * b.value >= bits + 4
+    assert lib.mx_nsquare_geometry(2051, 0, k, l, w, b) == -1
+    # kernel timing hooks: nothing launched, nothing recorded
+    total, launches = ctypes.c_double(-1.0), ctypes.c_int(-1)
+    assert lib.mx_profile(1) == 0 and lib.mx_profile_collect(total, launches) == 0 and lib.mx_profile(0) == 0
+    assert (total.value, launches.value) == (0.0, 0)
+    assert lib.mx_profile_collect(None, None) == -1
     assert lib.mx_powmod_workspace_bytes(129, 132, 10000, 1) > 0
     assert lib.mx_powmod_workspace_bytes(0, 1, 1, 1) == -1
 

@@ -22,6 +22,19 @@ def main() -> None:
         for r in csv.DictReader(open(f)):
             lines.append(f"{short(r['Name']):92s} {r['Calls']:>6s} {float(r['AverageNs'])/1e6:12.4f} "
                          f"{float(r['MinNs'])/1e6:12.4f} {float(r['MaxNs'])/1e6:12.4f} {float(r['Percentage']):7.3f}")
+    for f in glob.glob(stats_dir + "/**/*_kernel_trace.csv", recursive=True):
+        per = collections.defaultdict(list)
+        for r in csv.DictReader(open(f)):
+            if "mx::powmod" in r["Kernel_Name"]:
+                per[r["Kernel_Name"]].append((int(r["Start_Timestamp"]), (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6))
+        for k, v in per.items():
+            v.sort()
+            d = [x[1] for x in v]
+            lines.append("")
+            lines.append(f"## launches of {short(k)} in start order (ms): " + " ".join(f"{x:.1f}" for x in d))
+            for tail in (12, 9, 6):
+                if len(d) > tail:
+                    lines.append(f"   mean of the last {tail} (bench.py's timed steps when --steps {tail}): {sum(d[-tail:]) / tail:.3f} ms")
     for d in pmc_dirs:
         for f in glob.glob(d + "/**/*_counter_collection.csv", recursive=True):
             agg = collections.defaultdict(lambda: collections.defaultdict(list))

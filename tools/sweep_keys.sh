@@ -1,6 +1,7 @@
-# usage: bash tools/sweep_keys.sh — pair kernel, narrow vs wide geometry over key sizes
-for cfg in "1024 9 20000" "1024 18 20000" "3072 9 4000" "3072 18 4000" "4096 9 4000" "4096 18 4000" "4096 9 16000" "4096 18 16000" "2048 9 2000" "2048 18 2000"; do
+# usage: bash tools/sweep_keys.sh — headline kernel over key sizes and batch sizes, default bench settings
+for cfg in "1024 20000" "3072 4000" "4096 1000" "4096 4000" "4096 16000" "2048 2000" "2048 40000"; do
   set -- $cfg
-  echo "key=$1 L=$2 batch=$3"
-  python bench.py --no-cpu-baseline --key-length $1 --limbs-per-lane $2 --streams 3 --batch $3 --steps 6 --warmup 3 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(d['value'], d['ms_per_step'])"
+  printf "key=%s batch=%s " $1 $2
+  python bench.py --no-cpu-baseline --key-length $1 --batch $2 --steps 8 --warmup 4 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print(round(d['value']), round(d['ms_per_step'],2), d['roofline']['kernel'], d['config']['steps_in_flight'])"
 done
+python bench.py --no-cpu-baseline --generic-modulus 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('generic', round(d['value']), round(d['ms_per_step'],2), d['roofline']['kernel'], d['config']['steps_in_flight'])"
