@@ -173,3 +173,35 @@ def test_powmod_nsquare_golden_partial_decryptions(eng, golden_decrypt_synth, go
                 exp = oracle.partial_decrypt_exponent(int(i), grp["degree"], unhex(grp["n_fac"]), unhex(share))
                 bases = cs if exp >= 0 else [oracle.mod_inv(c, n2) for c in cs]
                 assert eng.powmod_nsquare_batch(bases, abs(exp), n) == [unhex(c["partials"][i]) for c in grp["cases"]], (name, i)
+
+
+def test_kernel_timing_hooks_and_concurrent_streams(eng):
+    """mx_profile brackets each modexp kernel with events on the caller's stream; launches issued on
+    several streams without any host synchronisation in between (the C ABI never synchronises) all
+    complete and are all recorded — what bench.py relies on."""
+    import torch
+
+    from protocols.distributed_keygen_amd import Engine, limbs as L
+
+    rng = random.Random(4242)
+    n = rng.getrandbits(1027) | (1 << 1026) | 1
+    n2 = n * n
+    e = rng.getrandbits(300) | 1
+    bases = [rng.randrange(n2) for _ in range(64)]
+    want = [oracle.pow_mod(b, e, n2) for b in bases]
+    rows = eng.to_device(L.pack(bases, L.limbs_for(n2)))
+    engines = [eng, Engine(), Engine()]
+    streams = [torch.cuda.Stream() for _ in engines]
+    torch.cuda.synchronize()
+    eng.profile(True)
+    outs = []
+    for k in range(6):
+        with torch.cuda.stream(streams[k % 3]):
+            outs.append(engines[k % 3].powmod_nsquare_t(rows, n, e) if k % 2 == 0 else engines[k % 3].powmod_shared_t(rows, n2, e))
+    eng.profile(False)
+    total_ms, launches = eng.profile_collect()
+    torch.cuda.synchronize()
+    assert launches == 6 and total_ms > 0
+    for out in outs:
+        assert L.unpack(eng.to_host(out)) == want
+    assert eng.profile_collect() == (0.0, 0)

@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""One-off soak test of mx_powmod_nsquare against CPython pow on all host cores (GPU box)."""
+"""Soak test of mx_powmod_nsquare against CPython pow on all host cores (GPU box).
+
+usage: soak_nsquare.py [seed] [trials] [limbs_per_lane 0|9|18]"""
 import multiprocessing as mp, random, sys, time
 from pathlib import Path
 sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
@@ -8,6 +10,7 @@ sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
 def main():
     from protocols.distributed_keygen_amd import Engine
     eng = Engine()
+    eng.set_limbs_per_lane(int(sys.argv[3]) if len(sys.argv) > 3 else 0)
     rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
     t0 = time.time(); checked = 0
     with mp.Pool() as pool:
