@@ -32,7 +32,7 @@ def main() -> None:
             d = [x[1] for x in v]
             lines.append("")
             lines.append(f"## launches of {short(k)} in start order (ms): " + " ".join(f"{x:.1f}" for x in d))
-            for tail in (12, 9, 6):
+            for tail in (48, 12, 9, 6):
                 if len(d) > tail:
                     lines.append(f"   mean of the last {tail} (bench.py's timed steps when --steps {tail}): {sum(d[-tail:]) / tail:.3f} ms")
     for d in pmc_dirs:
