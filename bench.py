@@ -64,8 +64,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--check", type=int, default=6, help="elements verified against CPython pow after timing")
     ap.add_argument("--streams", type=int, default=0,
                     help="independent steps (10k-ciphertext batches) kept in flight, one HIP stream each; "
-                         "1 = strictly one batch at a time; 0 = automatic: 4, or the count in 5..8 (or 3) that "
-                         "divides --steps so that every stream runs the same number of steps")
+                         "1 = strictly one batch at a time; 0 = automatic: the first of 4, 5, 6, 7, 8, 3 that "
+                         "divides --steps (every stream then runs the same number of steps), else 4")
     ap.add_argument("--limbs-per-lane", type=int, default=-1,
                     help="lane geometry 9|18, 0 = library heuristic; default: 18 (wide) when at least 4 steps "
                          "are in flight and the modulus has >= 2048 bits")
@@ -115,6 +115,13 @@ def cpu_baseline(key, exp: int, ciphertexts, seconds: float) -> dict:
 
 def main() -> None:
     args = parse()
+    # stdout carries exactly ONE line, the JSON result.  Libraries write banners to the C-level stdout
+    # (RCCL prints its version block when the first communicator is created, and stdio would flush it
+    # after Python's own output), so file descriptor 1 is pointed at stderr for the whole run and the
+    # result goes to the saved descriptor at the end.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     import numpy as np
     import torch
 
@@ -130,11 +137,24 @@ def main() -> None:
     local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    # MX_BENCH_FORCE_DIST=1 runs the process-group code path (RCCL init, all-gather, barrier) with a
+    # single rank: the only way to exercise it on a one-GPU box
+    force_dist = world == 1 and os.environ.get("MX_BENCH_FORCE_DIST") == "1"
+    if force_dist:
+        for k, v in (("MASTER_ADDR", "127.0.0.1"), ("MASTER_PORT", "29533"), ("RANK", "0"), ("WORLD_SIZE", "1")):
+            os.environ.setdefault(k, v)
+    if world > 1 or force_dist:
         import torch.distributed as dist  # type: ignore
 
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            # the all-gather kernels must find wavefront slots on a GPU that the modexp launches keep
+            # full: give RCCL's stream the high-priority queue (falls back if the option is unavailable)
+            try:
+                opts = dist.ProcessGroupNCCL.Options()
+                opts.is_high_priority_stream = True
+                dist.init_process_group("nccl", pg_options=opts, device_id=torch.device("cuda", local_rank))
+            except (AttributeError, TypeError):
+                dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
 
@@ -190,7 +210,7 @@ def main() -> None:
             "partials": partials_t if k == 0 else partials_t.clone(),
             "msg": torch.empty((batch, L.limbs_for(n)), dtype=torch.int32, device=eng.device),
             "status": torch.empty(batch, dtype=torch.uint8, device=eng.device),
-            "gathered": torch.empty((world, batch, limbs2), dtype=torch.int32, device=eng.device) if world > 1 else None,
+            "gathered": torch.empty((world, batch, limbs2), dtype=torch.int32, device=eng.device) if dist is not None else None,
         })
     torch.cuda.synchronize()
     msg_t, status_t, gathered = lanes[0]["msg"], lanes[0]["status"], lanes[0]["gathered"]
@@ -202,12 +222,12 @@ def main() -> None:
                 ln["eng"].powmod_shared_t(own_in_t, n2, own_exp, out_t=ln["partials"][own_slot])
             else:
                 ln["eng"].powmod_nsquare_t(own_in_t, n, own_exp, out_t=ln["partials"][own_slot])
-            if world > 1:
+            if dist is not None:
                 dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][own_slot].reshape(-1))
             ln["eng"].combine_t(ln["partials"], n, theta_inv, out_t=ln["msg"], status_t=ln["status"])
 
     def barrier() -> None:
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -231,7 +251,7 @@ def main() -> None:
     eng.profile(False)
     kernel_total_ms, kernel_launches = eng.profile_collect()
     assert kernel_launches == args.steps, (kernel_launches, args.steps)
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -240,7 +260,7 @@ def main() -> None:
     # ---- verification (outside the timed region)
     for ln in lanes:
         assert int(ln["status"].sum().item()) == 0, "share recombination flagged ciphertexts as inconsistent"
-    if world > 1:
+    if dist is not None:
         assert torch.equal(gathered[rank], partials_t[own_slot]), "all-gather shard mismatch"
     check_note = "skipped"
     if rank == 0 and args.check > 0:
@@ -323,8 +343,8 @@ def main() -> None:
             out["cpu_baseline"] = cpu_baseline(key, own_exp, [c if exps[own] >= 0 else pow(c, -1, n2) for c in cts[:64]], args.cpu_seconds)
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
-    if world > 1:
+        os.write(result_fd, (json.dumps(out) + "\n").encode())
+    if dist is not None:
         dist.destroy_process_group()
 
 
