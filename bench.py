@@ -43,7 +43,7 @@ VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
 # (FETCH_SIZE counts half of wide coalesced reads on gfx950, MI355X guide).  It is the table of odd
 # powers (64 pairs per ciphertext, 72 slots in all): ~0.4-0.5 GB written and ~2.7 GB of coalesced
 # look-ups per 10 000 modexps.  Keyed by limbs per lane (narrow, wide geometry).
-MEASURED_TRAFFIC_DEFAULT = {9: (2 * 1320544 + 410039) * 1024, 18: (2 * 1414452 + 501894) * 1024}
+MEASURED_TRAFFIC_DEFAULT = {9: (2 * 1320544 + 410039) * 1024, 18: (2 * 1414320 + 501583) * 1024}
 # VALU wave-instructions one powmod_n2_kernel launch of the default workload issues (SQ_INSTS_VALU of
 # the same profile), and the issue peak: 1024 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz.
 MEASURED_VALU_INSTS_DEFAULT = {9: 2.2432e10, 18: 1.8393e10}     # by limbs per lane (narrow, wide geometry)
