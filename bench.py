@@ -158,6 +158,13 @@ def main() -> None:
         else:
             dist.init_process_group(backend)
 
+    from protocols.distributed_keygen_amd import build as _build
+
+    if not _build.LIB.exists():      # a checkout without the built library: compile it (rank 0), never a CPU path
+        if local_rank == 0:
+            _build.build(force=True)
+        if dist is not None:
+            dist.barrier()
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
     eng = Engine(local_rank)
