@@ -272,3 +272,15 @@ def test_c_abi_status_codes_without_gpu():
     assert lib.mx_sieve_workspace_bytes(65, 302) > 0 and lib.mx_combine_workspace_bytes(65, 129, 3, 10) > 0
     assert lib.mx_verdict_workspace_bytes(65, 3, 10, 40) > 0 and lib.mx_jacobi_workspace_bytes(65, 10) > 0
     assert lib.mx_mulmod_workspace_bytes(129) > 0
+
+
+def test_public_header_is_plain_c():
+    """include/mxpaillier.h is the drop-in boundary: it must compile as C99 (and as C++) on its own."""
+    import shutil
+    import subprocess
+
+    header = str(ROOT / "include" / "mxpaillier.h")
+    for compiler, lang in (("gcc", ["-x", "c", "-std=c99"]), ("g++", ["-x", "c++"])):
+        if shutil.which(compiler) is None:
+            pytest.skip(f"{compiler} not installed")
+        subprocess.run([compiler, "-fsyntax-only", "-Wall", "-Werror", *lang, header], check=True)
