@@ -242,3 +242,24 @@ def test_jacobi_lanes_finishing_at_very_different_times(eng):
     rows = [vals[:64], vals[64:128], vals[128:]]
     got = eng.jacobi_batch(rows, mods)
     assert got == [[oracle.jacobi_symbol(v, m) for v in r] for r, m in zip(rows, mods)]
+
+
+def test_c_abi_from_plain_cpp(tmp_path):
+    """examples/capi_partial_decrypt.cpp: the library used from C++/HIP without Python or PyTorch —
+    mx_powmod_nsquare and mx_powmod_shared (two independent kernels) agree on 2048 partial decryptions
+    at key_length 2048, and c^1 == c."""
+    import shutil
+    import subprocess
+    from pathlib import Path
+
+    root = Path(__file__).resolve().parent.parent
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    if not Path(hipcc).exists():
+        pytest.skip("hipcc not installed")
+    pkg = root / "protocols" / "distributed_keygen_amd"
+    exe = tmp_path / "capi_partial_decrypt"
+    subprocess.run([hipcc, "-O2", "--offload-arch=gfx950", f"-I{root / 'include'}", str(root / "examples" / "capi_partial_decrypt.cpp"),
+                    f"-L{pkg}", "-lmxpaillier", f"-Wl,-rpath,{pkg}", "-o", str(exe)], check=True, capture_output=True)
+    run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
+    assert run.returncode == 0, run.stdout + run.stderr
+    assert "identical through both kernels" in run.stdout
