@@ -29,11 +29,22 @@ struct PowmodPlan {
 
 bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p,
                  int limbs_per_lane = 0) {
-  // the wide geometry pays in the shared-exponent (sliding-window) kernel; with per-group exponents
-  // the narrow one measured faster at every size (profiles/r01_biprime_*.json), unless forced
-  if (limbs_per_lane == 0)
-    limbs_per_lane = (groups > 1 && g_limbs_per_lane == 0 && !getenv("MX_LIMBS_PER_LANE"))
-                         ? LIMBS_PER_LANE : pick_limbs_per_lane(mod_bits, batch);
+  // Per-group exponents (biprimality test, fixed-window kernel): the wide geometry issues 30 % fewer
+  // instructions but runs 2 wavefronts per SIMD (216 VGPRs) with twice the elements each, so it
+  // only wins when the launch spans several rounds of the 2048 wavefront slots (tools/ab_biprime.sh:
+  // key_length 2048, 4096 candidates x 40: 1.31 M vs 1.13 M modexps/s; 1024 candidates: 1.02 M vs
+  // 1.08 M) and the narrow geometry needs at least 8 lanes per element.
+  if (limbs_per_lane == 0) {
+    if (groups > 1 && g_limbs_per_lane == 0 && !getenv("MX_LIMBS_PER_LANE")) {
+      Geometry narrow, wide;
+      limbs_per_lane = LIMBS_PER_LANE;
+      if (choose_geometry(mod_bits, narrow, LIMBS_PER_LANE) && choose_geometry(mod_bits, wide, LIMBS_PER_LANE_WIDE) &&
+          narrow.K >= 8 && (batch * wide.K + 63) / 64 >= 4 * 2048)
+        limbs_per_lane = LIMBS_PER_LANE_WIDE;
+    } else {
+      limbs_per_lane = pick_limbs_per_lane(mod_bits, batch);
+    }
+  }
   if (!choose_geometry(mod_bits, p.geo, limbs_per_lane)) return false;
   p.win = fixed_window(32 * exp_limbs);
   int gpw = 64 / p.geo.K;

@@ -38,7 +38,7 @@ struct PowmodArgs {
 // SLIDING = the shared-exponent schedule (A.ops), otherwise the fixed window with per-group digits;
 // two kernels rather than one branch so that neither carries the other's register pressure.
 template <int K, int L, int W, bool SLIDING>
-__global__ void __launch_bounds__(64, (L > 9 ? 3 : 1)) powmod_kernel(PowmodArgs A) {
+__global__ void __launch_bounds__(64, (L > 9 ? 2 : 1)) powmod_kernel(PowmodArgs A) {
   using M_t = Mont<K, L, W, true>;
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;
