@@ -160,9 +160,9 @@ def main() -> None:
 
     from protocols.distributed_keygen_amd import build as _build
 
-    if not _build.LIB.exists():      # a checkout without the built library: compile it (rank 0), never a CPU path
+    if _build.needs_build():         # missing or stale library: compile it (local rank 0), never a CPU path
         if local_rank == 0:
-            _build.build(force=True)
+            _build.build(force=False)
         if dist is not None:
             dist.barrier()
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
@@ -212,7 +212,7 @@ def main() -> None:
     lanes = []
     for k in range(nstreams):
         lanes.append({
-            "eng": eng if k == 0 else Engine(local_rank),
+            "eng": eng,          # one engine: its workspace is per stream, the per-key plans are shared
             "stream": torch.cuda.current_stream() if nstreams == 1 else torch.cuda.Stream(),
             "partials": partials_t if k == 0 else partials_t.clone(),
             "msg": torch.empty((batch, L.limbs_for(n)), dtype=torch.int32, device=eng.device),

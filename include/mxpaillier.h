@@ -15,7 +15,9 @@
  *   - d_* pointers are DEVICE pointers (e.g. torch.Tensor.data_ptr()), h_* are HOST pointers.
  *   - The caller owns every buffer, including the workspace; the library allocates nothing that
  *     outlives a call.  All work is enqueued on `stream` (a hipStream_t, NULL = default stream);
- *     calls return after enqueueing.  Host arrays (h_*) may be freed/reused on return.
+ *     calls return after enqueueing and NEVER synchronise the stream or the device.  Host arrays
+ *     (h_*) travel by value in kernel-argument blocks and may be freed/reused on return; operand
+ *     sets of thousands of moduli should use the *_dev entry points (device-resident operands).
  *   - Return value: MX_OK (0) or a negative MX_ERR_* code; nothing throws across the ABI.
  *   - Moduli must be odd and >= 3.  Supported modulus size: up to 16 700 bits.
  *   - Bases / partials must be < their modulus (the reference guarantees this: UT:361, PSK:92);
@@ -65,6 +67,23 @@ int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_
                     const uint32_t* h_exps, int limbs, int exp_limbs, int64_t groups,
                     int64_t group_size, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* mx_powmod_shared with the lane geometry as an argument: limbs_per_lane 9 (narrow: more lanes per
+ * element), 18 (wide: fewer, busier lanes) or 0 (automatic from the batch size). */
+int mx_powmod_shared_lpl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
+                         int limbs, int exp_limbs, int64_t batch, int limbs_per_lane, void* d_workspace,
+                         int64_t workspace_bytes, void* stream);
+
+/* mx_powmod_multi with DEVICE-resident moduli and exponents (d_mods [groups][limbs], d_exps
+ * [groups][exp_limbs]): the form for thousands of candidate moduli per keygen round (DK:1313-1329
+ * with batch_size in the thousands) — nothing but launches is enqueued, and the moduli may be the
+ * output of the device-side reconstruction of DK:1284.  mod_bits / exp_bits: upper bounds on the bit
+ * lengths (they select the lane geometry and the number of exponent digits).  The moduli must be
+ * odd and >= 3; this cannot be checked for device operands — an even modulus yields an unspecified
+ * residue for its group, never a hang.  Workspace: mx_powmod_workspace_bytes. */
+int mx_powmod_multi_dev(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* d_mods, const uint32_t* d_exps,
+                        int limbs, int exp_limbs, int mod_bits, int exp_bits, int64_t groups, int64_t group_size,
+                        int limbs_per_lane, void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* d_out[e] = d_bases[e] ^ exp mod N^2 with the modulus given by its ROOT h_n — the partial decryption
  * `pow_mod(ciphertext_value, exp, self.n_square)` of PSK:92 (n_square = n*n, PSK:46).  Same result
  * as mx_powmod_shared with the modulus N^2, computed with operations of the size of N only
@@ -76,6 +95,37 @@ int64_t mx_powmod_nsquare_workspace_bytes(int limbs_n, int exp_limbs, int64_t ba
 int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_n, const uint32_t* h_exp,
                       int limbs_n, int limbs2, int exp_limbs, int64_t batch, void* d_workspace,
                       int64_t workspace_bytes, void* stream);
+
+/* ---- per-key plans ------------------------------------------------------------------------
+ * Everything mx_powmod_nsquare derives from (N, exp) — the N-adic constant pairs, C', and the tape
+ * (conversion, table of odd powers, sliding-window schedule) — depends on the KEY only: N is the
+ * public modulus (PSK:46) and exp the party's Lagrange-folded share (PSK:79-85), both fixed for the
+ * life of a PaillierSharedKey.  prepare derives them once (about 1 ms of host work) and writes them
+ * into a caller-owned device block; run launches the modexp kernel and nothing else: no host
+ * arithmetic, no operand upload.  The plan descriptor is a plain struct the caller keeps on the
+ * host; the device block must stay valid, and the stream passed to prepare must be complete or
+ * ordered before the streams passed to run (prepare's uploads are enqueued on it).
+ * limbs_per_lane of run: 9 (narrow geometry), 18 (wide) or 0 = automatic from the batch size. */
+typedef struct mx_nsquare_plan {
+  const void* d_plan;     /* device block written by prepare */
+  int64_t plan_bytes;
+  int32_t limbs_n;        /* words of N */
+  int32_t n_bits;
+  int32_t exp_bits;
+  int32_t window;         /* sliding-window width of the tape (table of 2^(window-1) odd powers) */
+  int32_t ntape;          /* tape words */
+  int32_t n_sqr;          /* pair squarings one exponentiation executes */
+  int32_t n_mul;          /* pair multiplications one exponentiation executes */
+  int32_t reserved;
+} mx_nsquare_plan;
+int64_t mx_nsquare_plan_bytes(int limbs_n, int exp_limbs);
+int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp, int limbs_n,
+                              int exp_limbs, void* d_plan, int64_t plan_bytes, void* stream);
+/* workspace of one run (the table of odd powers of every base; one per launch in flight) */
+int64_t mx_powmod_nsquare_run_workspace_bytes(const mx_nsquare_plan* plan, int64_t batch);
+int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t* d_bases, uint32_t* d_out, int limbs2,
+                          int64_t batch, int limbs_per_lane, void* d_workspace, int64_t workspace_bytes,
+                          void* stream);
 
 /* ---- small-prime sieve -----------------------------------------------------------------
  * d_out[e] = 1 if some h_primes[k] divides candidate e else 0.  Replaces
@@ -98,6 +148,22 @@ int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* d_status, c
                const uint32_t* h_theta_inv, int limbs, int limbs2, int n_partials, int64_t batch,
                void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* Per-key plan of the recombination (N, N^2, the Montgomery constants and theta_inv depend on the
+ * key only, PSK:46-50): prepare once, then run enqueues the kernel and nothing else.  Rows of d_out
+ * are out_stride >= limbs words wide; if out_stride > limbs, word [limbs] of every row receives the
+ * status (0 / 1) and the remaining words are zero, so that plaintext and status travel as ONE row
+ * (one all-gather when ciphertexts are sharded over GPUs); d_status may then be NULL. */
+typedef struct mx_combine_plan {
+  const void* d_plan;
+  int64_t plan_bytes;
+  int32_t limbs, limbs2, n_bits, n2_bits;
+} mx_combine_plan;
+int64_t mx_combine_plan_bytes(int limbs, int limbs2);
+int mx_combine_prepare(mx_combine_plan* plan, const uint32_t* h_n, const uint32_t* h_theta_inv, int limbs,
+                       int limbs2, void* d_plan, int64_t plan_bytes, void* stream);
+int mx_combine_run(const mx_combine_plan* plan, const uint32_t* d_partials, uint32_t* d_out, int out_stride,
+                   uint8_t* d_status, int n_partials, int64_t batch, void* stream);
+
 /* ---- biprimality verdict ---------------------------------------------------------------
  * d_pass[g*n_slots + k] = 1 iff  v_1 == +-prod_{i>=2} v_i (mod N_g) for test slot k, where
  * d_v is [n_parties][groups][n_slots][limbs] (party index 1 first).  Replaces the per-slot test
@@ -106,6 +172,12 @@ int64_t mx_verdict_workspace_bytes(int limbs, int n_parties, int64_t groups, int
 int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* h_mods, int limbs,
                        int n_parties, int64_t groups, int64_t n_slots, void* d_workspace,
                        int64_t workspace_bytes, void* stream);
+
+/* The same with device-resident moduli (d_mods [groups][limbs], all odd and >= 3, at most mod_bits
+ * bits); workspace: mx_verdict_workspace_bytes. */
+int mx_biprime_verdict_dev(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* d_mods, int limbs, int mod_bits,
+                           int n_parties, int64_t groups, int64_t n_slots, void* d_workspace,
+                           int64_t workspace_bytes, void* stream);
 
 /* ---- modular multiplication ------------------------------------------------------------
  * d_out[e] = d_a[e] * d_b[e] mod h_mod.  The glue around the modexps: (1 + mN) * r^N of Paillier
@@ -125,6 +197,10 @@ int mx_mulmod_shared(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, 
 int64_t mx_jacobi_workspace_bytes(int limbs, int64_t groups);
 int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
               int64_t group_size, void* d_workspace, int64_t workspace_bytes, void* stream);
+
+/* The same with device-resident moduli (no workspace). */
+int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs, int64_t groups,
+                  int64_t group_size, void* stream);
 
 /* ---- selection of the generators -------------------------------------------------------
  * For every group, copies the first `keep` rows whose flag is 1 (in order) to d_out[g][0..keep) and
@@ -148,7 +224,7 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
 int mx_geometry(int mod_bits, int* lanes_per_element, int* limbs_per_lane, int* limb_bits, int* blocks);
 /* Kernel timing for benchmarks.  mx_profile(1): every following mx_powmod_shared / mx_powmod_multi /
  * mx_powmod_nsquare call records two events on its stream around its modexp kernel (after the operand
- * uploads).  mx_profile_collect waits for all recorded launches and returns the sum of their durations
+ * uploads; mx_powmod_nsquare_run and mx_powmod_multi_dev are timed too).  mx_profile_collect waits for all recorded launches and returns the sum of their durations
  * and their number, then forgets them.  mx_profile(0) stops recording.  Returns MX_OK / MX_ERR_HIP. */
 int mx_profile(int enable);
 int mx_profile_collect(double* total_ms, int* launches);
@@ -157,6 +233,14 @@ int mx_profile_collect(double* total_ms, int* launches);
  * mx_set_limbs_per_lane); returns MX_OK or MX_ERR_SIZE. */
 int mx_nsquare_geometry(int n_bits, int64_t batch, int* lanes_per_element, int* limbs_per_lane, int* limb_bits,
                         int* blocks);
+
+/* Geometry for an explicit limbs_per_lane (9 | 18 | 0 = the library's automatic choice for this
+ * batch), independent of the process-wide override: of a mx_powmod_nsquare_run launch, and of a
+ * mx_powmod_shared_lpl (groups = 1) / mx_powmod_multi_dev (groups > 1) launch. */
+int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_lane, int* lanes_per_element,
+                            int* limbs_per_lane_out, int* limb_bits, int* blocks);
+int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* lanes_per_element,
+                           int* limbs_per_lane_out, int* limb_bits, int* blocks);
 
 #ifdef __cplusplus
 }

@@ -13,6 +13,27 @@ LIB_PATH = Path(__file__).resolve().parent / "libmxpaillier.so"
 MX_OK = 0
 ERRORS = {-1: "MX_ERR_ARG", -2: "MX_ERR_SIZE", -3: "MX_ERR_MODULUS", -4: "MX_ERR_WORKSPACE", -5: "MX_ERR_HIP"}
 
+class NsquarePlan(ctypes.Structure):
+    """mx_nsquare_plan (include/mxpaillier.h)."""
+
+    _fields_ = [
+        ("d_plan", c_void_p), ("plan_bytes", c_int64), ("limbs_n", ctypes.c_int32), ("n_bits", ctypes.c_int32),
+        ("exp_bits", ctypes.c_int32), ("window", ctypes.c_int32), ("ntape", ctypes.c_int32),
+        ("n_sqr", ctypes.c_int32), ("n_mul", ctypes.c_int32), ("reserved", ctypes.c_int32),
+    ]
+
+
+class CombinePlan(ctypes.Structure):
+    """mx_combine_plan (include/mxpaillier.h)."""
+
+    _fields_ = [
+        ("d_plan", c_void_p), ("plan_bytes", c_int64), ("limbs", ctypes.c_int32), ("limbs2", ctypes.c_int32),
+        ("n_bits", ctypes.c_int32), ("n2_bits", ctypes.c_int32),
+    ]
+
+
+_P4 = [POINTER(c_int)] * 4
+
 # name -> (restype, argtypes); every symbol include/mxpaillier.h declares
 SYMBOLS = {
     "mx_version": (c_int, []),
@@ -23,6 +44,19 @@ SYMBOLS = {
     "mx_powmod_multi": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_powmod_nsquare_workspace_bytes": (c_int64, [c_int, c_int, c_int64]),
     "mx_powmod_nsquare": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_shared_lpl": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_multi_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_nsquare_plan_bytes": (c_int64, [c_int, c_int]),
+    "mx_powmod_nsquare_prepare": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_nsquare_run_workspace_bytes": (c_int64, [POINTER(NsquarePlan), c_int64]),
+    "mx_powmod_nsquare_run": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_combine_plan_bytes": (c_int64, [c_int, c_int]),
+    "mx_combine_prepare": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_combine_run": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
+    "mx_biprime_verdict_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
+    "mx_jacobi_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "mx_nsquare_geometry_for": (c_int, [c_int, c_int64, c_int, *_P4]),
+    "mx_powmod_geometry_for": (c_int, [c_int, c_int64, c_int64, c_int, *_P4]),
     "mx_sieve_workspace_bytes": (c_int64, [c_int, c_int]),
     "mx_sieve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_combine_workspace_bytes": (c_int64, [c_int, c_int, c_int, c_int64]),

@@ -7,6 +7,7 @@
 #include "mx_jacobi.hpp"
 #include "mx_mulmod.hpp"
 #include "mx_select.hpp"
+#include "mx_setup.hpp"
 #include <cstring>
 #include <algorithm>
 
@@ -27,24 +28,24 @@ struct PowmodPlan {
   int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_ops = 0, off_table = 0, total = 0;
 };
 
+// Geometry when the caller leaves the choice to the library.  Per-group exponents (biprimality test,
+// fixed-window kernel): the wide geometry issues 30 % fewer instructions but runs 2 wavefronts per
+// SIMD (216 VGPRs) with twice the elements each, so it only wins when the launch spans several
+// rounds of the 2048 wavefront slots (tools/ab_biprime.sh: key_length 2048, 4096 candidates x 40:
+// 1.31 M vs 1.13 M modexps/s; 1024 candidates: 1.02 M vs 1.08 M) and the narrow geometry needs at
+// least 8 lanes per element.  One shared exponent: wide once every SIMD gets two wavefronts.
+int auto_limbs_per_lane(int mod_bits, int64_t batch, int64_t groups) {
+  Geometry narrow, wide;
+  if (!choose_geometry(mod_bits, narrow, LIMBS_PER_LANE) || !choose_geometry(mod_bits, wide, LIMBS_PER_LANE_WIDE))
+    return LIMBS_PER_LANE;
+  const int64_t waves = (batch * wide.K + 63) / 64;
+  if (groups > 1) return (narrow.K >= 8 && waves >= 4 * 2048) ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+  return waves >= 2 * 1024 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+}
+
 bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p,
-                 int limbs_per_lane = 0) {
-  // Per-group exponents (biprimality test, fixed-window kernel): the wide geometry issues 30 % fewer
-  // instructions but runs 2 wavefronts per SIMD (216 VGPRs) with twice the elements each, so it
-  // only wins when the launch spans several rounds of the 2048 wavefront slots (tools/ab_biprime.sh:
-  // key_length 2048, 4096 candidates x 40: 1.31 M vs 1.13 M modexps/s; 1024 candidates: 1.02 M vs
-  // 1.08 M) and the narrow geometry needs at least 8 lanes per element.
-  if (limbs_per_lane == 0) {
-    if (groups > 1 && g_limbs_per_lane == 0 && !getenv("MX_LIMBS_PER_LANE")) {
-      Geometry narrow, wide;
-      limbs_per_lane = LIMBS_PER_LANE;
-      if (choose_geometry(mod_bits, narrow, LIMBS_PER_LANE) && choose_geometry(mod_bits, wide, LIMBS_PER_LANE_WIDE) &&
-          narrow.K >= 8 && (batch * wide.K + 63) / 64 >= 4 * 2048)
-        limbs_per_lane = LIMBS_PER_LANE_WIDE;
-    } else {
-      limbs_per_lane = pick_limbs_per_lane(mod_bits, batch);
-    }
-  }
+                 int limbs_per_lane) {
+  if (limbs_per_lane == 0) limbs_per_lane = auto_limbs_per_lane(mod_bits, batch, groups);
   if (!choose_geometry(mod_bits, p.geo, limbs_per_lane)) return false;
   p.win = fixed_window(32 * exp_limbs);
   int gpw = 64 / p.geo.K;
@@ -53,7 +54,7 @@ bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t 
   int64_t o = 0;
   p.off_mods = o;  o += align256((int64_t)groups * limbs * 4);
   p.off_rmodn = o; o += align256((int64_t)groups * limbs * 4);
-  p.off_exps = o;  o += align256((int64_t)groups * (exp_limbs + 1) * 4);
+  p.off_exps = o;  o += align256((int64_t)groups * exp_limbs * 4);
   p.off_ops = o;   o += align256((int64_t)MAX_SLIDING_OPS * 4);
   p.off_table = o; o += align256(((int64_t)1 << p.win) * p.geo.L * p.nlanes * 4);
   p.total = o;
@@ -75,64 +76,63 @@ int launch_powmod_kl(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
 
 template <int K>
 int launch_powmod_k(const mx::PowmodArgs& a, int64_t nblocks, int limbs_per_lane, hipStream_t s) {
-  if (limbs_per_lane == LIMBS_PER_LANE_WIDE) return launch_powmod_kl<K, LIMBS_PER_LANE_WIDE>(a, nblocks, s);
+  if (limbs_per_lane == LIMBS_PER_LANE_WIDE) {
+    // the largest supported modulus (MAX_MOD_BITS) needs 32 wide lanes: no <64, 18> instance
+    if constexpr (K <= 32) return launch_powmod_kl<K, LIMBS_PER_LANE_WIDE>(a, nblocks, s);
+    return MX_ERR_SIZE;
+  }
   return launch_powmod_kl<K, LIMBS_PER_LANE>(a, nblocks, s);
 }
 
-int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods, const uint32_t* h_exps,
-                int limbs, int exp_limbs, int64_t groups, int64_t group_size, void* d_ws, int64_t ws_bytes,
-                void* stream) {
-  if (!d_bases || !d_out || !h_mods || !h_exps || !d_ws) return MX_ERR_ARG;
-  if (limbs <= 0 || exp_limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
-  hipStream_t s = (hipStream_t)stream;
-  int64_t batch = groups * group_size;
-  int max_bits = 0;
-  for (int64_t g = 0; g < groups; ++g) {
-    const u32* n = h_mods + g * limbs;
-    if (!(n[0] & 1u)) return MX_ERR_MODULUS;
-    int b = bit_length(n, limbs);
-    if (b < 2) return MX_ERR_MODULUS;
-    if (b > max_bits) max_bits = b;
+// R mod N of every group, on the device (mx_setup.hpp); always the narrow-L instance of the
+// geometry's K would give a different R, so the instance follows the geometry of the consumer
+template <int K, int L>
+int launch_rmodn_kl(const mx::RmodnArgs& a, hipStream_t s) {
+  using M_t = mx::Mont<K, L, LIMB_BITS, true>;
+  int gpw = 64 / K;
+  int64_t nblocks = (a.groups + gpw - 1) / gpw;
+  hipLaunchKernelGGL((mx::rmodn_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64),
+                     (size_t)gpw * M_t::LDS_WORDS * 4, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+int launch_rmodn(const Geometry& g, const u32* d_mods, u32* d_rmodn, int limbs, int64_t groups, hipStream_t s) {
+  mx::RmodnArgs a;
+  a.mods = d_mods; a.rmodn = d_rmodn; a.groups = groups; a.limbs = limbs; a.nblk = g.nblk;
+  const bool wide = g.L == LIMBS_PER_LANE_WIDE;
+  switch (g.K) {
+#define MX_CASE(KK) case KK: return wide ? launch_rmodn_kl<KK, LIMBS_PER_LANE_WIDE>(a, s) : launch_rmodn_kl<KK, LIMBS_PER_LANE>(a, s);
+    MX_CASE(1) MX_CASE(2) MX_CASE(4) MX_CASE(8) MX_CASE(16) MX_CASE(32)
+#undef MX_CASE
+    case 64: return wide ? MX_ERR_SIZE : launch_rmodn_kl<64, LIMBS_PER_LANE>(a, s);
   }
-  PowmodPlan p;
-  if (!plan_powmod(max_bits, limbs, exp_limbs, batch, groups, p)) return MX_ERR_SIZE;
-  // the sizing call only knows `limbs`; it assumes the largest modulus that fits them
-  if (p.total > ws_bytes) return MX_ERR_WORKSPACE;
-  int max_ebits = 0;
-  for (int64_t g = 0; g < groups; ++g) {
-    int b = bit_length(h_exps + g * exp_limbs, exp_limbs);
-    if (b > max_ebits) max_ebits = b;
-  }
+  return MX_ERR_SIZE;
+}
+
+// Common tail of the modexp entry points: moduli and exponents are device-resident
+// (d_mods [groups][limbs], d_exps [groups][exp_limbs]); h_exp0 is the host copy of the exponent when
+// the launch shares one (sliding-window schedule), else null.
+int powmod_launch(const uint32_t* d_bases, uint32_t* d_out, const u32* d_mods, const u32* d_exps, const u32* h_exp0,
+                  int limbs, int exp_limbs, int max_ebits, int64_t groups, int64_t group_size, const PowmodPlan& p,
+                  char* ws, hipStream_t s) {
+  MX_TRY(launch_rmodn(p.geo, d_mods, (u32*)(ws + p.off_rmodn), limbs, groups, s));
   int ndigits = (max_ebits + p.win - 1) / p.win;
   if (ndigits < 1) ndigits = 1;
-
-  // per-group constants: R mod N with R = 2^(W*L*nblk)
-  const int m = p.geo.W * p.geo.L * p.geo.nblk;
-  std::vector<u32> rmodn((size_t)groups * limbs);
-  for (int64_t g = 0; g < groups; ++g) two_pow_mod(rmodn.data() + g * limbs, h_mods + g * limbs, limbs, m);
-  std::vector<u32> exps((size_t)groups * (exp_limbs + 1), 0u);
-  for (int64_t g = 0; g < groups; ++g)
-    std::memcpy(exps.data() + g * (exp_limbs + 1), h_exps + g * exp_limbs, (size_t)exp_limbs * 4);
-
-  char* ws = (char*)d_ws;
-  MX_TRY(upload_words(ws + p.off_mods, h_mods, (size_t)groups * limbs, s));
-  MX_TRY(upload_words(ws + p.off_rmodn, rmodn.data(), rmodn.size(), s));
-  MX_TRY(upload_words(ws + p.off_exps, exps.data(), exps.size(), s));
-
   mx::PowmodArgs a;
   a.bases = d_bases; a.out = d_out;
-  a.mods = (const u32*)(ws + p.off_mods);
+  a.mods = d_mods;
   a.rmodn = (const u32*)(ws + p.off_rmodn);
-  a.exps = (const u32*)(ws + p.off_exps);
+  a.exps = d_exps;
   a.table = (u32*)(ws + p.off_table);
-  a.batch = batch; a.group_size = group_size;
+  a.batch = groups * group_size; a.group_size = group_size;
   a.limbs = limbs; a.elimbs = exp_limbs; a.ndigits = ndigits; a.win = p.win; a.nblk = p.geo.nblk;
   a.ops = nullptr; a.nops = 0;
-  if (groups == 1 && max_ebits > 0) {
+  if (groups == 1 && max_ebits > 0 && h_exp0) {
     // one exponent for the whole launch: sliding window (odd powers only)
     int w = sliding_window(max_ebits);
     if (w > p.win) w = p.win;                       // the table region was sized for 2^win entries
-    std::vector<u32> ops = sliding_schedule(h_exps, exp_limbs, w);
+    std::vector<u32> ops = pack_sliding_ops(sliding_schedule(h_exp0, exp_limbs, w));
     if ((int)ops.size() <= MAX_SLIDING_OPS) {
       MX_TRY(upload_words(ws + p.off_ops, ops.data(), ops.size(), s));
       a.ops = (const u32*)(ws + p.off_ops);
@@ -150,6 +150,38 @@ int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods
     case 64: return launch_powmod_k<64>(a, p.nblocks, p.geo.L, s);
   }
   return MX_ERR_SIZE;
+}
+
+// host operands: validate, upload, launch
+int powmod_impl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods, const uint32_t* h_exps,
+                int limbs, int exp_limbs, int64_t groups, int64_t group_size, int limbs_per_lane, void* d_ws,
+                int64_t ws_bytes, void* stream) {
+  if (!d_bases || !d_out || !h_mods || !h_exps || !d_ws) return MX_ERR_ARG;
+  if (limbs <= 0 || exp_limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
+  hipStream_t s = (hipStream_t)stream;
+  int64_t batch = groups * group_size;
+  int max_bits = 0;
+  for (int64_t g = 0; g < groups; ++g) {
+    const u32* n = h_mods + g * limbs;
+    if (!(n[0] & 1u)) return MX_ERR_MODULUS;
+    int b = bit_length(n, limbs);
+    if (b < 2) return MX_ERR_MODULUS;
+    if (b > max_bits) max_bits = b;
+  }
+  PowmodPlan p;
+  if (!plan_powmod(max_bits, limbs, exp_limbs, batch, groups, p, limbs_per_lane)) return MX_ERR_SIZE;
+  // the sizing call only knows `limbs`; it assumes the largest modulus that fits them
+  if (p.total > ws_bytes) return MX_ERR_WORKSPACE;
+  int max_ebits = 0;
+  for (int64_t g = 0; g < groups; ++g) {
+    int b = bit_length(h_exps + g * exp_limbs, exp_limbs);
+    if (b > max_ebits) max_ebits = b;
+  }
+  char* ws = (char*)d_ws;
+  MX_TRY(upload_words(ws + p.off_mods, h_mods, (size_t)groups * limbs, s));
+  MX_TRY(upload_words(ws + p.off_exps, h_exps, (size_t)groups * exp_limbs, s));
+  return powmod_launch(d_bases, d_out, (const u32*)(ws + p.off_mods), (const u32*)(ws + p.off_exps),
+                       groups == 1 ? h_exps : nullptr, limbs, exp_limbs, max_ebits, groups, group_size, p, ws, s);
 }
 
 // ---- lane self-test ------------------------------------------------------------------------
@@ -189,7 +221,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 100; }
+int mx_version(void) { return 200; }
 
 const char* mx_error_string(int code) {
   switch (code) {
@@ -241,7 +273,7 @@ int mx_profile_collect(double* total_ms, int* launches) {
 
 int mx_geometry(int mod_bits, int* k, int* l, int* w, int* blocks) {
   Geometry g;
-  int lpl = (g_limbs_per_lane == LIMBS_PER_LANE_WIDE) ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+  int lpl = (override_limbs_per_lane() == LIMBS_PER_LANE_WIDE) ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
   if (!choose_geometry(mod_bits, g, lpl)) return MX_ERR_SIZE;
   if (k) *k = g.K;
   if (l) *l = g.L;
@@ -262,14 +294,48 @@ int64_t mx_powmod_workspace_bytes(int limbs, int exp_limbs, int64_t batch, int64
 int mx_powmod_shared(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
                      int limbs, int exp_limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes,
                      void* stream) {
-  return powmod_impl(d_bases, d_out, h_mod, h_exp, limbs, exp_limbs, 1, batch, d_workspace, workspace_bytes, stream);
+  return powmod_impl(d_bases, d_out, h_mod, h_exp, limbs, exp_limbs, 1, batch, override_limbs_per_lane(),
+                     d_workspace, workspace_bytes, stream);
+}
+
+int mx_powmod_shared_lpl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
+                         int limbs, int exp_limbs, int64_t batch, int limbs_per_lane, void* d_workspace,
+                         int64_t workspace_bytes, void* stream) {
+  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  return powmod_impl(d_bases, d_out, h_mod, h_exp, limbs, exp_limbs, 1, batch, limbs_per_lane, d_workspace,
+                     workspace_bytes, stream);
 }
 
 int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mods, const uint32_t* h_exps,
                     int limbs, int exp_limbs, int64_t groups, int64_t group_size, void* d_workspace,
                     int64_t workspace_bytes, void* stream) {
-  return powmod_impl(d_bases, d_out, h_mods, h_exps, limbs, exp_limbs, groups, group_size, d_workspace,
-                     workspace_bytes, stream);
+  return powmod_impl(d_bases, d_out, h_mods, h_exps, limbs, exp_limbs, groups, group_size,
+                     override_limbs_per_lane(), d_workspace, workspace_bytes, stream);
+}
+
+int mx_powmod_multi_dev(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* d_mods, const uint32_t* d_exps,
+                        int limbs, int exp_limbs, int mod_bits, int exp_bits, int64_t groups, int64_t group_size,
+                        int limbs_per_lane, void* d_workspace, int64_t workspace_bytes, void* stream) {
+  if (!d_bases || !d_out || !d_mods || !d_exps || !d_workspace) return MX_ERR_ARG;
+  if (limbs <= 0 || exp_limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
+  if (mod_bits < 2 || mod_bits > 32 * limbs || exp_bits < 0 || exp_bits > 32 * exp_limbs) return MX_ERR_ARG;
+  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  PowmodPlan p;
+  if (!plan_powmod(mod_bits, limbs, exp_limbs, groups * group_size, groups, p, limbs_per_lane)) return MX_ERR_SIZE;
+  if (p.total > workspace_bytes) return MX_ERR_WORKSPACE;
+  return powmod_launch(d_bases, d_out, d_mods, d_exps, nullptr, limbs, exp_limbs, exp_bits, groups, group_size, p,
+                       (char*)d_workspace, (hipStream_t)stream);
+}
+
+int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* k, int* l, int* w,
+                           int* blocks) {
+  if (!k || !l || !w || !blocks || batch <= 0 || groups <= 0) return MX_ERR_ARG;
+  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  Geometry g;
+  if (!choose_geometry(mod_bits, g, limbs_per_lane ? limbs_per_lane : auto_limbs_per_lane(mod_bits, batch, groups)))
+    return MX_ERR_SIZE;
+  *k = g.K; *l = g.L; *w = g.W; *blocks = g.nblk;
+  return MX_OK;
 }
 
 int mx_selftest_lanes(void* stream) {
@@ -353,16 +419,18 @@ int launch_combine_k(const mx::CombineArgs& a, hipStream_t s) {
 }
 }  // namespace
 
-extern "C" int64_t mx_combine_workspace_bytes(int limbs, int limbs2, int n_partials, int64_t batch) {
-  if (limbs <= 0 || limbs2 < limbs || n_partials <= 0 || batch <= 0) return MX_ERR_ARG;
-  return align256((int64_t)5 * limbs2 * 4);
+inline int64_t combine_plan_words(int limbs2) { return (int64_t)5 * limbs2; }
+
+extern "C" int64_t mx_combine_plan_bytes(int limbs, int limbs2) {
+  if (limbs <= 0 || limbs2 < limbs) return MX_ERR_ARG;
+  return align256(combine_plan_words(limbs2) * 4);
 }
 
-extern "C" int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* d_status, const uint32_t* h_n,
-                          const uint32_t* h_theta_inv, int limbs, int limbs2, int n_partials, int64_t batch,
-                          void* d_ws, int64_t ws_bytes, void* stream) {
-  if (!d_partials || !d_out || !d_status || !h_n || !h_theta_inv || !d_ws) return MX_ERR_ARG;
-  if (limbs <= 0 || limbs2 < limbs || n_partials <= 0 || batch <= 0) return MX_ERR_ARG;
+// constants of a key, each limbs2 words: N | N^2 | R1 mod N | R2 mod N^2 | theta_inv
+extern "C" int mx_combine_prepare(mx_combine_plan* plan, const uint32_t* h_n, const uint32_t* h_theta_inv, int limbs,
+                                  int limbs2, void* d_plan, int64_t plan_bytes, void* stream) {
+  if (!plan || !h_n || !h_theta_inv || !d_plan) return MX_ERR_ARG;
+  if (limbs <= 0 || limbs2 < limbs) return MX_ERR_ARG;
   if (!(h_n[0] & 1u)) return MX_ERR_MODULUS;
   int bits1 = bit_length(h_n, limbs);
   if (bits1 < 2) return MX_ERR_MODULUS;
@@ -374,8 +442,7 @@ extern "C" int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* 
   if (!choose_geometry(bits2, g2)) return MX_ERR_SIZE;
   Geometry g1 = g2;
   g1.nblk = (bits1 + 4 + g1.W * g1.L - 1) / (g1.W * g1.L);
-  if (align256((int64_t)5 * limbs2 * 4) > ws_bytes) return MX_ERR_WORKSPACE;
-  // constants, each limbs2 words: N | N^2 | R1 mod N | R2 mod N^2 | theta_inv
+  if (mx_combine_plan_bytes(limbs, limbs2) > plan_bytes) return MX_ERR_WORKSPACE;
   std::vector<u32> c((size_t)5 * limbs2, 0u);
   std::memcpy(&c[0], h_n, (size_t)limbs * 4);
   std::memcpy(&c[limbs2], n2.data(), (size_t)std::min(limbs2, 2 * limbs) * 4);
@@ -386,15 +453,34 @@ extern "C" int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* 
     two_pow_mod(&c[(size_t)3 * limbs2], n2p.data(), limbs2, g2.W * g2.L * g2.nblk);
   }
   std::memcpy(&c[(size_t)4 * limbs2], h_theta_inv, (size_t)limbs * 4);
-  hipStream_t s = (hipStream_t)stream;
-  MX_TRY(upload_words(d_ws, c.data(), c.size(), s));
-  const u32* w = (const u32*)d_ws;
+  MX_TRY(upload_words(d_plan, c.data(), c.size(), (hipStream_t)stream));
+  plan->d_plan = d_plan;
+  plan->plan_bytes = plan_bytes;
+  plan->limbs = limbs;
+  plan->limbs2 = limbs2;
+  plan->n_bits = bits1;
+  plan->n2_bits = bits2;
+  return MX_OK;
+}
+
+extern "C" int mx_combine_run(const mx_combine_plan* plan, const uint32_t* d_partials, uint32_t* d_out, int out_stride,
+                              uint8_t* d_status, int n_partials, int64_t batch, void* stream) {
+  if (!plan || !plan->d_plan || !d_partials || !d_out) return MX_ERR_ARG;
+  if (n_partials <= 0 || batch <= 0 || out_stride < plan->limbs) return MX_ERR_ARG;
+  if (!d_status && out_stride == plan->limbs) return MX_ERR_ARG;      // the status must go somewhere
+  Geometry g2;
+  if (!choose_geometry(plan->n2_bits, g2)) return MX_ERR_SIZE;
+  Geometry g1 = g2;
+  g1.nblk = (plan->n_bits + 4 + g1.W * g1.L - 1) / (g1.W * g1.L);
+  const int limbs2 = plan->limbs2;
+  const u32* w = (const u32*)plan->d_plan;
   mx::CombineArgs a;
   a.partials = d_partials; a.out = d_out; a.status = d_status;
   a.n = w; a.n2 = w + limbs2; a.rmodn1 = w + 2 * (size_t)limbs2; a.rmodn2 = w + 3 * (size_t)limbs2;
   a.theta_inv = w + 4 * (size_t)limbs2;
-  a.batch = batch; a.limbs = limbs; a.limbs2 = limbs2; a.np = n_partials;
+  a.batch = batch; a.limbs = plan->limbs; a.limbs2 = limbs2; a.np = n_partials; a.out_stride = out_stride;
   a.nblk1 = g1.nblk; a.nblk2 = g2.nblk;
+  hipStream_t s = (hipStream_t)stream;
   switch (g2.K) {
     case 1: return launch_combine_k<1>(a, s);
     case 2: return launch_combine_k<2>(a, s);
@@ -405,6 +491,22 @@ extern "C" int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* 
     case 64: return launch_combine_k<64>(a, s);
   }
   return MX_ERR_SIZE;
+}
+
+// ---- one-shot form: prepare into the workspace, run
+extern "C" int64_t mx_combine_workspace_bytes(int limbs, int limbs2, int n_partials, int64_t batch) {
+  if (limbs <= 0 || limbs2 < limbs || n_partials <= 0 || batch <= 0) return MX_ERR_ARG;
+  return mx_combine_plan_bytes(limbs, limbs2);
+}
+
+extern "C" int mx_combine(const uint32_t* d_partials, uint32_t* d_out, uint8_t* d_status, const uint32_t* h_n,
+                          const uint32_t* h_theta_inv, int limbs, int limbs2, int n_partials, int64_t batch,
+                          void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_partials || !d_out || !d_status || !h_n || !h_theta_inv || !d_ws) return MX_ERR_ARG;
+  if (limbs <= 0 || limbs2 < limbs || n_partials <= 0 || batch <= 0) return MX_ERR_ARG;
+  mx_combine_plan plan;
+  MX_TRY(mx_combine_prepare(&plan, h_n, h_theta_inv, limbs, limbs2, d_ws, ws_bytes, stream));
+  return mx_combine_run(&plan, d_partials, d_out, limbs, d_status, n_partials, batch, stream);
 }
 
 // ---- biprimality verdict -------------------------------------------------------------------
@@ -427,6 +529,32 @@ extern "C" int64_t mx_verdict_workspace_bytes(int limbs, int n_parties, int64_t 
   return 2 * align256((int64_t)groups * limbs * 4);
 }
 
+extern "C" int mx_biprime_verdict_dev(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* d_mods, int limbs,
+                                      int mod_bits, int n_parties, int64_t groups, int64_t n_slots, void* d_ws,
+                                      int64_t ws_bytes, void* stream) {
+  if (!d_v || !d_pass || !d_mods || !d_ws || limbs <= 0 || n_parties <= 0 || groups <= 0 || n_slots <= 0)
+    return MX_ERR_ARG;
+  if (mod_bits < 2 || mod_bits > 32 * limbs) return MX_ERR_ARG;
+  Geometry geo;
+  if (!choose_geometry(mod_bits, geo)) return MX_ERR_SIZE;
+  if (align256((int64_t)groups * limbs * 4) > ws_bytes) return MX_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  MX_TRY(launch_rmodn(geo, d_mods, (u32*)d_ws, limbs, groups, s));
+  mx::VerdictArgs a;
+  a.v = d_v; a.pass = d_pass; a.mods = d_mods; a.rmodn = (const u32*)d_ws;
+  a.groups = groups; a.n_slots = n_slots; a.limbs = limbs; a.n_parties = n_parties; a.nblk = geo.nblk;
+  switch (geo.K) {
+    case 1: return launch_verdict_k<1>(a, s);
+    case 2: return launch_verdict_k<2>(a, s);
+    case 4: return launch_verdict_k<4>(a, s);
+    case 8: return launch_verdict_k<8>(a, s);
+    case 16: return launch_verdict_k<16>(a, s);
+    case 32: return launch_verdict_k<32>(a, s);
+    case 64: return launch_verdict_k<64>(a, s);
+  }
+  return MX_ERR_SIZE;
+}
+
 extern "C" int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const uint32_t* h_mods, int limbs,
                                   int n_parties, int64_t groups, int64_t n_slots, void* d_ws, int64_t ws_bytes,
                                   void* stream) {
@@ -440,30 +568,12 @@ extern "C" int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const ui
     if (b < 2) return MX_ERR_MODULUS;
     if (b > max_bits) max_bits = b;
   }
-  Geometry geo;
-  if (!choose_geometry(max_bits, geo)) return MX_ERR_SIZE;
   int64_t part = align256((int64_t)groups * limbs * 4);
   if (2 * part > ws_bytes) return MX_ERR_WORKSPACE;
-  std::vector<u32> rmodn((size_t)groups * limbs);
-  for (int64_t g = 0; g < groups; ++g)
-    two_pow_mod(rmodn.data() + g * limbs, h_mods + g * limbs, limbs, geo.W * geo.L * geo.nblk);
-  hipStream_t s = (hipStream_t)stream;
   char* ws = (char*)d_ws;
-  MX_TRY(upload_words(ws, h_mods, (size_t)groups * limbs, s));
-  MX_TRY(upload_words(ws + part, rmodn.data(), rmodn.size(), s));
-  mx::VerdictArgs a;
-  a.v = d_v; a.pass = d_pass; a.mods = (const u32*)ws; a.rmodn = (const u32*)(ws + part);
-  a.groups = groups; a.n_slots = n_slots; a.limbs = limbs; a.n_parties = n_parties; a.nblk = geo.nblk;
-  switch (geo.K) {
-    case 1: return launch_verdict_k<1>(a, s);
-    case 2: return launch_verdict_k<2>(a, s);
-    case 4: return launch_verdict_k<4>(a, s);
-    case 8: return launch_verdict_k<8>(a, s);
-    case 16: return launch_verdict_k<16>(a, s);
-    case 32: return launch_verdict_k<32>(a, s);
-    case 64: return launch_verdict_k<64>(a, s);
-  }
-  return MX_ERR_SIZE;
+  MX_TRY(upload_words(ws, h_mods, (size_t)groups * limbs, (hipStream_t)stream));
+  return mx_biprime_verdict_dev(d_v, d_pass, (const u32*)ws, limbs, max_bits, n_parties, groups, n_slots, ws + part,
+                                ws_bytes - part, stream);
 }
 
 // ---- Jacobi symbol -------------------------------------------------------------------------
@@ -482,17 +592,13 @@ extern "C" int64_t mx_jacobi_workspace_bytes(int limbs, int64_t groups) {
   return align256((int64_t)groups * limbs * 4);
 }
 
-extern "C" int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
-                         int64_t group_size, void* d_ws, int64_t ws_bytes, void* stream) {
-  if (!d_values || !d_out || !h_mods || !d_ws || limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
+extern "C" int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs,
+                             int64_t groups, int64_t group_size, void* stream) {
+  if (!d_values || !d_out || !d_mods || limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
   if (limbs > 129) return MX_ERR_SIZE;
-  for (int64_t g = 0; g < groups; ++g)
-    if (!(h_mods[g * limbs] & 1u)) return MX_ERR_MODULUS;
-  if (align256((int64_t)groups * limbs * 4) > ws_bytes) return MX_ERR_WORKSPACE;
   hipStream_t s = (hipStream_t)stream;
-  MX_TRY(upload_words(d_ws, h_mods, (size_t)groups * limbs, s));
   mx::JacobiArgs a;
-  a.a = d_values; a.mods = (const u32*)d_ws; a.out = (signed char*)d_out;
+  a.a = d_values; a.mods = d_mods; a.out = (signed char*)d_out;
   a.count = groups * group_size; a.group_size = group_size; a.limbs = limbs;
   if (limbs <= 3) return launch_jacobi<3>(a, s);
   if (limbs <= 5) return launch_jacobi<5>(a, s);
@@ -501,6 +607,17 @@ extern "C" int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t
   if (limbs <= 33) return launch_jacobi<33>(a, s);
   if (limbs <= 65) return launch_jacobi<65>(a, s);
   return launch_jacobi<129>(a, s);
+}
+
+extern "C" int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
+                         int64_t group_size, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_values || !d_out || !h_mods || !d_ws || limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
+  if (limbs > 129) return MX_ERR_SIZE;
+  for (int64_t g = 0; g < groups; ++g)
+    if (!(h_mods[g * limbs] & 1u)) return MX_ERR_MODULUS;
+  if (align256((int64_t)groups * limbs * 4) > ws_bytes) return MX_ERR_WORKSPACE;
+  MX_TRY(upload_words(d_ws, h_mods, (size_t)groups * limbs, (hipStream_t)stream));
+  return mx_jacobi_dev(d_values, d_out, (const u32*)d_ws, limbs, groups, group_size, stream);
 }
 
 // ---- modular multiplication ------------------------------------------------------------------

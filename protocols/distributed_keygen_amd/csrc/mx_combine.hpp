@@ -15,15 +15,16 @@ namespace mx {
 
 struct CombineArgs {
   const u32* partials;   // [np][batch][limbs2] device
-  u32* out;              // [batch][limbs] device
-  unsigned char* status; // [batch] device
+  u32* out;              // [batch][out_stride] device: limbs words of plaintext, then (if the row is
+                         // wider) one status word and zeros — one row = one unit of an all-gather
+  unsigned char* status; // [batch] device, or null
   const u32* n;          // [limbs2] device, N zero padded
   const u32* n2;         // [limbs2] device, N^2
   const u32* rmodn1;     // [limbs2] device, R1 mod N
   const u32* rmodn2;     // [limbs2] device, R2 mod N^2
   const u32* theta_inv;  // [limbs2] device
   long long batch;
-  int limbs, limbs2, np;
+  int limbs, limbs2, np, out_stride;
   int nblk1, nblk2;
 };
 
@@ -118,8 +119,11 @@ __global__ void __launch_bounds__(64) combine_kernel(CombineArgs A) {
 #pragma unroll
     for (int j = 0; j < L; ++j) m[j] = 0;
   }
-  M1.store(A.out + elem * A.limbs, A.limbs, m, valid);
-  if (valid && M1.p == 0) A.status[elem] = divisible ? 0 : 1;
+  M1.store(A.out + elem * A.out_stride, A.limbs, m, valid);
+  if (valid && M1.p == 0) {
+    if (A.status) A.status[elem] = divisible ? 0 : 1;
+    for (int k = A.limbs; k < A.out_stride; ++k) A.out[elem * A.out_stride + k] = (k == A.limbs && !divisible) ? 1u : 0u;
+  }
 }
 
 }  // namespace mx

@@ -25,8 +25,10 @@ struct Geometry {
 };
 
 // R = 2^(W*L*nblk) must be >= 16 N (lazy reduction bound, mx_mont.hpp), nblk <= K.
+// Largest modulus the engine takes (any geometry): the narrow geometry's R = 2^(W*9*64) >= 16 N.
+constexpr int MAX_MOD_BITS = LIMB_BITS * LIMBS_PER_LANE * 64 - 4;
 inline bool choose_geometry(int mod_bits, Geometry& g, int limbs_per_lane = LIMBS_PER_LANE) {
-  if (mod_bits < 2) return false;
+  if (mod_bits < 2 || mod_bits > MAX_MOD_BITS) return false;
   g.L = limbs_per_lane;
   int need = mod_bits + 4;
   int per_blk = g.W * g.L;
@@ -149,10 +151,15 @@ inline int sliding_window(int exp_bits) {
   return best;
 }
 
-// Left-to-right sliding-window schedule of a non-zero exponent: ops[k] = (squarings << 16) |
-// (index of the odd power + 1), index + 1 == 0 for the trailing squarings.  ops[0] only loads.
-inline std::vector<u32> sliding_schedule(const u32* e, int limbs, int w) {
-  std::vector<u32> ops;
+// Left-to-right sliding-window schedule of a non-zero exponent: step k squares `squarings` times and
+// then multiplies by the odd power with index `index1 - 1` (index1 == 0: trailing squarings, no
+// multiplication).  Step 0 only loads its odd power.
+struct SlidingOp {
+  int squarings;
+  u32 index1;
+};
+inline std::vector<SlidingOp> sliding_schedule(const u32* e, int limbs, int w) {
+  std::vector<SlidingOp> ops;
   int bits = bit_length(e, limbs);
   auto bit = [&](int i) { return (e[i >> 5] >> (i & 31)) & 1u; };
   int i = bits - 1, pending = 0;
@@ -163,31 +170,38 @@ inline std::vector<u32> sliding_schedule(const u32* e, int limbs, int w) {
     u32 val = 0;
     for (int k = 0; k < l; ++k) val = (val << 1) | bit(i - k);
     u32 idx1 = (val - 1) / 2 + 1;
-    ops.push_back(ops.empty() ? idx1 : (((u32)(pending + l) << 16) | idx1));
+    ops.push_back(SlidingOp{ops.empty() ? 0 : pending + l, idx1});
     pending = 0;
     i -= l;
   }
-  if (pending) ops.push_back((u32)pending << 16);
+  if (pending) ops.push_back(SlidingOp{pending, 0u});
   return ops;
 }
 
-// Which limbs-per-lane to run a modexp batch with.  The wide geometry spends a larger share of its
-// instructions on multiply-accumulates (the per-limb bookkeeping is amortised over 2L MACs) but
-// puts half as many lanes on the machine; it pays once the batch still fills every SIMD with
-// at least two wavefronts (1024 SIMDs x 64 lanes) — or when the caller keeps several batches in
-// flight on different streams, which the library cannot see: mx_set_limbs_per_lane(9|18) or the
-// environment variable MX_LIMBS_PER_LANE override the automatic choice.
-extern int g_limbs_per_lane;   // 0 = automatic; set by mx_set_limbs_per_lane
-inline int pick_limbs_per_lane(int mod_bits, int64_t batch) {
+// The schedule as the words powmod_kernel<..., SLIDING> reads: (squarings << 16) | index1.  A run of
+// more than 65535 squarings (an exponent with that many consecutive zero bits) is split into
+// squaring-only words so that the 16-bit field never overflows.
+inline std::vector<u32> pack_sliding_ops(const std::vector<SlidingOp>& ops) {
+  std::vector<u32> out;
+  for (size_t k = 0; k < ops.size(); ++k) {
+    int nsq = ops[k].squarings;
+    while (nsq > 0xFFFF) { out.push_back(0xFFFFu << 16); nsq -= 0xFFFF; }
+    out.push_back(((u32)nsq << 16) | ops[k].index1);
+  }
+  return out;
+}
+
+// Limbs per lane (9 narrow / 18 wide) are a per-call argument of the entry points that end in _lpl,
+// _dev or _run.  The older entry points without that argument honour a process-wide override
+// (mx_set_limbs_per_lane, or the environment variable MX_LIMBS_PER_LANE); 0 = automatic.
+extern int g_limbs_per_lane;
+inline int override_limbs_per_lane() {
   if (g_limbs_per_lane == LIMBS_PER_LANE || g_limbs_per_lane == LIMBS_PER_LANE_WIDE) return g_limbs_per_lane;
   if (const char* e = getenv("MX_LIMBS_PER_LANE")) {
     int v = atoi(e);
     if (v == LIMBS_PER_LANE || v == LIMBS_PER_LANE_WIDE) return v;
   }
-  Geometry wide;
-  if (!choose_geometry(mod_bits, wide, LIMBS_PER_LANE_WIDE)) return LIMBS_PER_LANE;
-  int64_t waves = (batch * wide.K + 63) / 64;
-  return waves >= 2 * 1024 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+  return 0;
 }
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }

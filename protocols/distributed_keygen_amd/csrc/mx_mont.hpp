@@ -395,6 +395,37 @@ struct Mont {
     for (int j = 0; j < L; ++j) r2[j] = x[j];
   }
 
+  // R mod N (the Montgomery form of 1) from the modulus alone, exact limbs: start from the largest
+  // power of two below N and double with a conditional subtraction until 2^(W*L*nblk) is reached.
+  // R >= 16 N, so this is at most W*L + 4 doublings for a modulus that fills its geometry; groups of
+  // one wavefront may hold moduli of different lengths, so the loop runs over the wave-wide range
+  // and every group joins in at its own starting bit (uniform control flow, no divergence).
+  __device__ __forceinline__ void rmodn_by_doubling(u32 (&x)[L]) {
+    int top = -1;
+#pragma unroll
+    for (int j = 0; j < L; ++j) top = n[j] ? W * (p * L + j) + (31 - __builtin_clz(n[j])) : top;
+#pragma unroll
+    for (int off = K / 2; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off));   // stays inside the group
+    int lo;
+    lo = top;
+    for (int off = 32; off > 0; off >>= 1) lo = min(lo, __shfl_xor(lo, off));
+    lo = __builtin_amdgcn_readfirstlane(lo);
+#pragma unroll
+    for (int j = 0; j < L; ++j) x[j] = (top >= 0 && top / W == p * L + j) ? (1u << (top % W)) : 0u;
+    const int m = W * L * nblk;
+    for (int i = (lo < 0 ? 0 : lo); i < m; ++i) {
+      u64 t[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) t[j] = (u64)x[j] << 1;
+      u32 y[L];
+      normalize_full(y, t);
+      cond_sub(y);
+      const bool take = i >= top;
+#pragma unroll
+      for (int j = 0; j < L; ++j) x[j] = take ? y[j] : x[j];
+    }
+  }
+
   // lazy Montgomery-domain value -> canonical residue in [0, N), exact limbs
   __device__ __forceinline__ void from_mont_canonical(u32 (&out)[L], const u32 (&x)[L]) {
     u32 one[L];

@@ -18,8 +18,8 @@ struct PowmodArgs {
   const u32* bases;   // [batch][limbs]      device, radix 2^32 little-endian words
   u32* out;           // [batch][limbs]      device
   const u32* mods;    // [groups][limbs]     device (workspace copy)
-  const u32* rmodn;   // [groups][limbs]     device: R mod N per group (host-computed)
-  const u32* exps;    // [groups][elimbs+1]  device, zero padded
+  const u32* rmodn;   // [groups][limbs]     device: R mod N per group (rmodn_kernel, mx_setup.hpp)
+  const u32* exps;    // [groups][elimbs]    device
   u32* table;         // [2^win][L][nlanes]  device
   i64 batch;
   i64 group_size;
@@ -122,12 +122,12 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 1)) powmod_kernel(PowmodArgs 
     }
   }
 
-  const u32* ex = A.exps + grp * (A.elimbs + 1);
+  const u32* ex = A.exps + grp * A.elimbs;
   const u32 wmask = (1u << A.win) - 1u;
   auto digit = [&](int d) -> u32 {
     int bit = d * A.win;
     int w = bit >> 5, off = bit & 31;
-    u64 v = (u64)ex[w] | ((u64)ex[w + 1] << 32);
+    u64 v = (u64)ex[w] | ((u64)(w + 1 < A.elimbs ? ex[w + 1] : 0u) << 32);
     return (u32)(v >> off) & wmask;
   };
 

@@ -22,20 +22,15 @@ __global__ void __launch_bounds__(256) upload_kernel(uint32_t* dst, UploadChunk 
 }
 
 int upload_words(void* d_dst, const uint32_t* h_src, size_t n, hipStream_t s) {
-  if (n <= (size_t)UPLOAD_WORDS * 32) {
-    UploadChunk c;
-    for (size_t off = 0; off < n; off += UPLOAD_WORDS) {
-      int m = (int)std::min<size_t>(UPLOAD_WORDS, n - off);
-      std::memcpy(c.w, h_src + off, (size_t)m * 4);
-      hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(256), 0, s, (uint32_t*)d_dst + off, c, m);
-      MX_HIP(hipGetLastError());
-    }
-    return MX_OK;
+  // any size: one launch per 3.5 KiB chunk, never a synchronisation (operand sets of thousands of
+  // moduli are better passed device-resident through the *_dev entry points)
+  UploadChunk c;
+  for (size_t off = 0; off < n; off += UPLOAD_WORDS) {
+    int m = (int)std::min<size_t>(UPLOAD_WORDS, n - off);
+    std::memcpy(c.w, h_src + off, (size_t)m * 4);
+    hipLaunchKernelGGL(upload_kernel, dim3(1), dim3(256), 0, s, (uint32_t*)d_dst + off, c, m);
+    MX_HIP(hipGetLastError());
   }
-  // large operand sets (thousands of candidate moduli): staged copy, then wait for it so that the
-  // caller may release h_src
-  MX_HIP(hipMemcpyAsync(d_dst, h_src, n * 4, hipMemcpyHostToDevice, s));
-  MX_HIP(hipStreamSynchronize(s));
   return MX_OK;
 }
 #define MX_TRY(call) do { int rc__ = (call); if (rc__ != MX_OK) return rc__; } while (0)
@@ -70,8 +65,6 @@ struct MxKernelTimer {
 };
 
 namespace {
-// Largest modulus the engine takes: R = 2^(W*L*64) >= 16 N.
-constexpr int MAX_MOD_BITS = LIMB_BITS * LIMBS_PER_LANE * 64 - 4;
 // Sizing queries only know the row width; assume the widest modulus that fits it.
 inline int sizing_bits(int limbs) { return 32 * limbs < MAX_MOD_BITS ? 32 * limbs : MAX_MOD_BITS; }
 constexpr int MAX_SLIDING_OPS = 16384;   // covers exponents up to 16384 bits

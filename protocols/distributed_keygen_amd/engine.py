@@ -15,15 +15,30 @@ Engine without a GPU or without the built library raises.
 
 from __future__ import annotations
 
-from typing import List, Optional, Sequence, Tuple
+from collections import OrderedDict
+from typing import Any, Dict, List, Optional, Sequence, Tuple
 
 import numpy as np
 
 from . import _lib, limbs as _limbs
 
 
+class _Plan:
+    """A per-key plan: the ctypes descriptor, the device block it points to (kept alive here) and the
+    event that marks the end of prepare's uploads on the stream they were enqueued on."""
+
+    __slots__ = ("desc", "block", "stream_ptr", "ready")
+
+    def __init__(self, desc, block, stream_ptr, ready) -> None:
+        self.desc, self.block, self.stream_ptr, self.ready = desc, block, stream_ptr, ready
+
+
 class Engine:
-    """One engine per process/GPU.  Not re-entrant (matches the reference's single asyncio thread)."""
+    """One engine per process/GPU.  Calls enqueue on ``torch.cuda.current_stream()``; every stream gets
+    its own workspace, so one Engine may be driven from several streams (one launch in flight per
+    stream).  Not thread-safe (matches the reference's single asyncio thread)."""
+
+    MAX_PLANS = 16     # per-key plans kept (a party normally has one key)
 
     def __init__(self, device: Optional[int] = None) -> None:
         import torch
@@ -34,19 +49,36 @@ class Engine:
         self.lib = _lib.lib()
         idx = torch.cuda.current_device() if device is None else int(device)
         self.device = torch.device("cuda", idx)
-        self._ws = None
+        self._ws: Dict[int, Any] = {}          # stream -> workspace tensor
+        self._lpl = 0                          # lane geometry of this engine's modexp launches (0 = automatic)
+        self._n2_plans: "OrderedDict[Tuple[int, int], _Plan]" = OrderedDict()
+        self._combine_plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
 
     # ------------------------------------------------------------------ plumbing
     def _stream_ptr(self) -> int:
         return int(self.torch.cuda.current_stream(self.device).cuda_stream)
 
     def _workspace(self, nbytes: int):
+        """Scratch of the CURRENT stream (launches on different streams must not share scratch: the
+        window tables of one launch would be overwritten by the next)."""
         if nbytes < 0:
             _lib.check(int(nbytes), "workspace query")
-        if self._ws is None or self._ws.numel() < nbytes:
-            self._ws = None
-            self._ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
-        return self._ws
+        key = self._stream_ptr()
+        ws = self._ws.get(key)
+        if ws is None or ws.numel() < nbytes:
+            self._ws[key] = None
+            with self.torch.cuda.device(self.device):
+                ws = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+            self._ws[key] = ws
+        return ws
+
+    def _use_plan(self, plan: _Plan) -> None:
+        """Order the current stream after the plan's uploads if they were enqueued on another stream."""
+        if plan.ready is not None:
+            if plan.stream_ptr != self._stream_ptr():
+                self.torch.cuda.current_stream(self.device).wait_event(plan.ready)
+            if plan.ready.query():
+                plan.ready = None
 
     def to_device(self, rows: np.ndarray):
         """uint32 rows -> int32 device tensor (bit pattern preserved)."""
@@ -61,18 +93,22 @@ class Engine:
         self.torch.cuda.current_stream(self.device).synchronize()
 
     def set_limbs_per_lane(self, limbs_per_lane: int) -> None:
-        """0 = automatic, 9 = narrow geometry, 18 = wide geometry (process-wide; include/mxpaillier.h)."""
-        _lib.check(self.lib.mx_set_limbs_per_lane(int(limbs_per_lane)), "mx_set_limbs_per_lane")
+        """Lane geometry of this engine's modexp launches: 0 = automatic (from the batch size), 9 =
+        narrow, 18 = wide.  Passed with every call (no process-wide state)."""
+        if limbs_per_lane not in (0, 9, 18):
+            raise ValueError("limbs_per_lane must be 0, 9 or 18")
+        self._lpl = int(limbs_per_lane)
 
     def selftest_lanes(self) -> int:
         with self.torch.cuda.device(self.device):
             return _lib.check(self.lib.mx_selftest_lanes(self._stream_ptr()), "mx_selftest_lanes")
 
-    def geometry(self, mod_bits: int) -> Tuple[int, int, int, int]:
+    def geometry(self, mod_bits: int, batch: int = 1, groups: int = 1) -> Tuple[int, int, int, int]:
+        """(lanes per element, limbs per lane, limb bits, blocks) of a generic-modulus modexp launch."""
         import ctypes
 
         k, l, w, b = (ctypes.c_int() for _ in range(4))
-        _lib.check(self.lib.mx_geometry(mod_bits, k, l, w, b), "mx_geometry")
+        _lib.check(self.lib.mx_powmod_geometry_for(mod_bits, batch, groups, self._lpl, k, l, w, b), "mx_powmod_geometry_for")
         return k.value, l.value, w.value, b.value
 
     def profile(self, enable: bool) -> None:
@@ -92,8 +128,24 @@ class Engine:
         import ctypes
 
         k, l, w, b = (ctypes.c_int() for _ in range(4))
-        _lib.check(self.lib.mx_nsquare_geometry(n_bits, batch, k, l, w, b), "mx_nsquare_geometry")
+        _lib.check(self.lib.mx_nsquare_geometry_for(n_bits, batch, self._lpl, k, l, w, b), "mx_nsquare_geometry_for")
         return k.value, l.value, w.value, b.value
+
+    def _mods_operand(self, mods, limbs: int, odd_only: bool = True):
+        """Moduli of a per-group launch as (device rows [groups, limbs], max bits).  `mods` is a sequence
+        of Python ints (validated and uploaded here) or an already device-resident pair (rows, bits)."""
+        if isinstance(mods, tuple) and len(mods) == 2 and hasattr(mods[0], "data_ptr"):
+            rows_t, bits = mods
+            if rows_t.shape[1] != limbs:
+                raise ValueError("device moduli must have the row width of the operands")
+            return rows_t, int(bits)
+        for m in mods:
+            if odd_only:
+                _check_modulus(m)
+        bits = _limbs.max_bits(mods)
+        if bits > 32 * limbs:
+            raise ValueError("modulus wider than the limb rows")
+        return self.to_device(_limbs.pack(mods, limbs)), bits
 
     # ------------------------------------------------------------------ modexp, tensor level
     def powmod_shared_t(self, bases_t, mod: int, exp: int, out_t=None):
@@ -110,61 +162,131 @@ class Engine:
             out_t = self.torch.empty_like(bases_t)
         with self.torch.cuda.device(self.device):
             ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, 1))
-            rc = self.lib.mx_powmod_shared(
+            rc = self.lib.mx_powmod_shared_lpl(
                 bases_t.data_ptr(), out_t.data_ptr(), h_mod.ctypes.data, h_exp.ctypes.data,
-                limbs, elimbs, batch, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+                limbs, elimbs, batch, self._lpl, ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
-        _lib.check(rc, "mx_powmod_shared")
+        _lib.check(rc, "mx_powmod_shared_lpl")
         return out_t
 
-    def powmod_multi_t(self, bases_t, mods: Sequence[int], exps: Sequence[int], group_size: int, out_t=None):
-        """out[g*group_size+k] = bases[g*group_size+k]^exps[g] mod mods[g]."""
-        groups = len(mods)
-        if len(exps) != groups:
-            raise ValueError("one exponent per modulus expected")
-        if any(e < 0 for e in exps):
-            raise ValueError("negative exponent")
+    def powmod_multi_t(self, bases_t, mods, exps, group_size: int, out_t=None):
+        """out[g*group_size+k] = bases[g*group_size+k]^exps[g] mod mods[g].  `mods` / `exps`: sequences of
+        ints, or device-resident (rows, max bits) pairs — the operands reach the kernel as device rows
+        either way (mx_powmod_multi_dev), so thousands of candidates cost no host-side staging."""
         batch, limbs = bases_t.shape
+        mods_t, mod_bits = self._mods_operand(mods, limbs)
+        groups = mods_t.shape[0]
+        if isinstance(exps, tuple) and len(exps) == 2 and hasattr(exps[0], "data_ptr"):
+            exps_t, exp_bits = exps[0], int(exps[1])
+        else:
+            if len(exps) != groups:
+                raise ValueError("one exponent per modulus expected")
+            if any(e < 0 for e in exps):
+                raise ValueError("negative exponent")
+            exp_bits = _limbs.max_bits(exps)
+            exps_t = self.to_device(_limbs.pack(exps, _limbs.limbs_for_bits(exp_bits)))
+        if exps_t.shape[0] != groups:
+            raise ValueError("one exponent per modulus expected")
+        elimbs = exps_t.shape[1]
         if batch != groups * group_size:
             raise ValueError("bases must hold groups*group_size rows")
-        if _limbs.max_bits(mods) > 32 * limbs:
-            raise ValueError("modulus wider than the limb rows")
-        elimbs = _limbs.limbs_for_bits(_limbs.max_bits(exps))
-        h_mods = _limbs.pack(mods, limbs)
-        h_exps = _limbs.pack(exps, elimbs)
         if out_t is None:
             out_t = self.torch.empty_like(bases_t)
         with self.torch.cuda.device(self.device):
             ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, groups))
-            rc = self.lib.mx_powmod_multi(
-                bases_t.data_ptr(), out_t.data_ptr(), h_mods.ctypes.data, h_exps.ctypes.data,
-                limbs, elimbs, groups, group_size, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            rc = self.lib.mx_powmod_multi_dev(
+                bases_t.data_ptr(), out_t.data_ptr(), mods_t.data_ptr(), exps_t.data_ptr(),
+                limbs, elimbs, mod_bits, exp_bits, groups, group_size, self._lpl, ws.data_ptr(), ws.numel(),
+                self._stream_ptr(),
             )
-        _lib.check(rc, "mx_powmod_multi")
+        _lib.check(rc, "mx_powmod_multi_dev")
         return out_t
+
+    # ------------------------------------------------------------------ per-key plans
+    def nsquare_plan(self, n: int, exp: int) -> _Plan:
+        """The plan of `x -> x^exp mod n^2` (constants and tape of mx_powmod_nsquare_prepare), cached:
+        (n, exp) is a key's public modulus and the party's Lagrange-folded share (PSK:46, PSK:79-85)."""
+        key = (n, exp)
+        plan = self._n2_plans.get(key)
+        if plan is not None:
+            self._n2_plans.move_to_end(key)
+            return plan
+        if exp < 0:
+            raise ValueError("negative exponent: invert the base first (paillier_shared_key.py:89-91)")
+        _check_modulus(n)
+        limbs_n = _limbs.limbs_for(n)
+        elimbs = _limbs.limbs_for(exp)
+        h_n = _limbs.pack_one(n, limbs_n)
+        h_exp = _limbs.pack_one(exp, elimbs)
+        desc = _lib.NsquarePlan()
+        with self.torch.cuda.device(self.device):
+            nbytes = _lib.check(self.lib.mx_nsquare_plan_bytes(limbs_n, elimbs), "mx_nsquare_plan_bytes")
+            block = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+            rc = self.lib.mx_powmod_nsquare_prepare(
+                desc, h_n.ctypes.data, h_exp.ctypes.data, limbs_n, elimbs, block.data_ptr(), block.numel(),
+                self._stream_ptr(),
+            )
+            _lib.check(rc, "mx_powmod_nsquare_prepare")
+            ready = self.torch.cuda.Event()
+            ready.record(self.torch.cuda.current_stream(self.device))
+        plan = _Plan(desc, block, self._stream_ptr(), ready)
+        self._n2_plans[key] = plan
+        while len(self._n2_plans) > self.MAX_PLANS:
+            self._n2_plans.popitem(last=False)
+        return plan
+
+    def combine_plan(self, n: int, theta_inv: int, limbs2: int) -> _Plan:
+        """The plan of the share recombination for a key (mx_combine_prepare), cached."""
+        key = (n, theta_inv, limbs2)
+        plan = self._combine_plans.get(key)
+        if plan is not None:
+            self._combine_plans.move_to_end(key)
+            return plan
+        _check_modulus(n)
+        limbs = _limbs.limbs_for(n)
+        if _limbs.limbs_for(n * n) > limbs2:
+            raise ValueError("partial rows narrower than N^2")
+        if not 0 <= theta_inv < n:
+            raise ValueError("theta_inv must be a residue modulo N")
+        h_n = _limbs.pack_one(n, limbs)
+        h_t = _limbs.pack_one(theta_inv, limbs)
+        desc = _lib.CombinePlan()
+        with self.torch.cuda.device(self.device):
+            nbytes = _lib.check(self.lib.mx_combine_plan_bytes(limbs, limbs2), "mx_combine_plan_bytes")
+            block = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
+            rc = self.lib.mx_combine_prepare(
+                desc, h_n.ctypes.data, h_t.ctypes.data, limbs, limbs2, block.data_ptr(), block.numel(), self._stream_ptr()
+            )
+            _lib.check(rc, "mx_combine_prepare")
+            ready = self.torch.cuda.Event()
+            ready.record(self.torch.cuda.current_stream(self.device))
+        plan = _Plan(desc, block, self._stream_ptr(), ready)
+        self._combine_plans[key] = plan
+        while len(self._combine_plans) > self.MAX_PLANS:
+            self._combine_plans.popitem(last=False)
+        return plan
 
     def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None):
         """out[e] = bases[e]^exp mod n^2 (rows of the width of n^2), computed through pairs modulo n
-        (include/mxpaillier.h: mx_powmod_nsquare) — the fast path of the partial decryption PSK:92."""
+        (include/mxpaillier.h: mx_powmod_nsquare_prepare / _run) — the fast path of the partial
+        decryption PSK:92.  The per-key plan is prepared on first use; afterwards a call is one launch."""
         if exp < 0:
             raise ValueError("negative exponent: invert the base first (paillier_shared_key.py:89-91)")
         batch, limbs2 = bases_t.shape
         _check_modulus(n)
-        limbs_n = _limbs.limbs_for(n)
         if _limbs.limbs_for(n * n) > limbs2:
             raise ValueError("rows narrower than N^2")
-        elimbs = _limbs.limbs_for(exp)
-        h_n = _limbs.pack_one(n, limbs_n)
-        h_exp = _limbs.pack_one(exp, elimbs)
+        plan = self.nsquare_plan(n, exp)
         if out_t is None:
             out_t = self.torch.empty_like(bases_t)
         with self.torch.cuda.device(self.device):
-            ws = self._workspace(self.lib.mx_powmod_nsquare_workspace_bytes(limbs_n, elimbs, batch))
-            rc = self.lib.mx_powmod_nsquare(
-                bases_t.data_ptr(), out_t.data_ptr(), h_n.ctypes.data, h_exp.ctypes.data,
-                limbs_n, limbs2, elimbs, batch, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            self._use_plan(plan)
+            ws = self._workspace(self.lib.mx_powmod_nsquare_run_workspace_bytes(plan.desc, batch))
+            rc = self.lib.mx_powmod_nsquare_run(
+                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl, ws.data_ptr(), ws.numel(),
+                self._stream_ptr(),
             )
-        _lib.check(rc, "mx_powmod_nsquare")
+        _lib.check(rc, "mx_powmod_nsquare_run")
         return out_t
 
     def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int) -> List[int]:
@@ -292,22 +414,25 @@ class Engine:
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, g_t, n2, out_t=rn_t)))
 
     # ------------------------------------------------------------------ Jacobi symbol
-    def jacobi_t(self, values_t, mods: Sequence[int], group_size: int, out_t=None):
-        """int8 [groups*group_size]: Jacobi symbol (values[g*group_size+k] / mods[g]) (DK:1089)."""
+    def jacobi_t(self, values_t, mods, group_size: int, out_t=None):
+        """int8 [groups*group_size]: Jacobi symbol (values[g*group_size+k] / mods[g]) (DK:1089).
+        `mods`: sequence of ints or a device-resident (rows, max bits) pair."""
         count, limbs = values_t.shape
-        groups = len(mods)
+        if not (isinstance(mods, tuple) and hasattr(mods[0], "data_ptr")):
+            for m in mods:
+                if m < 1 or m % 2 == 0:
+                    raise ValueError("n should be an odd positive integer")
+        mods_t, _ = self._mods_operand(mods, limbs, odd_only=False)
+        groups = mods_t.shape[0]
         if count != groups * group_size:
             raise ValueError("values must hold groups*group_size rows")
-        h_mods = _limbs.pack(mods, limbs)
         if out_t is None:
             out_t = self.torch.empty(count, dtype=self.torch.int8, device=self.device)
         with self.torch.cuda.device(self.device):
-            ws = self._workspace(self.lib.mx_jacobi_workspace_bytes(limbs, groups))
-            rc = self.lib.mx_jacobi(
-                values_t.data_ptr(), out_t.data_ptr(), h_mods.ctypes.data, limbs, groups, group_size,
-                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            rc = self.lib.mx_jacobi_dev(
+                values_t.data_ptr(), out_t.data_ptr(), mods_t.data_ptr(), limbs, groups, group_size, self._stream_ptr()
             )
-        _lib.check(rc, "mx_jacobi")
+        _lib.check(rc, "mx_jacobi_dev")
         return out_t
 
     def jacobi_batch(self, values: Sequence[Sequence[int]], mods: Sequence[int]) -> List[List[int]]:
@@ -345,6 +470,19 @@ class Engine:
         _lib.check(rc, "mx_select_first")
         return out_t, cnt_t
 
+    def biprime_v_t(self, g_t, mods, exps, group_size: int, keep: int):
+        """Tensor-level v-calculation of DK:1084-1099 for many candidates, nothing leaving the device:
+        g_t int32 [groups*group_size, limbs] (the jointly random generators, reduced) -> (v rows int32
+        [groups*keep, limbs], counts int32 [groups]): Jacobi symbols of all generators, selection of the
+        first `keep` with symbol 1 (in order), v = g^exp mod N for those; rows beyond a candidate's count
+        are the modexp of a zero row and are ignored by the caller."""
+        limbs = g_t.shape[1]
+        mods_op = self._mods_operand(mods, limbs)
+        j_t = self.jacobi_t(g_t, mods_op, group_size)
+        sel_t, cnt_t = self.select_first_t(g_t, j_t, group_size, keep)
+        v_t = self.powmod_multi_t(sel_t, mods_op, exps, keep)
+        return v_t, cnt_t
+
     def biprime_v_batch(
         self, g_values: Sequence[Sequence[int]], exps: Sequence[int], mods: Sequence[int], keep: int
     ) -> List[List[int]]:
@@ -365,9 +503,7 @@ class Engine:
             flat.extend(_reduce(x, m) for x in gs)
             flat.extend([0] * (gsize - len(gs)))          # padding: symbol (0/N) = 0, never selected
         g_t = self.to_device(_limbs.pack(flat, limbs))
-        j_t = self.jacobi_t(g_t, list(mods), gsize)
-        sel_t, cnt_t = self.select_first_t(g_t, j_t, gsize, keep)
-        v_t = self.powmod_multi_t(sel_t, list(mods), list(exps), keep)
+        v_t, cnt_t = self.biprime_v_t(g_t, list(mods), list(exps), gsize, keep)
         counts = cnt_t.cpu().numpy()
         vals = _limbs.unpack(self.to_host(v_t))
         return [vals[g * keep : g * keep + int(counts[g])] for g in range(groups)]
@@ -402,30 +538,29 @@ class Engine:
         return [bool(x) for x in out.cpu().numpy()]
 
     # ------------------------------------------------------------------ share recombination
-    def combine_t(self, partials_t, n: int, theta_inv: int, out_t=None, status_t=None):
+    def combine_t(self, partials_t, n: int, theta_inv: int, out_t=None, status_t=None, packed: bool = False):
         """partials_t int32 [n_partials, batch, limbs2] (players 1..degree+1 in order) ->
-        (plaintext rows int32 [batch, limbs(N)], status uint8 [batch], 1 = not divisible by N)."""
+        (plaintext rows int32 [batch, limbs(N)], status uint8 [batch], 1 = not divisible by N).
+        With ``packed=True`` the result is ONE tensor [batch, limbs(N)+1] whose last word is the
+        status — plaintext and status as one row (one all-gather when ciphertexts are sharded)."""
         n_partials, batch, limbs2 = partials_t.shape
-        _check_modulus(n)
-        limbs = _limbs.limbs_for(n)
-        if _limbs.limbs_for(n * n) > limbs2:
-            raise ValueError("partial rows narrower than N^2")
-        if not 0 <= theta_inv < n:
-            raise ValueError("theta_inv must be a residue modulo N")
-        h_n = _limbs.pack_one(n, limbs)
-        h_t = _limbs.pack_one(theta_inv, limbs)
+        plan = self.combine_plan(n, theta_inv, limbs2)
+        limbs = plan.desc.limbs
+        stride = limbs + 1 if packed else limbs
         if out_t is None:
-            out_t = self.torch.empty((batch, limbs), dtype=self.torch.int32, device=self.device)
-        if status_t is None:
+            out_t = self.torch.empty((batch, stride), dtype=self.torch.int32, device=self.device)
+        if tuple(out_t.shape) != (batch, stride):
+            raise ValueError("output rows of the wrong shape")
+        if status_t is None and not packed:
             status_t = self.torch.empty(batch, dtype=self.torch.uint8, device=self.device)
         with self.torch.cuda.device(self.device):
-            ws = self._workspace(self.lib.mx_combine_workspace_bytes(limbs, limbs2, n_partials, batch))
-            rc = self.lib.mx_combine(
-                partials_t.data_ptr(), out_t.data_ptr(), status_t.data_ptr(), h_n.ctypes.data, h_t.ctypes.data,
-                limbs, limbs2, n_partials, batch, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            self._use_plan(plan)
+            rc = self.lib.mx_combine_run(
+                plan.desc, partials_t.data_ptr(), out_t.data_ptr(), stride,
+                status_t.data_ptr() if status_t is not None else None, n_partials, batch, self._stream_ptr(),
             )
-        _lib.check(rc, "mx_combine")
-        return out_t, status_t
+        _lib.check(rc, "mx_combine_run")
+        return out_t if packed else (out_t, status_t)
 
     def combine_batch(
         self, partials: Sequence[Sequence[int]], n: int, theta_inv: int
@@ -445,21 +580,22 @@ class Engine:
         return _limbs.unpack(self.to_host(out_t)), ok
 
     # ------------------------------------------------------------------ biprimality verdict
-    def biprime_verdict_t(self, v_t, mods: Sequence[int], pass_t=None):
-        """v_t int32 [n_parties, groups, n_slots, limbs] (party 1 first) -> uint8 [groups, n_slots]."""
+    def biprime_verdict_t(self, v_t, mods, pass_t=None):
+        """v_t int32 [n_parties, groups, n_slots, limbs] (party 1 first) -> uint8 [groups, n_slots].
+        `mods`: sequence of ints or a device-resident (rows, max bits) pair."""
         n_parties, groups, n_slots, limbs = v_t.shape
-        if len(mods) != groups:
+        mods_t, mod_bits = self._mods_operand(mods, limbs)
+        if mods_t.shape[0] != groups:
             raise ValueError("one modulus per group expected")
-        h_mods = _limbs.pack(mods, limbs)
         if pass_t is None:
             pass_t = self.torch.empty((groups, n_slots), dtype=self.torch.uint8, device=self.device)
         with self.torch.cuda.device(self.device):
             ws = self._workspace(self.lib.mx_verdict_workspace_bytes(limbs, n_parties, groups, n_slots))
-            rc = self.lib.mx_biprime_verdict(
-                v_t.data_ptr(), pass_t.data_ptr(), h_mods.ctypes.data, limbs, n_parties, groups, n_slots,
+            rc = self.lib.mx_biprime_verdict_dev(
+                v_t.data_ptr(), pass_t.data_ptr(), mods_t.data_ptr(), limbs, mod_bits, n_parties, groups, n_slots,
                 ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
-        _lib.check(rc, "mx_biprime_verdict")
+        _lib.check(rc, "mx_biprime_verdict_dev")
         return pass_t
 
     def biprime_verdict_batch(self, v: Sequence[Sequence[Sequence[int]]], mods: Sequence[int]) -> List[List[bool]]:

@@ -28,7 +28,7 @@ def _decrypt_all(eng, key, cts):
     for i in range(1, key.degree + 2):
         e = key.exponent(i)
         bases = cts if e >= 0 else eng.modinv_batch(cts, n2)
-        partials.append(eng.powmod_batch(bases, abs(e), n2))
+        partials.append(eng.powmod_nsquare_batch(bases, abs(e), key.n))     # the product's path (PSK:92)
     rows = [[partials[i][k] for i in range(key.degree + 1)] for k in range(len(cts))]
     msgs, ok = eng.combine_batch(rows, key.n, key.theta_inv)
     return partials, msgs, ok

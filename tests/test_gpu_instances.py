@@ -1,0 +1,141 @@
+"""GPU parity of every kernel instance the launchers can select (tests/instance_cases.py), bit-exact
+against CPython pow(), plus the key_length-4096 (configs[4]) product path at the batch sizes of its
+sweep with the automatically selected geometry asserted."""
+
+from __future__ import annotations
+
+import multiprocessing as mp
+import random
+
+import pytest
+
+import instance_cases as ic
+from conftest import unhex
+from oracle import oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def eng():
+    from protocols.distributed_keygen_amd import Engine
+
+    e = Engine()
+    yield e
+    e.set_limbs_per_lane(0)
+
+
+def _modulus(rng, bits):
+    return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+
+
+@pytest.mark.parametrize("case", ic.ALL_CASES, ids=lambda c: f"{c[0]}-{c[1]}b-L{c[2]}-x{c[3]}")
+def test_instance_parity(eng, case):
+    from protocols.distributed_keygen_amd import _lib
+
+    kind, bits, lpl, batch, ebits = case
+    rng = random.Random(hash(case) & 0xFFFFFF)
+    eng.set_limbs_per_lane(lpl)
+    inst = ic.case_instance(_lib.lib(), case)
+    assert inst is not None
+    if kind == "n2":
+        n = _modulus(rng, bits)
+        n2 = n * n
+        assert eng.nsquare_geometry(bits, batch)[:2] == inst[1:]
+        bases = [0, 1, n2 - 1, n, n + 1, n2 - n][: max(1, batch - 1)] + [rng.randrange(n2) for _ in range(batch)]
+        bases = bases[:batch]
+        for e in (rng.getrandbits(ebits) | (1 << (ebits - 1)) | 1, 2):
+            assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (case, e.bit_length())
+    elif kind == "shared":
+        mod = _modulus(rng, bits)
+        assert eng.geometry(bits, batch, 1)[:2] == inst[1:]
+        bases = ([0, 1, mod - 1] + [rng.randrange(mod) for _ in range(batch)])[:batch]
+        e = rng.getrandbits(ebits) | (1 << (ebits - 1)) | 1
+        assert eng.powmod_batch(bases, e, mod) == [pow(b, e, mod) for b in bases], case
+    else:
+        groups = 3
+        mods = [_modulus(rng, bits - g) for g in range(groups)]
+        assert eng.geometry(bits, batch * groups, groups)[:2] == inst[1:]
+        exps = [rng.getrandbits(ebits - g) for g in range(groups)]
+        rows = [([0, 1, m - 1] + [rng.randrange(m) for _ in range(batch)])[:batch] for m in mods]
+        assert eng.powmod_batch_multi(rows, exps, mods) == [[pow(b, e, m) for b in r] for r, e, m in zip(rows, exps, mods)]
+    eng.set_limbs_per_lane(0)
+
+
+def _special_moduli(bits):
+    m = [(1 << bits) - 1, (1 << bits) - 3, (1 << (bits - 1)) + 1, (1 << bits) - (1 << (bits // 2)) - 1]
+    return [x | 1 for x in m]
+
+
+@pytest.mark.parametrize("bits", [3075, 4099, 6003])
+def test_wide_pair_kernel_k8_k16_special_operands(eng, bits):
+    """powmod_n2_kernel<8,18,29> / <16,18,29> (what key_length 3072 / 4096 launches from batch 3840)
+    with the operands that stress the lazy-carry machinery: all-ones and sparse moduli, bases that
+    are multiples of N, all-ones limb patterns in radix 2^29 and 2^32."""
+    eng.set_limbs_per_lane(18)
+    rng = random.Random(bits)
+    assert eng.nsquare_geometry(bits, 16)[:2] == ((8, 18) if bits <= 4172 else (16, 18))
+    for n in _special_moduli(bits)[: 4 if bits < 5000 else 2]:
+        n2 = n * n
+        nb = n2.bit_length()
+        pat29 = sum(((1 << 29) - 1) << (29 * k) for k in range(0, nb // 29 + 1, 2)) % n2
+        pat32 = sum(0xFFFFFFFF << (32 * k) for k in range(0, nb // 32 + 1, 2)) % n2
+        bases = [0, 1, n - 1, n, n + 1, 2 * n, n * (n - 1), n2 - 1, n2 - n, (n2 - 1) // 2, pat29, pat32,
+                 (n2 - pat29) % n2, (n2 - pat32) % n2] + [rng.randrange(n2) for _ in range(4)]
+        for e in (0, 1, 2, 3, (1 << 130) - 1, rng.getrandbits(150) | 1):
+            assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (bits, e.bit_length())
+    eng.set_limbs_per_lane(0)
+
+
+@pytest.mark.parametrize("lpl", [9, 18])
+def test_golden_key4096_partial_decryptions_both_geometries(eng, golden_decrypt_synth, lpl):
+    """The reference-generated partial decryptions of the key_length-4096 key through the narrow
+    <16,9> AND the wide <8,18> pair kernel."""
+    grp = golden_decrypt_synth["k4096_n3_t1"]
+    n = unhex(grp["n"])
+    n2 = n * n
+    eng.set_limbs_per_lane(lpl)
+    assert eng.nsquare_geometry(n.bit_length(), 3)[:2] == ((16, 9) if lpl == 9 else (8, 18))
+    cs = [unhex(c["c"]) for c in grp["cases"]]
+    for i, share in grp["shares"].items():
+        exp = oracle.partial_decrypt_exponent(int(i), grp["degree"], unhex(grp["n_fac"]), unhex(share))
+        bases = cs if exp >= 0 else [oracle.mod_inv(c, n2) for c in cs]
+        assert eng.powmod_nsquare_batch(bases, abs(exp), n) == [unhex(c["partials"][i]) for c in grp["cases"]], i
+    eng.set_limbs_per_lane(0)
+
+
+def test_c5_sweep_point_batch4096_auto_geometry(eng):
+    """configs[4] at a batch size of its sweep: 4096 ciphertexts at key_length 4096 through the
+    product path with the library's own geometry choice — which must be the wide <8,18> instance —
+    96 samples bit-exact against pow() on the host cores, and the full threshold decryption
+    round trip decrypt(encrypt(m)) == m on all 4096."""
+    from protocols.distributed_keygen_amd import synthetic
+
+    key = synthetic.make_key(4096, 3, 1)
+    n, n2 = key.n, key.n_square
+    batch = 4096
+    eng.set_limbs_per_lane(0)
+    assert eng.nsquare_geometry(n.bit_length(), batch)[:2] == (8, 18)
+    rng = random.Random(40960)
+    msgs = [rng.randrange(n) for _ in range(batch)]
+    msgs[:3] = [0, 1, n - 1]
+    rs = [rng.randrange(1, n) for _ in range(batch)]
+    cts = eng.encrypt_batch(msgs, rs, n)                               # r^N through the same kernel
+    assert cts[5] == (1 + msgs[5] * n) * pow(rs[5], n, n2) % n2
+    partials = []
+    for i in range(1, key.degree + 2):
+        e = key.exponent(i)
+        bases = cts if e >= 0 else eng.modinv_batch(cts, n2)
+        partials.append(eng.powmod_nsquare_batch(bases, abs(e), n))
+    got, ok = eng.combine_batch([[partials[i][k] for i in range(key.degree + 1)] for k in range(batch)], n, key.theta_inv)
+    assert all(ok) and got == msgs
+    i_pos = next(i for i in (1, 2, 3) if key.exponent(i) >= 0)
+    idx = [0, 1, 2, batch - 1] + [(k * 7919) % batch for k in range(1, 93)]
+    with mp.Pool() as pool:
+        want = pool.starmap(pow, [(cts[k], key.exponent(i_pos), n2) for k in idx], chunksize=1)
+    assert [partials[i_pos - 1][k] for k in idx] == want
+    # the narrow instance on the same inputs agrees on every ciphertext
+    eng.set_limbs_per_lane(9)
+    assert eng.nsquare_geometry(n.bit_length(), batch)[:2] == (16, 9)
+    assert eng.powmod_nsquare_batch(cts, key.exponent(i_pos), n) == partials[i_pos - 1]
+    eng.set_limbs_per_lane(0)

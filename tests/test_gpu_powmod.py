@@ -205,3 +205,32 @@ def test_kernel_timing_hooks_and_concurrent_streams(eng):
     for out in outs:
         assert L.unpack(eng.to_host(out)) == want
     assert eng.profile_collect() == (0.0, 0)
+
+
+def test_one_engine_driven_from_several_streams(eng):
+    """one Engine used under several torch streams.  Each stream has its own
+    workspace inside the engine (the window tables of launches in flight must not overlap) and the
+    per-key plan prepared on one stream is ordered before its use on the others.  Eight launches with
+    different exponents / keys interleaved over four streams with no host synchronisation."""
+    import torch
+
+    from protocols.distributed_keygen_amd import limbs as L
+
+    rng = random.Random(777)
+    n = rng.getrandbits(1027) | (1 << 1026) | 1
+    n2 = n * n
+    exps = [rng.getrandbits(400) | 1 for _ in range(3)]
+    bases = [rng.randrange(n2) for _ in range(96)]
+    rows = eng.to_device(L.pack(bases, L.limbs_for(n2)))
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    torch.cuda.synchronize()
+    outs = []
+    for k in range(8):
+        with torch.cuda.stream(streams[k % 4]):
+            e = exps[k % 3]
+            out = eng.powmod_nsquare_t(rows, n, e) if k % 2 == 0 else eng.powmod_shared_t(rows, n2, e)
+            outs.append((e, out))
+    torch.cuda.synchronize()
+    assert len(eng._ws) >= 4
+    for e, out in outs:
+        assert L.unpack(eng.to_host(out)) == [pow(b, e, n2) for b in bases]
