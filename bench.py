@@ -1,18 +1,28 @@
 #!/usr/bin/env python3
 """Headline benchmark: modexps/sec (2048-bit N, mod N^2) — BASELINE.json's metric.
 
-Workload (BASELINE.json configs[2], SURVEY.md §8d "C3"): one 3-party threshold-Paillier key,
-key_length 2048, t = 1; a step = one party's pass over a batch of 10 000 ciphertexts:
-  partial decryption   c^exp_i mod N^2     (paillier_shared_key.py:92 looped at distributed_keygen.py:463-466)
-  share recombination  of the 3 partials   (paillier_shared_key.py:95-127 looped at distributed_keygen.py:510-515)
-Inputs (ciphertext rows, the other parties' partial rows) are resident in HBM before the timed
-region.  With N GPUs every rank processes its own 10 000-ciphertext batch (weak scaling, batches
-are independent) and the partial-decryption rows are all-gathered over RCCL, which is the only
-exchange step the path has.
+Workloads:
+  c3 (default, BASELINE.json configs[2])  one 3-party threshold-Paillier key, key_length 2048, t = 1; a
+      step = one party's pass over a batch of 10 000 ciphertexts:
+        partial decryption   c^exp_i mod N^2   (paillier_shared_key.py:92 looped at distributed_keygen.py:463-466)
+        share recombination  of the 3 partials (paillier_shared_key.py:95-127 looped at distributed_keygen.py:510-515)
+      With N GPUs every rank processes its own batch (weak scaling, batches are independent) and the
+      partial-decryption rows are all-gathered over RCCL — the only exchange step the path has.
+  biprime (configs[3])  5-party key_length 2048, t = 2: a step = one party's biprimality-test pass over
+      a batch of candidate moduli that survived the sieve: 160 Jacobi symbols, selection of the first
+      40 generators with symbol 1 and 40 modexps g^e mod N per candidate (distributed_keygen.py:1084-1099
+      looped at :1313-1329), then the verdict of every candidate from all parties' v values
+      (:1110-1175 looped at :1339-1360).  With N GPUs the candidates are sharded contiguously; the v
+      rows and the verdict bytes are all-gathered (the biprimality vote, :1331-1360).
+  c5 (configs[4])  c3 at key_length 4096 (8200-bit modulus), batch 4096.
 
   python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
 
-Prints ONE JSON line (rank 0).  `roofline` and `cpu_baseline` are described in DESIGN.md §6.
+Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0) whose `roofline`
+is the VALU instruction-issue roof (the path is integer-only: no MFMA, HBM three orders of
+magnitude away) with the HBM figures as a sub-block, plus `cpu_baseline` (the
+reference's gmpy2 engine on the host cores) and, on one GPU, the legs `single_batch`,
+`end_to_end`, `extra.biprime_k2048` and `extra.c5_k4096`.  DESIGN.md §6 defines every field.
 """
 
 from __future__ import annotations
@@ -20,6 +30,7 @@ from __future__ import annotations
 import argparse
 import json
 import os
+import random
 import subprocess
 import sys
 import tempfile
@@ -34,53 +45,47 @@ sys.path.insert(0, str(ROOT))
 # queues, 246-272 k with 8; tools/ab_queues.sh).  Must be set before the runtime initialises.
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
-HBM_PEAK_GBS = 8000.0            # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# measured on MI355X: v_mad_u64_u32, 8 waves/SIMD, 2.085 ns per wave-instruction per SIMD
-# (profiles/r01_ubench_valu_rates.txt)  ->  1024 SIMDs * 64 lanes / 2.085 ns
-VALU_MAC_PEAK = 1024 * 64 / 2.085e-9
-# HBM bytes per powmod launch of the default workload, from the rocprofv3 --pmc passes committed in
-# profiles/r01_bench_single_stream_{wide,narrow}_rocprof_summary.txt: (2 x FETCH_SIZE + WRITE_SIZE) KiB
-# (FETCH_SIZE counts half of wide coalesced reads on gfx950, MI355X guide).  It is the table of odd
-# powers (64 pairs per ciphertext, 72 slots in all): ~0.4-0.5 GB written and ~2.7 GB of coalesced
-# look-ups per 10 000 modexps.  Keyed by limbs per lane (narrow, wide geometry).
-MEASURED_TRAFFIC_DEFAULT = {9: (2 * 1320544 + 410039) * 1024, 18: (2 * 1414320 + 501583) * 1024}
-# VALU wave-instructions one powmod_n2_kernel launch of the default workload issues (SQ_INSTS_VALU of
-# the same profile), and the issue peak: 1024 SIMDs, one VALU instruction per 4 cycles at 2.4 GHz.
-MEASURED_VALU_INSTS_DEFAULT = {9: 2.2432e10, 18: 1.8393e10}     # by limbs per lane (narrow, wide geometry)
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4
+HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+# VALU issue: 1024 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD (16 lanes per cycle;
+# 157.3 TFLOP/s fp32 vector peak = that rate with packed FMA), 2.4 GHz.  Measured on this chip
+# (profiles/r01_ubench_valu_rates.txt): plain VALU 4.0-4.3 cycles, v_mad_u64_u32 4.5-5.0.
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4          # wave-instructions per second
+MAD_CYCLES, OTHER_CYCLES = 4.75, 4.15       # measured issue cost of v_mad_u64_u32 / of the other VALU instructions
+INSTR_MODEL = ROOT / "profiles" / "r02_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits)
+HBM_MEASURED = ROOT / "profiles" / "r02_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def parse() -> argparse.Namespace:
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     # 48 timed steps: with 4 steps in flight the last round drains a partly empty machine, which costs
-    # ~10 % of a 12-step run (267 k) and ~2 % of a 48-step one (292-300 k, the sustained rate)
+    # ~3 % of a 20-step run and ~1 % of a 48-step one
     ap.add_argument("--steps", type=int, default=48)
     ap.add_argument("--warmup", type=int, default=8)
-    ap.add_argument("--batch", type=int, default=10000, help="ciphertexts per step per GPU")
-    ap.add_argument("--key-length", type=int, default=2048)
+    ap.add_argument("--workload", choices=("c3", "biprime", "c5"), default="c3")
+    ap.add_argument("--batch", type=int, default=0,
+                    help="units per step per GPU: ciphertexts (c3: 10000, c5: 4096) or candidate moduli (biprime: 4096/N)")
+    ap.add_argument("--key-length", type=int, default=0, help="default 2048 (c3, biprime), 4096 (c5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the single_batch / end_to_end / extra legs")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
     ap.add_argument("--check", type=int, default=6, help="elements verified against CPython pow after timing")
     ap.add_argument("--streams", type=int, default=0,
-                    help="independent steps (10k-ciphertext batches) kept in flight, one HIP stream each; "
-                         "1 = strictly one batch at a time; 0 = automatic: the first of 4, 5, 6, 7, 8, 3 that "
-                         "divides --steps (every stream then runs the same number of steps), else 4")
+                    help="independent steps kept in flight, one HIP stream each; 1 = strictly one batch at a time; "
+                         "0 = automatic: the first of 4, 5, 6, 7, 8, 3 that divides --steps, else 4")
     ap.add_argument("--limbs-per-lane", type=int, default=-1,
-                    help="lane geometry 9|18, 0 = library heuristic; default: 18 (wide) when at least 4 steps "
-                         "are in flight and the modulus has >= 2048 bits")
+                    help="lane geometry 9|18, 0 = library heuristic; default: 18 (wide) when the launches in flight "
+                         "over-subscribe the wide geometry's 2048 wavefront slots")
     ap.add_argument("--generic-modulus", action="store_true",
-                    help="time mx_powmod_shared on the modulus N^2 instead of mx_powmod_nsquare (pairs modulo N)")
+                    help="c3/c5: time mx_powmod_shared on the modulus N^2 instead of the N-adic pair kernel")
     return ap.parse_args()
 
 
-def cpu_baseline(key, exp: int, ciphertexts, seconds: float) -> dict:
-    """Times the reference's CPU engine (gmpy2 -> libgmp) on all host cores, on a bounded sample."""
-    sample = ciphertexts[:64]
-    job = {
-        "mod": hex(key.n_square), "exp": hex(exp), "bases": [hex(c) for c in sample],
-        "nprocs": os.cpu_count() or 1, "seconds": seconds,
-    }
+# ---------------------------------------------------------------------------------------------------
+# CPU baseline: the reference's engine (gmpy2.powmod -> libgmp mpz_powm) on the host cores
+# ---------------------------------------------------------------------------------------------------
+def cpu_baseline(mod: int, exp: int, bases, seconds: float, what: str) -> dict:
+    job = {"mod": hex(mod), "exp": hex(exp), "bases": [hex(c) for c in bases], "nprocs": 0, "seconds": seconds}
     with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
         json.dump(job, f)
         path = f.name
@@ -97,14 +102,18 @@ def cpu_baseline(key, exp: int, ciphertexts, seconds: float) -> dict:
                     tried.append(f"{py}: no gmpy2")
                     continue
                 os.unlink(path)
+                ci = res["core_info"]
                 return {
                     "value": res["rate_all_cores"], "unit": "modexps/s", "cores": res["cores"],
-                    "kind": "reference",
-                    "engine": res["engine_desc"],
+                    "kind": "reference", "engine": res["engine_desc"],
                     "single_core_value": res["rate_single_core"],
-                    "sample": (f"{res['modexps_timed']} modexps in {res['wall_s']:.1f} s wall on {res['cores']} processes, "
-                               f"same modulus/exponent, first {len(sample)} ciphertexts of the batch cycled; engine = the "
-                               "routine the reference's pow_mod dispatches to (gmpy2.powmod -> libgmp mpz_powm)"),
+                    "parallel_efficiency": res["parallel_efficiency"],
+                    "effective_cores": res["rate_all_cores"] / res["rate_single_core"],
+                    "cores_basis": (f"processes = usable cores: sched_getaffinity {ci['affinity']}, cgroup quota "
+                                    f"{ci['cgroup_quota']}, os.cpu_count {ci['host_cpu_count']}"),
+                    "sample": (f"{res['modexps_timed']} modexps in {res['wall_s']:.1f} s wall on {res['cores']} processes; "
+                               f"{what}; engine = the routine the reference's pow_mod dispatches to "
+                               "(gmpy2.powmod -> libgmp mpz_powm)"),
                 }
             tried.append(f"{py}: rc={r.returncode} {r.stderr[-200:]}")
         except Exception as exc:  # pragma: no cover - measurement plumbing
@@ -113,6 +122,518 @@ def cpu_baseline(key, exp: int, ciphertexts, seconds: float) -> dict:
     return {"value": None, "unit": "modexps/s", "cores": 0, "kind": "reference", "sample": "failed: " + "; ".join(tried)}
 
 
+# ---------------------------------------------------------------------------------------------------
+# roofline helpers
+# ---------------------------------------------------------------------------------------------------
+def _load_json(path: Path):
+    try:
+        return json.loads(path.read_text())
+    except Exception:
+        return None
+
+
+def instr_per_wave(kind: str, L: int, nblk: int, n_sqr: int, n_mul: int):
+    """VALU wave-instructions one wavefront of a modexp launch executes (tools/calibrate_instr.py)."""
+    model = _load_json(INSTR_MODEL)
+    try:
+        i_sqr, i_mul, fixed = model[kind][str(L)][str(nblk)]
+    except Exception:
+        return None
+    return n_sqr * i_sqr + n_mul * i_mul + fixed
+
+
+def valu_roofline(kernel: str, instr_per_launch, launches: int, elapsed: float, kernel_ms: float, concurrent: int,
+                  mac_share=None) -> dict:
+    out = {
+        "bound": "valu-issue", "kernel": kernel, "unit": "G VALU wave-instructions/s",
+        "peak": VALU_ISSUE_PEAK / 1e9, "kernel_ms": kernel_ms, "concurrent_launches": concurrent,
+        "instructions_per_launch": instr_per_launch,
+        "instructions_basis": "n_waves x (n_sqr x I_sqr + n_mul x I_mul + F): squarings/multiplications from the "
+                              "exponent's tape, per-instance constants fitted to SQ_INSTS_VALU (profiles/r02_instr_model.json)",
+        "peak_basis": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, "
+                      "157.3 TFLOP/s fp32 vector); v_mad_u64_u32 itself issues at 4.5-5.0 cycles (profiles/r01_ubench_valu_rates.txt)",
+    }
+    if instr_per_launch is None:
+        out.update({"achieved": None, "frac": None})
+        return out
+    achieved = instr_per_launch * launches / elapsed
+    out["achieved"] = achieved / 1e9
+    out["frac"] = achieved / VALU_ISSUE_PEAK
+    if mac_share is not None:
+        # the same instruction stream priced with the measured issue cost of its two instruction classes
+        mix_cycles = mac_share * MAD_CYCLES + (1 - mac_share) * OTHER_CYCLES
+        out["mix_ceiling_frac"] = 4.0 / mix_cycles
+        out["mix_note"] = (f"{mac_share:.0%} of the stream is v_mad_u64_u32 ({MAD_CYCLES} cycles measured) and the rest "
+                           f"plain VALU ({OTHER_CYCLES}): no schedule of this instruction mix can exceed frac = 4/{mix_cycles:.2f}")
+    return out
+
+
+def hbm_block(alg_bytes: float, kernel_ms: float, traffic_model, traffic_key: str) -> dict:
+    achieved = alg_bytes / (kernel_ms * 1e-3) / 1e9
+    measured = (_load_json(HBM_MEASURED) or {}).get(traffic_key)
+    blk = {
+        "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+        "algorithmic_bytes_per_launch": alg_bytes,
+        "traffic": measured["bytes"] if measured else None,
+        "traffic_source": (measured["source"] if measured else
+                           f"no rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass committed for '{traffic_key}' (profiles/r02_hbm_traffic.json)"),
+        "traffic_model": traffic_model,
+        "traffic_model_basis": "window-table accesses of the tape x 2 x limbs_per_lane words x lanes, plus the I/O rows "
+                               "(an upper bound: L2 hits are not subtracted)",
+    }
+    t = blk["traffic"] or traffic_model
+    if t:
+        blk["traffic_over_algorithmic"] = t / alg_bytes
+        blk["traffic_GBs"] = t / (kernel_ms * 1e-3) / 1e9
+    return blk
+
+
+# ---------------------------------------------------------------------------------------------------
+# decryption workload (c3 / c5): partial decryption + share recombination
+# ---------------------------------------------------------------------------------------------------
+class DecryptWorkload:
+    """Inputs of one party's decryption pass, resident on the device."""
+
+    def __init__(self, eng, key_length: int, batch: int, rank: int, generic: bool):
+        import torch
+
+        from protocols.distributed_keygen_amd import limbs as L, synthetic
+
+        self.eng, self.torch, self.L = eng, torch, L
+        self.key = key = synthetic.make_key(key_length, 3, 1)
+        self.n, self.n2 = key.n, key.n_square
+        self.batch, self.generic = batch, generic
+        self.parties = list(range(1, key.degree + 2))
+        self.exps = {i: key.exponent(i) for i in self.parties}
+        self.own = next((i for i in self.parties if self.exps[i] >= 0), self.parties[0])
+        self.own_exp = abs(self.exps[self.own])
+        self.own_slot = self.parties.index(self.own)
+        self.limbs2 = L.limbs_for(self.n2)
+        self.limbs = L.limbs_for(self.n)
+        self.cts = synthetic.random_ciphertexts(key, batch, seed=synthetic.SEED + 17 * rank)
+        self.c_t = eng.to_device(L.pack(self.cts, self.limbs2))
+        # the other parties' partial decryptions, as they would arrive over the wire (untimed setup)
+        self.partials_t = torch.empty((len(self.parties), batch, self.limbs2), dtype=torch.int32, device=eng.device)
+        for k, i in enumerate(self.parties):
+            src = self.c_t if self.exps[i] >= 0 else eng.modinv_t(self.c_t, self.n2)     # PSK:89-91
+            eng.powmod_nsquare_t(src, self.n, abs(self.exps[i]), out_t=self.partials_t[k])
+        self.own_in_t = self.c_t if self.exps[self.own] >= 0 else eng.modinv_t(self.c_t, self.n2)
+        self.theta_inv = key.theta_inv
+        self.lanes = []
+
+    def make_lanes(self, nstreams: int, dist, world: int) -> None:
+        torch, eng = self.torch, self.eng
+        self.lanes = []
+        for k in range(nstreams):
+            self.lanes.append({
+                "stream": torch.cuda.current_stream() if nstreams == 1 else torch.cuda.Stream(),
+                "partials": self.partials_t if k == 0 else self.partials_t.clone(),
+                "msg": torch.empty((self.batch, self.limbs), dtype=torch.int32, device=eng.device),
+                "status": torch.empty(self.batch, dtype=torch.uint8, device=eng.device),
+                "gathered": torch.empty((world, self.batch, self.limbs2), dtype=torch.int32, device=eng.device) if dist is not None else None,
+            })
+        torch.cuda.synchronize()
+
+    def step(self, k: int, dist) -> None:
+        ln = self.lanes[k % len(self.lanes)]
+        eng = self.eng
+        with self.torch.cuda.stream(ln["stream"]):
+            if self.generic:
+                eng.powmod_shared_t(self.own_in_t, self.n2, self.own_exp, out_t=ln["partials"][self.own_slot])
+            else:
+                eng.powmod_nsquare_t(self.own_in_t, self.n, self.own_exp, out_t=ln["partials"][self.own_slot])
+            if dist is not None:
+                dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][self.own_slot].reshape(-1))
+            eng.combine_t(ln["partials"], self.n, self.theta_inv, out_t=ln["msg"], status_t=ln["status"])
+
+    def verify(self, check: int, rank: int, dist) -> str:
+        L, eng = self.L, self.eng
+        for ln in self.lanes:
+            assert int(ln["status"].sum().item()) == 0, "share recombination flagged ciphertexts as inconsistent"
+        if dist is not None:
+            assert self.torch.equal(self.lanes[0]["gathered"][rank], self.partials_t[self.own_slot]), "all-gather shard mismatch"
+        if check <= 0:
+            return "skipped"
+        # spot check with CPython big-int arithmetic (the definition of the reference's pow_mod /
+        # PaillierSharedKey.decrypt, paillier_shared_key.py:92 and :115-125)
+        batch, n, n2 = self.batch, self.n, self.n2
+        idx = [0, batch - 1] + [(k * 7919) % batch for k in range(1, max(1, check - 1))]
+        rows = eng.to_host(self.partials_t[self.own_slot][idx])
+        msgs = L.unpack(eng.to_host(self.lanes[0]["msg"][idx]))
+        allp = [L.unpack(eng.to_host(self.partials_t[k][idx])) for k in range(len(self.parties))]
+        for j, e in enumerate(idx):
+            base = self.cts[e] if self.exps[self.own] >= 0 else pow(self.cts[e], -1, n2)
+            assert L.unpack(rows[j : j + 1])[0] == pow(base, self.own_exp, n2), f"partial decryption {e} differs from pow()"
+            x = 1
+            for k in range(len(self.parties)):
+                x = x * allp[k][j] % n2
+            assert (x - 1) % n == 0 and msgs[j] == (x - 1) // n * self.theta_inv % n, f"plaintext {e} differs"
+        return f"{len(idx)} elements bit-exact vs CPython pow; all {batch} combines divisible by N"
+
+
+def pick_decrypt_geometry(args, key_length: int, batch: int, nstreams: int) -> int:
+    if args.limbs_per_lane >= 0:
+        return args.limbs_per_lane
+    if args.generic_modulus:
+        return 18 if nstreams >= 3 else 0
+    wide_lanes = 1
+    while wide_lanes * 29 * 18 < key_length + 8:
+        wide_lanes *= 2
+    wide_waves_in_flight = nstreams * batch * wide_lanes // 64
+    return 18 if (nstreams >= 4 and key_length >= 2048 and wide_waves_in_flight >= 2048) else 0
+
+
+def time_steps(eng, torch, dist, step_fn, steps: int, warmup: int, nstreams: int):
+    """W warm-up steps, then EXACTLY `steps` timed steps bracketed by barrier + device synchronisation;
+    returns (elapsed seconds [max over ranks], mean modexp-kernel ms, kernel launches)."""
+
+    def barrier() -> None:
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # one untimed pass per lane allocates that lane's workspace, so that no allocation (a device
+    # synchronisation) can fall into the timed region even when --warmup < steps in flight
+    for k in range(nstreams):
+        step_fn(k)
+    barrier()
+    for k in range(warmup):
+        step_fn(k)
+    barrier()
+    # HIP events around the modexp kernel itself, recorded by the library on the stream it launches
+    # on (mx_profile): the same interval rocprofv3 --kernel-trace reports for that kernel
+    eng.profile(True)
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step_fn(k)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    eng.profile(False)
+    kernel_total_ms, launches = eng.profile_collect()
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed, (kernel_total_ms / launches if launches else 0.0), launches
+
+
+def decrypt_roofline(eng, wl: DecryptWorkload, steps: int, elapsed: float, kernel_ms: float, nstreams: int, key_length: int) -> dict:
+    n_bits, batch = wl.n.bit_length(), wl.batch
+    if wl.generic:
+        K, Lw, _, nblk = eng.geometry(wl.n2.bit_length(), batch, 1)
+        name = f"mx::powmod_kernel<{K},{Lw},29,true>"
+        roof = valu_roofline(name, None, steps, elapsed, kernel_ms, nstreams)
+        roof["instructions_basis"] = "no model for the sliding-window generic kernel (not the product path)"
+        traffic_model = None
+    else:
+        K, Lw, _, nblk = eng.nsquare_geometry(n_bits, batch)
+        name = f"mx::powmod_n2_kernel<{K},{Lw},29>"
+        plan = eng.nsquare_plan(wl.n, wl.own_exp).desc
+        nwaves = -(-batch // (64 // K))
+        per_wave = instr_per_wave("n2", Lw, nblk, plan.n_sqr, plan.n_mul)
+        # multiply-accumulates of the stream: a pair squaring is a symmetric pass (L/2+1 product + L
+        # reduction MACs per limb step) + a full pass (L + L); a pair multiplication a full pass + a
+        # two-row pass (2L + L); nblk * L limb steps per pass
+        steps_per_pass = nblk * Lw
+        macs = plan.n_sqr * steps_per_pass * ((Lw // 2 + 1 + Lw) + 2 * Lw) + plan.n_mul * steps_per_pass * (2 * Lw + 3 * Lw)
+        roof = valu_roofline(name, None if per_wave is None else per_wave * nwaves, steps, elapsed, kernel_ms, nstreams,
+                             mac_share=None if per_wave is None else macs / per_wave)
+        roof["tape"] = {"pair_squarings": plan.n_sqr, "pair_multiplications": plan.n_mul, "window": plan.window}
+        traffic_model = nwaves * 64 * 4 * 2 * Lw * (plan.n_slot_reads + plan.n_slot_writes) + 2 * batch * 4 * wl.limbs2
+    e_bits = wl.own_exp.bit_length()
+    alg_bytes = batch * (2 * 4 * wl.limbs2) + 4 * wl.limbs2 + (e_bits + 7) // 8
+    roof["traffic"] = None
+    roof["hbm"] = hbm_block(alg_bytes, kernel_ms, traffic_model, f"n2_k{key_length}_b{batch}_L{Lw}" if not wl.generic else "generic")
+    roof["traffic"] = roof["hbm"]["traffic"]
+    roof["hbm"]["note"] = ("bytes of ONE launch over its own duration; the path is integer-VALU bound (north_star: no MFMA) and "
+                           "the window table of odd powers lives in HBM on purpose: its traffic is ~1 % of the HBM roof")
+    return roof
+
+
+def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: int, batch: int, label: str) -> dict:
+    nstreams = args.streams if args.streams > 0 else next(
+        (d for d in (4, 5, 6, 7, 8, 3) if args.steps % d == 0), min(4, max(1, args.steps)))
+    eng.set_limbs_per_lane(pick_decrypt_geometry(args, key_length, batch, nstreams))
+    wl = DecryptWorkload(eng, key_length, batch, rank, args.generic_modulus)
+    wl.make_lanes(nstreams, dist, world)
+    elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), args.steps, args.warmup, nstreams)
+    assert launches == args.steps, (launches, args.steps)
+    note = wl.verify(args.check if rank == 0 else 0, rank, dist)
+    if rank != 0:
+        return {}
+    geo = eng.geometry(wl.n2.bit_length(), batch, 1) if args.generic_modulus else eng.nsquare_geometry(wl.n.bit_length(), batch)
+    out = {
+        "metric": "modexps/sec (2048-bit N, mod N^2)" if key_length == 2048 else f"modexps/sec ({key_length}-bit N, mod N^2)",
+        "value": world * batch * args.steps / elapsed,
+        "unit": "modexps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": f"{label}: 3-party key_length={key_length} t=1, {batch} ciphertexts/GPU/step: "
+                        "partial-decrypt c^exp mod N^2 + share-combine",
+            "batch_per_gpu": batch, "mod_bits": wl.n2.bit_length(), "exp_bits": wl.own_exp.bit_length(),
+            "limbs_u32": wl.limbs2, "party": wl.own, "parallelism": f"dp{world}", "steps_in_flight": nstreams,
+            "geometry_K_L_W_blocks": list(geo),
+            "algorithm": "Montgomery modulo N^2" if args.generic_modulus else "N-adic pairs, two Montgomery passes modulo N per product",
+            "call_path": "per-key plan (mx_powmod_nsquare_prepare once) + mx_powmod_nsquare_run + mx_combine_run per step",
+            "verified": note,
+        },
+        "roofline": decrypt_roofline(eng, wl, args.steps, elapsed, kernel_ms, nstreams, key_length),
+    }
+    out["_wl"] = wl
+    return out
+
+
+def leg_single_batch(eng, torch, wl: DecryptWorkload, key_length: int) -> dict:
+    """The same step with ONE launch in flight (what a caller without its own streams gets)."""
+    saved = eng._lpl
+    eng.set_limbs_per_lane(0)
+    wl.make_lanes(1, None, 1)
+    steps = 6
+    elapsed, kernel_ms, _ = time_steps(eng, torch, None, lambda k: wl.step(k, None), steps, 1, 1)
+    geo = eng.nsquare_geometry(wl.n.bit_length(), wl.batch)
+    eng.set_limbs_per_lane(saved)
+    return {"value": wl.batch * steps / elapsed, "unit": "modexps/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
+            "kernel_ms": kernel_ms, "geometry_K_L_W_blocks": list(geo),
+            "note": f"one {wl.batch}-ciphertext launch at a time: {-(-wl.batch // (64 // geo[0]))} wavefronts for 1024 SIMDs"}
+
+
+def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
+    """Python ints in -> Python ints out through the drop-in classes: GpuPaillierSharedKey
+    .partial_decrypt_batch (pack, H2D, modexp, D2H, unpack) and .decrypt_batch (the same around the
+    recombination) — the loops distributed_keygen.py:463-466 and :510-515 as the patch runs them,
+    for one batch and for a 4x longer sequence (which the engine cuts into chunks on several streams)."""
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+
+    key, L = wl.key, wl.L
+    share = ShareView(dict(key.shares), key.degree, key.n_fac)
+    gk = GpuPaillierSharedKey(key.n, key.t, wl.own, share, key.theta, engine=eng)
+    saved = eng._lpl
+    eng.set_limbs_per_lane(0)
+    others1 = {i: L.unpack(eng.to_host(wl.partials_t[k])) for k, i in enumerate(wl.parties) if i != wl.own}
+    out = {"unit": "ciphertexts/s, Python ints to Python ints",
+           "note": "one call each on the default stream; includes Python int <-> limb rows (C codec), PCIe both ways, "
+                   "ciphertext.get_value() per element and the reference's type/key checks"}
+    for mult in (1, 4):
+        count = wl.batch * mult
+        others = {i: v * mult for i, v in others1.items()}
+        res, tm = {}, None
+        for rep in range(2):                                # the first pass warms allocations and pinned buffers
+            cts = [PlainCiphertext(c, key.n) for c in wl.cts * mult]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            partials = gk.partial_decrypt_batch(cts)
+            t1 = time.perf_counter()
+            tm = eng.last_timing
+            dicts = [{wl.own: p, **{i: others[i][k] for i in others}} for k, p in enumerate(partials)]
+            t2 = time.perf_counter()
+            msgs = gk.decrypt_batch(dicts)
+            t3 = time.perf_counter()
+            res = {"partial_decrypt_s": t1 - t0, "combine_s": t3 - t2}
+        k = 7
+        x = 1
+        for i in wl.parties:
+            x = x * (partials[k] if i == wl.own else others[i][k]) % wl.n2
+        assert msgs[k] == (x - 1) // wl.n * wl.theta_inv % wl.n and len(msgs) == count
+        out[f"n{count}"] = {
+            "partial_decrypt_rate": count / res["partial_decrypt_s"],
+            "partial_decrypt_vs_tensor_level": count / res["partial_decrypt_s"] / tensor_rate,
+            "combine_rate": count / res["combine_s"],
+            "both_rate": count / (res["partial_decrypt_s"] + res["combine_s"]),
+            "partial_decrypt_breakdown": {k2: (round(v, 5) if isinstance(v, float) else v) for k2, v in (tm or {}).items()},
+        }
+    out["value"] = out[f"n{wl.batch * 4}"]["partial_decrypt_rate"]
+    eng.set_limbs_per_lane(saved)
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
+# biprimality-test workload (configs[3]; configs[1] with --key-length 1024)
+# ---------------------------------------------------------------------------------------------------
+class BiprimeWorkload:
+    """`cands` candidate moduli of the distributed_keygen.py:855-876 shape that pass the small-prime
+    sieve, 160 jointly random generators each, this party's exponent per candidate; all on the device."""
+
+    GENS, KEEP = 160, 40          # 4 x correct_param_biprime generators (DK:1028), 40 tests (DK:1086)
+
+    def __init__(self, eng, key_length: int, n_parties: int, cands: int, seed: int, index: int = 1):
+        import sympy
+        import torch
+
+        from protocols.distributed_keygen_amd import limbs as L, synthetic
+
+        self.eng, self.torch, self.L = eng, torch, L
+        rng = random.Random(seed)
+        half = key_length // 2
+        self.primes = [int(p) for p in sympy.primerange(3, 2001)]          # prime_threshold 2000 (DK:85)
+        self.shares, self.mods = [], []
+        self.sieved = 0
+        while len(self.mods) < cands:                                     # survivors of DK:1288-1292
+            cand = [synthetic.candidate_shares(rng, n_parties, half) for _ in range(max(256, cands * 4))]
+            cm = [sum(p) * sum(q) for p, q in cand]
+            bad = eng.sieve_batch(cm, self.primes)
+            self.sieved += len(cm)
+            for sh, m, b in zip(cand, cm, bad):
+                if not b and len(self.mods) < cands:
+                    self.shares.append(sh)
+                    self.mods.append(m)
+        self.cands, self.n_parties, self.index = cands, n_parties, index
+        self.mod_bits = max(m.bit_length() for m in self.mods)
+        self.limbs = L.limbs_for_bits(self.mod_bits)
+        self.exps_by_party = {
+            i: [((m - p[0] - q[0] + 1) // 4) if i == 1 else ((p[i - 1] + q[i - 1]) // 4) for m, (p, q) in zip(self.mods, self.shares)]
+            for i in range(1, n_parties + 1)
+        }
+        self.exps = self.exps_by_party[index]
+        self.exp_bits = max(e.bit_length() for e in self.exps)
+        nb = (self.mod_bits + 7) // 8 + 8
+        g_all = [int.from_bytes(rng.randbytes(nb), "little") % m for m in self.mods for _ in range(self.GENS)]
+        self.g_sample = g_all[: self.GENS]
+        self.g_t = eng.to_device(L.pack(g_all, self.limbs))
+        self.mods_op = (eng.to_device(L.pack(self.mods, self.limbs)), self.mod_bits)
+        self.exps_op = (eng.to_device(L.pack(self.exps, L.limbs_for_bits(self.exp_bits))), self.exp_bits)
+        # the other parties' v rows, as they would arrive (untimed): same generators, their exponents
+        self.v_all = torch.zeros((n_parties, cands, self.KEEP, self.limbs), dtype=torch.int32, device=eng.device)
+        for i in range(1, n_parties + 1):
+            ex = self.exps_by_party[i]
+            ex_op = (eng.to_device(L.pack(ex, L.limbs_for_bits(max(e.bit_length() for e in ex)))), max(e.bit_length() for e in ex))
+            v_t, cnt_t = eng.biprime_v_t(self.g_t, self.mods_op, ex_op, self.GENS, self.KEEP)
+            self.v_all[i - 1] = v_t.view(cands, self.KEEP, self.limbs)
+            if i == index:
+                self.counts = cnt_t.clone()
+        self.lanes = []
+
+    def make_lanes(self, nstreams: int, dist, world: int) -> None:
+        torch, eng = self.torch, self.eng
+        self.lanes = []
+        for k in range(nstreams):
+            self.lanes.append({
+                "stream": torch.cuda.current_stream() if nstreams == 1 else torch.cuda.Stream(),
+                "v_all": self.v_all if k == 0 else self.v_all.clone(),
+                "verdict": torch.empty((self.cands, self.KEEP), dtype=torch.uint8, device=eng.device),
+                "v_gather": torch.empty((world, self.cands * self.KEEP, self.limbs), dtype=torch.int32, device=eng.device) if dist is not None else None,
+                "vote_gather": torch.empty((world, self.cands, self.KEEP), dtype=torch.uint8, device=eng.device) if dist is not None else None,
+            })
+        torch.cuda.synchronize()
+
+    def step(self, k: int, dist) -> None:
+        ln = self.lanes[k % len(self.lanes)]
+        eng = self.eng
+        with self.torch.cuda.stream(ln["stream"]):
+            # DK:1084-1099 over this rank's candidates: Jacobi filter -> first 40 -> 40 modexps each
+            v_t, _ = eng.biprime_v_t(self.g_t, self.mods_op, self.exps_op, self.GENS, self.KEEP)
+            ln["v_all"][self.index - 1].view(-1, self.limbs).copy_(v_t)
+            if dist is not None:                                          # v rows to every rank (DK:1331-1337)
+                dist.all_gather_into_tensor(ln["v_gather"].view(-1), v_t.reshape(-1))
+            # DK:1147-1158 for every (candidate, test slot) of this rank's candidates
+            eng.biprime_verdict_t(ln["v_all"], self.mods_op, pass_t=ln["verdict"])
+            if dist is not None:                                          # the vote: verdict bytes of all ranks
+                dist.all_gather_into_tensor(ln["vote_gather"].view(-1), ln["verdict"].reshape(-1))
+
+    def verify(self, check: int) -> str:
+        import sympy
+
+        L, eng = self.L, self.eng
+        v_rows = L.unpack(eng.to_host(self.lanes[0]["v_all"][self.index - 1][0]))
+        m, e = self.mods[0], self.exps[0]
+        keep = [g for g in self.g_sample if sympy.jacobi_symbol(g, m) == 1][: self.KEEP]
+        assert v_rows[: len(keep)] == [pow(g, e, m) for g in keep], "v values differ from pow()"
+        assert int(self.counts[0].item()) == len(keep)
+        # composites fail a slot almost surely; the verdict bytes must equal the host computation for candidate 0
+        want = []
+        allv = [L.unpack(eng.to_host(self.lanes[0]["v_all"][i][0])) for i in range(self.n_parties)]
+        for s in range(self.KEEP):
+            prod = 1
+            for i in range(1, self.n_parties):
+                prod *= allv[i][s]
+            want.append(1 if (allv[0][s] % m == prod % m or allv[0][s] % m == (-prod) % m) else 0)
+        got = [int(x) for x in self.lanes[0]["verdict"][0].cpu().numpy()]
+        assert got == want, "verdict bytes differ from DK:1147-1158 on the host"
+        return f"candidate 0: {len(keep)} v values bit-exact vs CPython pow, Jacobi selection vs sympy, {self.KEEP} verdict bytes vs host"
+
+
+def biprime_roofline(eng, wl: BiprimeWorkload, steps: int, elapsed: float, kernel_ms: float, nstreams: int) -> dict:
+    from tools.calibrate_instr import generic_counts
+
+    batch = wl.cands * wl.KEEP
+    K, Lw, _, nblk = eng.geometry(wl.mod_bits, batch, wl.cands)
+    elimbs = wl.exps_op[0].shape[1]
+    n_sqr, n_mul = generic_counts(wl.exp_bits, elimbs)
+    per_wave = instr_per_wave("generic", Lw, nblk, n_sqr, n_mul)
+    nwaves = -(-batch // (64 // K))
+    steps_per_pass = nblk * Lw
+    macs = n_sqr * steps_per_pass * (Lw // 2 + 1 + Lw) + n_mul * steps_per_pass * 2 * Lw
+    roof = valu_roofline(f"mx::powmod_kernel<{K},{Lw},29,false>", None if per_wave is None else per_wave * nwaves, steps,
+                         elapsed, kernel_ms, nstreams, mac_share=None if per_wave is None else macs / per_wave)
+    roof["exponentiation"] = {"squarings": n_sqr, "multiplications": n_mul, "fixed_window": True}
+    s = wl.limbs
+    alg_bytes = batch * 2 * 4 * s + wl.cands * 4 * (s + elimbs)
+    # window table: 2^win entries written once, one entry read per exponent digit (= n_mul + 3 accesses), L words per lane
+    traffic_model = nwaves * 64 * 4 * Lw * (n_mul + 3) + 2 * batch * 4 * s
+    roof["hbm"] = hbm_block(alg_bytes, kernel_ms, traffic_model, f"biprime_b{wl.mod_bits}_c{wl.cands}_L{Lw}")
+    roof["traffic"] = roof["hbm"]["traffic"]
+    return roof
+
+
+def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, total_cands: int, steps: int, warmup: int,
+                nstreams: int, n_parties: int = 5) -> dict:
+    cands = -(-total_cands // world)
+    eng.set_limbs_per_lane(args.limbs_per_lane if args.limbs_per_lane >= 0 else 0)
+    wl = BiprimeWorkload(eng, key_length, n_parties, cands, seed=0xD15C0 + 3 + 101 * rank)
+    wl.make_lanes(nstreams, dist, world)
+    elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), steps, warmup, nstreams)
+    assert launches == steps
+    note = wl.verify(args.check) if rank == 0 else ""
+    if dist is not None:
+        assert torch.equal(wl.lanes[0]["vote_gather"][rank], wl.lanes[0]["verdict"]), "vote all-gather shard mismatch"
+    if rank != 0:
+        return {}
+    geo = eng.geometry(wl.mod_bits, cands * wl.KEEP, cands)
+    # the stages on their own (one launch each, untimed region above excluded)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    j_t = eng.jacobi_t(wl.g_t, wl.mods_op, wl.GENS)
+    torch.cuda.synchronize()
+    jac_s = time.perf_counter() - t0
+    big = eng.to_device(wl.L.pack((wl.mods * (65536 // len(wl.mods) + 1))[:65536], wl.limbs))
+    eng.sieve_t(big, wl.primes)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    eng.sieve_t(big, wl.primes)
+    torch.cuda.synchronize()
+    sieve_s = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    eng.biprime_verdict_t(wl.lanes[0]["v_all"], wl.mods_op)
+    torch.cuda.synchronize()
+    verdict_s = time.perf_counter() - t0
+    del j_t, big
+    return {
+        "metric": f"biprimality-test modexps/sec ({key_length}-bit N)",
+        "value": world * cands * wl.KEEP * steps / elapsed,
+        "unit": "modexps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
+        "ms_per_step": elapsed / steps * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "config": {
+            "workload": f"C4: {n_parties}-party key_length={key_length} t=2, {total_cands} sieve-surviving candidate moduli "
+                        f"sharded over {world} GPU(s) ({cands}/GPU/step): 160 Jacobi symbols + first-40 selection + 40 modexps "
+                        "g^e mod N per candidate (party 1's exponent (N-p1-q1+1)/4), verdict of all parties' v values"
+                        + ("; all-gather of v rows and verdict bytes" if dist is not None else ""),
+            "candidates_per_gpu": cands, "mod_bits": wl.mod_bits, "exp_bits": wl.exp_bits, "limbs_u32": wl.limbs,
+            "parallelism": f"dp{world}", "steps_in_flight": nstreams, "geometry_K_L_W_blocks": list(geo),
+            "verified": note,
+        },
+        "stages": {
+            "jacobi_symbols_per_s": cands * wl.GENS / jac_s, "jacobi_ms": jac_s * 1e3,
+            "sieve_candidates_per_s": 65536 / sieve_s, "sieve_ms_65536": sieve_s * 1e3, "sieve_primes": len(wl.primes),
+            "verdict_slots_per_s": cands * wl.KEEP / verdict_s, "verdict_ms": verdict_s * 1e3,
+            "sieve_survival": cands / wl.sieved,
+        },
+        "roofline": biprime_roofline(eng, wl, steps, elapsed, kernel_ms, nstreams),
+        "_wl": wl,
+    }
+
+
+# ---------------------------------------------------------------------------------------------------
 def main() -> None:
     args = parse()
     # stdout carries exactly ONE line, the JSON result.  Libraries write banners to the C-level stdout
@@ -122,7 +643,6 @@ def main() -> None:
     sys.stdout.flush()
     result_fd = os.dup(1)
     os.dup2(2, 1)
-    import numpy as np
     import torch
 
     rank = int(os.environ.get("RANK", "0"))
@@ -165,191 +685,73 @@ def main() -> None:
             _build.build(force=False)
         if dist is not None:
             dist.barrier()
-    from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
+    from protocols.distributed_keygen_amd import Engine
 
     eng = Engine(local_rank)
-    if args.streams <= 0:
-        args.streams = next((d for d in (4, 5, 6, 7, 8, 3) if args.steps % d == 0), min(4, max(1, args.steps)))
-    # Lane geometry (mx_set_limbs_per_lane, part of the C ABI): the wide geometry issues 18 % fewer
-    # instructions per modexp; it is selected when the launches in flight together over-subscribe its
-    # 2048 wavefront slots, otherwise the library's per-launch heuristic decides.
-    if args.limbs_per_lane >= 0:
-        lpl = args.limbs_per_lane
-    elif args.generic_modulus:
-        lpl = 18 if args.streams >= 3 else 0
-    else:
-        wide_lanes = 1
-        while wide_lanes * 29 * 18 < args.key_length + 8:
-            wide_lanes *= 2
-        wide_waves_in_flight = args.streams * args.batch * wide_lanes // 64
-        lpl = 18 if (args.streams >= 4 and args.key_length >= 2048 and wide_waves_in_flight >= 2048) else 0
-    eng.set_limbs_per_lane(lpl)
-    key = synthetic.make_key(args.key_length, 3, 1)
-    n, n2 = key.n, key.n_square
-    parties = list(range(1, key.degree + 2))
-    exps = {i: key.exponent(i) for i in parties}
-    own = next((i for i in parties if exps[i] >= 0), parties[0])
-    batch = args.batch
-    limbs2 = L.limbs_for(n2)
-    cts = synthetic.random_ciphertexts(key, batch, seed=synthetic.SEED + 17 * rank)
-    c_t = eng.to_device(L.pack(cts, limbs2))
-
-    # ---- setup (untimed): the other parties' partial decryptions, as they would arrive over the wire
-    nstreams = max(1, args.streams)
-    partials_t = torch.empty((len(parties), batch, limbs2), dtype=torch.int32, device=eng.device)
-    for k, i in enumerate(parties):
-        eng.powmod_shared_t(c_t, n2, abs(exps[i]), out_t=partials_t[k])
-        if exps[i] < 0:  # paillier_shared_key.py:89-91 — c^-|e| = (c^|e|)^-1, inverted on the host here
-            vals = L.unpack(eng.to_host(partials_t[k]))
-            partials_t[k].copy_(eng.to_device(L.pack([pow(v, -1, n2) for v in vals], limbs2)))
-    own_exp = abs(exps[own])
-    own_in_t = c_t
-    if exps[own] < 0:
-        own_in_t = eng.to_device(L.pack([pow(c, -1, n2) for c in cts], limbs2))
-    own_slot = parties.index(own)
-    theta_inv = key.theta_inv
-    # one set of buffers (and one engine workspace) per in-flight step
-    lanes = []
-    for k in range(nstreams):
-        lanes.append({
-            "eng": eng,          # one engine: its workspace is per stream, the per-key plans are shared
-            "stream": torch.cuda.current_stream() if nstreams == 1 else torch.cuda.Stream(),
-            "partials": partials_t if k == 0 else partials_t.clone(),
-            "msg": torch.empty((batch, L.limbs_for(n)), dtype=torch.int32, device=eng.device),
-            "status": torch.empty(batch, dtype=torch.uint8, device=eng.device),
-            "gathered": torch.empty((world, batch, limbs2), dtype=torch.int32, device=eng.device) if dist is not None else None,
-        })
-    torch.cuda.synchronize()
-    msg_t, status_t, gathered = lanes[0]["msg"], lanes[0]["status"], lanes[0]["gathered"]
-
-    def step(timed: bool, k: int = 0) -> None:
-        ln = lanes[k % nstreams]
-        with torch.cuda.stream(ln["stream"]):
-            if args.generic_modulus:
-                ln["eng"].powmod_shared_t(own_in_t, n2, own_exp, out_t=ln["partials"][own_slot])
+    extras = world == 1 and not args.no_extras and not args.generic_modulus
+    if args.workload in ("c3", "c5"):
+        key_length = args.key_length or (2048 if args.workload == "c3" else 4096)
+        batch = args.batch or (10000 if args.workload == "c3" else 4096)
+        label = "C3 (BASELINE.json configs[2])" if args.workload == "c3" else "C5 (BASELINE.json configs[4])"
+        out = run_decrypt_main(args, eng, torch, dist, rank, world, key_length, batch, label)
+        if rank == 0:
+            wl = out.pop("_wl")
+            if world == 1 and not args.no_cpu_baseline:
+                bases = [c if wl.exps[wl.own] >= 0 else pow(c, -1, wl.n2) for c in wl.cts[:64]]
+                out["cpu_baseline"] = cpu_baseline(wl.n2, wl.own_exp, bases, args.cpu_seconds,
+                                                   "same modulus/exponent, first 64 ciphertexts of the batch cycled")
             else:
-                ln["eng"].powmod_nsquare_t(own_in_t, n, own_exp, out_t=ln["partials"][own_slot])
-            if dist is not None:
-                dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][own_slot].reshape(-1))
-            ln["eng"].combine_t(ln["partials"], n, theta_inv, out_t=ln["msg"], status_t=ln["status"])
-
-    def barrier() -> None:
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    # setup (untimed): one pass per lane allocates that lane's workspace and output buffers, so that no
-    # allocation (a device synchronisation) can fall into the timed region even when --warmup is
-    # smaller than the number of steps in flight; then the W warm-up steps proper
-    for k in range(nstreams):
-        step(False, k)
-    barrier()
-    for k in range(args.warmup):
-        step(False, k)
-    barrier()
-    # HIP events around the modexp kernel itself, recorded by the library on the stream it launches
-    # on (mx_profile): the same interval rocprofv3 --kernel-trace reports for that kernel
-    eng.profile(True)
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        step(True, k)
-    barrier()
-    elapsed = time.perf_counter() - t0
-    eng.profile(False)
-    kernel_total_ms, kernel_launches = eng.profile_collect()
-    assert kernel_launches == args.steps, (kernel_launches, args.steps)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    powmod_ms = kernel_total_ms / kernel_launches
-
-    # ---- verification (outside the timed region)
-    for ln in lanes:
-        assert int(ln["status"].sum().item()) == 0, "share recombination flagged ciphertexts as inconsistent"
-    if dist is not None:
-        assert torch.equal(gathered[rank], partials_t[own_slot]), "all-gather shard mismatch"
-    check_note = "skipped"
-    if rank == 0 and args.check > 0:
-        # spot check with CPython big-int arithmetic (the definition of the reference's pow_mod /
-        # PaillierSharedKey.decrypt, paillier_shared_key.py:92 and :115-125)
-        idx = [0, batch - 1] + [(k * 7919) % batch for k in range(1, max(1, args.check - 1))]
-        rows = eng.to_host(partials_t[own_slot][idx])
-        msgs = L.unpack(eng.to_host(msg_t[idx]))
-        allp = [L.unpack(eng.to_host(partials_t[k][idx])) for k in range(len(parties))]
-        for j, e in enumerate(idx):
-            base = cts[e] if exps[own] >= 0 else pow(cts[e], -1, n2)
-            assert L.unpack(rows[j : j + 1])[0] == pow(base, own_exp, n2), f"partial decryption {e} differs from pow()"
-            x = 1
-            for k in range(len(parties)):
-                x = x * allp[k][j] % n2
-            assert (x - 1) % n == 0 and msgs[j] == (x - 1) // n * theta_inv % n, f"plaintext {e} differs"
-        check_note = f"{len(idx)} elements bit-exact vs CPython pow; all {batch} combines divisible by N"
-
+                out["cpu_baseline"] = None
+            if not extras:
+                del wl
+            if extras:
+                out["single_batch"] = leg_single_batch(eng, torch, wl, key_length)
+                out["end_to_end"] = leg_end_to_end(eng, torch, wl, out["value"])
+                del wl
+                torch.cuda.empty_cache()
+                out["extra"] = {}
+                if args.workload == "c3" and key_length == 2048:
+                    bp = run_biprime(args, eng, torch, None, 0, 1, 2048, 4096, steps=8, warmup=2, nstreams=2)
+                    bwl = bp.pop("_wl")
+                    if not args.no_cpu_baseline:
+                        bp["cpu_baseline"] = cpu_baseline(bwl.mods[0], bwl.exps[0], bwl.g_sample[:40], min(args.cpu_seconds, 3.0),
+                                                          "candidate 0's modulus and party-1 exponent, its first 40 generators cycled")
+                    del bwl
+                    torch.cuda.empty_cache()
+                    out["extra"]["biprime_k2048"] = {k: bp[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "stages", "roofline", "cpu_baseline") if k in bp}
+                    a5 = argparse.Namespace(**vars(args))
+                    a5.steps, a5.warmup, a5.streams, a5.limbs_per_lane, a5.check = 8, 2, 4, -1, 3
+                    c5 = run_decrypt_main(a5, eng, torch, None, 0, 1, 4096, 4096, "C5 (BASELINE.json configs[4])")
+                    c5wl = c5.pop("_wl")
+                    if not args.no_cpu_baseline:
+                        bases = [c if c5wl.exps[c5wl.own] >= 0 else pow(c, -1, c5wl.n2) for c in c5wl.cts[:32]]
+                        c5["cpu_baseline"] = cpu_baseline(c5wl.n2, c5wl.own_exp, bases, min(args.cpu_seconds, 3.0),
+                                                          "same modulus/exponent, first 32 ciphertexts cycled")
+                    del c5wl
+                    out["extra"]["c5_k4096"] = {k: c5[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "cpu_baseline") if k in c5}
+        if world > 1 and not args.no_extras and args.workload == "c3" and not args.generic_modulus:
+            # configs[3] on N GPUs inside the driver's scaling run: 4096 candidates sharded over the ranks,
+            # all-gather of the v rows and of the verdict bytes (the biprimality vote, DK:1331-1360)
+            if rank == 0:
+                out.pop("_wl", None)
+            torch.cuda.empty_cache()
+            bp = run_biprime(args, eng, torch, dist, rank, world, 2048, 4096, steps=8, warmup=2, nstreams=2)
+            if rank == 0:
+                bp.pop("_wl", None)
+                out["extra"] = {"biprime_k2048": {k: bp[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "stages", "roofline") if k in bp}}
+    else:
+        key_length = args.key_length or 2048
+        total = args.batch * world if args.batch else 4096
+        nstreams = args.streams if args.streams > 0 else 2
+        out = run_biprime(args, eng, torch, dist, rank, world, key_length, total, args.steps, args.warmup, nstreams)
+        if rank == 0:
+            wl = out.pop("_wl")
+            if world == 1 and not args.no_cpu_baseline:
+                out["cpu_baseline"] = cpu_baseline(wl.mods[0], wl.exps[0], wl.g_sample[:40], args.cpu_seconds,
+                                                   "candidate 0's modulus and party-1 exponent, its first 40 generators cycled")
+            else:
+                out["cpu_baseline"] = None
     if rank == 0:
-        total_modexps = world * batch * args.steps
-        s_limbs, e_bits = limbs2, own_exp.bit_length()
-        alg_bytes = batch * (2 * 4 * s_limbs) + 4 * s_limbs + (e_bits + 7) // 8
-        alg_macs = batch * (e_bits + -(-e_bits // 5) + 16) * (2 * s_limbs * s_limbs + s_limbs)
-        achieved_gbs = alg_bytes / (powmod_ms * 1e-3) / 1e9
-        # aggregate VALU rate of this GPU over the timed region (launches of different steps overlap
-        # when several steps are in flight, so per-launch durations would under-state it)
-        agg_mac_rate = alg_macs * args.steps / elapsed
-        out = {
-            "metric": "modexps/sec (2048-bit N, mod N^2)",
-            "value": total_modexps / elapsed,
-            "unit": "modexps/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": "u32",
-            "data": "synthetic",
-            "config": {
-                "workload": f"C3: 3-party key_length={args.key_length} t=1, {batch} ciphertexts/GPU/step: "
-                            "partial-decrypt c^exp mod N^2 + share-combine (BASELINE.json configs[2])",
-                "batch_per_gpu": batch, "mod_bits": n2.bit_length(), "exp_bits": e_bits,
-                "limbs_u32": s_limbs, "party": own, "parallelism": f"dp{world}", "steps_in_flight": nstreams,
-                "geometry_K_L_W_blocks": list(eng.geometry(n2.bit_length()) if args.generic_modulus else eng.nsquare_geometry(n.bit_length(), batch)),
-                "algorithm": "Montgomery modulo N^2" if args.generic_modulus else "N-adic pairs, two Montgomery passes modulo N per product",
-                "verified": check_note,
-            },
-            "roofline": {
-                "bound": "hbm",
-                "kernel": ("mx::powmod_kernel<%d,%d,29,true>" % tuple(eng.geometry(n2.bit_length())[:2])) if args.generic_modulus
-                          else ("mx::powmod_n2_kernel<%d,%d,29>" % tuple(eng.nsquare_geometry(n.bit_length(), batch)[:2])),
-                "achieved": achieved_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                "frac": achieved_gbs / HBM_PEAK_GBS,
-                "traffic": MEASURED_TRAFFIC_DEFAULT[eng.nsquare_geometry(n.bit_length(), batch)[1]]
-                if (batch == 10000 and args.key_length == 2048 and not args.generic_modulus) else None,
-                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this command, profiles/ (not collected live)",
-                "kernel_ms": powmod_ms, "concurrent_launches": nstreams,
-                "algorithmic_bytes_per_launch": alg_bytes,
-                "note": "integer-VALU-bound path (north_star: no MFMA); the HBM fraction is reported as asked "
-                        "(bytes of ONE launch over its own duration; `concurrent_launches` launches overlap), "
-                        "the binding roof is the v_mad_u64_u32 issue rate below",
-                "valu": {
-                    "achieved": agg_mac_rate / 1e12, "peak": VALU_MAC_PEAK / 1e12,
-                    "unit": "T 32x32-bit MAC/s", "frac": agg_mac_rate / VALU_MAC_PEAK,
-                    "algorithmic_macs_per_launch": alg_macs,
-                    "issue_utilization": (MEASURED_VALU_INSTS_DEFAULT[eng.nsquare_geometry(n.bit_length(), batch)[1]] * args.steps / elapsed / VALU_ISSUE_PEAK)
-                    if (batch == 10000 and args.key_length == 2048 and not args.generic_modulus) else None,
-                    "issue_utilization_basis": "SQ_INSTS_VALU per launch (profiles/: 2.24e10 narrow, 1.84e10 wide geometry) x "
-                                               "launches / wall time, over 1024 SIMDs x 2.4 GHz / 4 cycles per VALU instruction",
-                    "basis": "all launches of the timed region / wall time of the region, this GPU; the MAC count is "
-                             "SURVEY.md 8(d)'s figure for schoolbook Montgomery modulo N^2 — a fraction above 1 means "
-                             "the kernel needs fewer multiply-accumulates than that figure assumes (symmetric squaring, "
-                             "half-size passes modulo N)",
-                },
-            },
-        }
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(key, own_exp, [c if exps[own] >= 0 else pow(c, -1, n2) for c in cts[:64]], args.cpu_seconds)
-        else:
-            out["cpu_baseline"] = None
         os.write(result_fd, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()

@@ -116,7 +116,9 @@ typedef struct mx_nsquare_plan {
   int32_t ntape;          /* tape words */
   int32_t n_sqr;          /* pair squarings one exponentiation executes */
   int32_t n_mul;          /* pair multiplications one exponentiation executes */
-  int32_t reserved;
+  int32_t has_wide;       /* 1 if the wide geometry (limbs_per_lane 18) is available for this modulus */
+  int32_t n_slot_reads;   /* pair slots (2 * limbs_per_lane words per lane) one exponentiation reads from ... */
+  int32_t n_slot_writes;  /* ... and writes to the workspace: the kernel's HBM traffic model */
 } mx_nsquare_plan;
 int64_t mx_nsquare_plan_bytes(int limbs_n, int exp_limbs);
 int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp, int limbs_n,

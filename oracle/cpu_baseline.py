@@ -93,9 +93,35 @@ def _worker(args):
     return count, el, name, desc
 
 
+def usable_cores() -> dict:
+    """Cores this process may actually use: the scheduler affinity mask, capped by the cgroup CPU
+    quota (cpu.max of cgroup v2 / cfs_quota of v1) — os.cpu_count() reports the whole host even when
+    the container is limited to a fraction of it."""
+    try:
+        affinity = len(os.sched_getaffinity(0))
+    except AttributeError:  # pragma: no cover - non-Linux
+        affinity = os.cpu_count() or 1
+    quota = None
+    try:
+        first = open("/sys/fs/cgroup/cpu.max").read().split()
+        if first[0] != "max":
+            quota = float(first[0]) / float(first[1])
+    except Exception:
+        try:
+            q = float(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            per = float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                quota = q / per
+        except Exception:
+            pass
+    usable = affinity if quota is None else max(1, min(affinity, int(quota + 0.5)))
+    return {"host_cpu_count": os.cpu_count(), "affinity": affinity, "cgroup_quota": quota, "usable": usable}
+
+
 def main() -> None:
     job = json.load(open(sys.argv[1]))
-    nprocs = int(job.get("nprocs") or os.cpu_count() or 1)
+    cores = usable_cores()
+    nprocs = int(job.get("nprocs") or cores["usable"])
     seconds = float(job.get("seconds", 4.0))
     single = _worker((job, 0, min(seconds, 2.0)))
     if nprocs > 1:
@@ -107,8 +133,9 @@ def main() -> None:
     else:
         total, wall, rate_all = single[0], single[1], single[0] / single[1]
     print(json.dumps({
-        "engine": single[2], "engine_desc": single[3], "cores": nprocs,
+        "engine": single[2], "engine_desc": single[3], "cores": nprocs, "core_info": cores,
         "rate_all_cores": rate_all, "rate_single_core": single[0] / single[1],
+        "parallel_efficiency": rate_all / (single[0] / single[1] * nprocs),
         "modexps_timed": total, "wall_s": wall,
     }))
 

@@ -19,7 +19,8 @@ class NsquarePlan(ctypes.Structure):
     _fields_ = [
         ("d_plan", c_void_p), ("plan_bytes", c_int64), ("limbs_n", ctypes.c_int32), ("n_bits", ctypes.c_int32),
         ("exp_bits", ctypes.c_int32), ("window", ctypes.c_int32), ("ntape", ctypes.c_int32),
-        ("n_sqr", ctypes.c_int32), ("n_mul", ctypes.c_int32), ("reserved", ctypes.c_int32),
+        ("n_sqr", ctypes.c_int32), ("n_mul", ctypes.c_int32), ("has_wide", ctypes.c_int32),
+        ("n_slot_reads", ctypes.c_int32), ("n_slot_writes", ctypes.c_int32),
     ]
 
 

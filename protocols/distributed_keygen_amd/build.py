@@ -10,6 +10,8 @@ from pathlib import Path
 PKG = Path(__file__).resolve().parent
 CSRC = PKG / "csrc"
 LIB = PKG / "libmxpaillier.so"
+CODEC_SRC = CSRC / "mx_pycodec.c"
+CODEC = PKG / "_mxcodec.so"          # CPython helper: bulk Python int <-> limb rows (host side, no arithmetic)
 SOURCES = [CSRC / "mx_capi.hip", CSRC / "mx_capi_n2.hip", CSRC / "mx_capi_n2w.hip"]
 HEADERS = sorted(CSRC.glob("*.hpp")) + [PKG.parent.parent / "include" / "mxpaillier.h"]
 
@@ -25,12 +27,31 @@ def needs_build() -> bool:
     if not LIB.exists():
         return True
     t = LIB.stat().st_mtime
-    return any(p.stat().st_mtime > t for p in SOURCES + HEADERS)
+    if any(p.stat().st_mtime > t for p in SOURCES + HEADERS):
+        return True
+    return not CODEC.exists() or CODEC_SRC.stat().st_mtime > CODEC.stat().st_mtime
+
+
+def build_codec(verbose: bool = False) -> Path:
+    """gcc build of the CPython int <-> rows helper against the running interpreter's headers."""
+    import sysconfig
+
+    cc = shutil.which("gcc") or shutil.which("cc")
+    if cc is None:
+        raise RuntimeError("gcc not found")
+    cmd = [cc, "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], str(CODEC_SRC), "-o", str(CODEC)]
+    if verbose:
+        print(" ".join(cmd))
+    subprocess.run(cmd, check=True)
+    return CODEC
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
     """Compile the shared library for gfx950; returns its path."""
     if not force and not needs_build():
+        return LIB
+    build_codec(verbose)
+    if not force and LIB.exists() and not any(p.stat().st_mtime > LIB.stat().st_mtime for p in SOURCES + HEADERS):
         return LIB
     from concurrent.futures import ThreadPoolExecutor
 

@@ -128,10 +128,13 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
   // ---- the tape (mx_powmod_n2.hpp): conversion, table of odd powers, sliding window, times E
   std::vector<u32> tape;
   int n_sqr = 0, n_mul = 0, w = 1;
+  int n_reads = 0, n_writes = 6;                               // the prologue writes 4 constant pairs and x_lo, x_hi
   auto emit = [&](u32 op, int arg) {
     tape.push_back((op << 28) | (u32)arg);
     if (op == mx::N2_SQR) n_sqr += arg;
     if (op == mx::N2_MUL) n_mul += 1;
+    if (op == mx::N2_STORE) n_writes += 1;
+    if (op == mx::N2_MUL || op == mx::N2_ADD || op == mx::N2_LOAD) n_reads += 1;
   };
   if (ebits == 0) {
     emit(mx::N2_LOAD, mx::N2_SLOT_ONE);
@@ -176,7 +179,9 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
   plan->ntape = (int)tape.size();
   plan->n_sqr = n_sqr;
   plan->n_mul = n_mul;
-  plan->reserved = has_wide ? 1 : 0;
+  plan->has_wide = has_wide ? 1 : 0;
+  plan->n_slot_reads = n_reads;
+  plan->n_slot_writes = n_writes;
   return MX_OK;
 }
 
@@ -200,7 +205,7 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   const int lpl = limbs_per_lane ? limbs_per_lane : n2_auto_limbs_per_lane(bits, batch);
   N2Shape p;
   if (!shape_n2(bits, plan->window, batch, lpl, p)) return MX_ERR_SIZE;
-  if (lpl == LIMBS_PER_LANE_WIDE && !plan->reserved) return MX_ERR_SIZE;
+  if (lpl == LIMBS_PER_LANE_WIDE && !plan->has_wide) return MX_ERR_SIZE;
   if (p.table_bytes > ws_bytes) return MX_ERR_WORKSPACE;
   if (2 * p.geo.K * p.geo.L + 8 < limbs2 + 2) return MX_ERR_ARG;   // row wider than the staging area
   const int64_t cb = n2_consts_bytes(plan->limbs_n);

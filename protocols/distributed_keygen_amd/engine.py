@@ -53,6 +53,9 @@ class Engine:
         self._lpl = 0                          # lane geometry of this engine's modexp launches (0 = automatic)
         self._n2_plans: "OrderedDict[Tuple[int, int], _Plan]" = OrderedDict()
         self._combine_plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
+        self._side_streams: List[Any] = []     # chunked int-level batches (_pipelined)
+        self._pin: Dict[str, Any] = {}         # pinned staging buffers of _pipelined
+        self.last_timing: Optional[Dict[str, Any]] = None   # host/GPU time split of the last int-level modexp batch
 
     # ------------------------------------------------------------------ plumbing
     def _stream_ptr(self) -> int:
@@ -290,14 +293,93 @@ class Engine:
         return out_t
 
     def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int) -> List[int]:
-        """[pow_mod(b, exp, n*n) for b in bases] through the N-adic pair kernel."""
+        """[pow_mod(b, exp, n*n) for b in bases] through the N-adic pair kernel.  Sequences of
+        PIPELINE_MIN elements or more are cut into chunks that run on several streams: the chunks
+        together fill the machine (one 10 000-element launch occupies 61 % of the SIMDs), and the
+        packing of chunk k+1 and the PCIe copies overlap the modexps of chunk k."""
         if len(bases) == 0:
             return []
         _check_modulus(n)
         n2 = n * n
         limbs2 = _limbs.limbs_for(n2)
-        rows = _limbs.pack([_reduce(b, n2) for b in bases], limbs2)
-        return _limbs.unpack(self.to_host(self.powmod_nsquare_t(self.to_device(rows), n, exp)))
+        vals = [_reduce(b, n2) for b in bases]
+        if len(vals) < self.PIPELINE_MIN:
+            import time as _t
+
+            t0 = _t.perf_counter()
+            rows = _limbs.pack(vals, limbs2)
+            t1 = _t.perf_counter()
+            out = self.to_host(self.powmod_nsquare_t(self.to_device(rows), n, exp))
+            t2 = _t.perf_counter()
+            res = _limbs.unpack(out)
+            self.last_timing = {"chunks": 1, "pack_s": t1 - t0, "copies_and_gpu_s": t2 - t1, "unpack_s": _t.perf_counter() - t2}
+            return res
+        self.nsquare_plan(n, exp)          # prepared once, before the chunks fan out over streams
+        return self._pipelined(vals, limbs2, limbs2, lambda t: self.powmod_nsquare_t(t, n, exp))
+
+    # ------------------------------------------------------------------ chunked execution on several streams
+    PIPELINE_MIN = 20000       # elements from which an int-level batch is cut into chunks
+    PIPELINE_STREAMS = 8
+
+    def _pinned(self, which: str, rows: int, limbs: int):
+        buf = self._pin.get(which)
+        if buf is None or buf.numel() < rows * limbs:
+            buf = self.torch.empty(rows * limbs, dtype=self.torch.int32, pin_memory=True)
+            self._pin[which] = buf
+        return buf[: rows * limbs].view(rows, limbs)
+
+    def _pipelined(self, vals: List[int], limbs_in: int, limbs_out: int, launch) -> List[int]:
+        """ints -> ints through `launch(device rows) -> device rows`, chunked over side streams with
+        pinned staging buffers: pack chunk k+1 on the host while chunk k is copied and computed."""
+        import time as _t
+
+        torch = self.torch
+        total = len(vals)
+        nchunks = max(4, min(self.PIPELINE_STREAMS, total // 10000))
+        per = -(-total // nchunks)
+        while len(self._side_streams) < nchunks:
+            with torch.cuda.device(self.device):
+                self._side_streams.append(torch.cuda.Stream(device=self.device))
+        in_pin = self._pinned("in", total, limbs_in)
+        out_pin = self._pinned("out", total, limbs_out)
+        in_np = in_pin.numpy().view(np.uint32)
+        out_np = out_pin.numpy().view(np.uint32)
+        cur = torch.cuda.current_stream(self.device)
+        events, bounds, keep = [], [], []
+        pack_s = 0.0
+        t_start = _t.perf_counter()
+        for k in range(nchunks):
+            lo, hi = k * per, min(total, (k + 1) * per)
+            if lo >= hi:
+                break
+            t0 = _t.perf_counter()
+            _limbs.pack_into(vals[lo:hi], limbs_in, in_np, lo)
+            pack_s += _t.perf_counter() - t0
+            side = self._side_streams[k]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                d_in = in_pin[lo:hi].to(self.device, non_blocking=True)
+                d_out = launch(d_in)
+                out_pin[lo:hi].copy_(d_out, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(side)
+            keep.append((d_in, d_out))
+            events.append(ev)
+            bounds.append((lo, hi))
+        out: List[int] = []
+        wait_s = unpack_s = 0.0
+        for ev, (lo, hi) in zip(events, bounds):
+            t0 = _t.perf_counter()
+            ev.synchronize()
+            t1 = _t.perf_counter()
+            out.extend(_limbs.unpack(out_np[lo:hi]))
+            wait_s += t1 - t0
+            unpack_s += _t.perf_counter() - t1
+        for side in self._side_streams[: len(events)]:
+            cur.wait_stream(side)
+        self.last_timing = {"chunks": len(events), "pack_s": pack_s, "wait_for_gpu_s": wait_s, "unpack_s": unpack_s,
+                            "total_s": _t.perf_counter() - t_start}
+        return out
 
     # ------------------------------------------------------------------ modexp, int level
     def powmod_batch(self, bases: Sequence[int], exp: int, mod: int) -> List[int]:

@@ -18,14 +18,37 @@ def limbs_for(value: int) -> int:
     return limbs_for_bits(int(value).bit_length())
 
 
-def pack(values: Sequence[int], limbs: int) -> np.ndarray:
-    """ints (0 <= v < 2^(32*limbs)) -> uint32 array [len(values), limbs]."""
+try:  # bulk conversion in C (csrc/mx_pycodec.c, built by build.py next to the HIP library)
+    from . import _mxcodec  # type: ignore
+except ImportError:  # pragma: no cover - a checkout that has not been built yet
+    _mxcodec = None
+
+
+def pack_into(values: Sequence[int], limbs: int, out: np.ndarray, row_offset: int = 0) -> None:
+    """ints -> rows [row_offset, row_offset + len(values)) of the C-contiguous uint32 array `out`
+    (e.g. a pinned staging buffer), without intermediate copies."""
+    if _mxcodec is not None and isinstance(values, (list, tuple)) and all(type(v) is int for v in values[:1]):
+        try:
+            _mxcodec.pack_into(values, limbs, out, row_offset)
+            return
+        except TypeError:
+            pass                                    # int-like objects (e.g. gmpy2.mpz): the generic path converts them
     nbytes = 4 * limbs
+    flat = out.reshape(-1).view(np.uint8)
     try:
-        buf = b"".join(int(v).to_bytes(nbytes, "little") for v in values)
+        for k, v in enumerate(values):
+            flat[(row_offset + k) * nbytes : (row_offset + k + 1) * nbytes] = np.frombuffer(int(v).to_bytes(nbytes, "little"), dtype=np.uint8)
     except OverflowError as exc:
         raise ValueError(f"value does not fit in {limbs} uint32 limbs (or is negative)") from exc
-    return np.frombuffer(buf, dtype="<u4").reshape(len(values), limbs).copy()
+
+
+def pack(values: Sequence[int], limbs: int) -> np.ndarray:
+    """ints (0 <= v < 2^(32*limbs)) -> uint32 array [len(values), limbs]."""
+    if not isinstance(values, (list, tuple)):
+        values = list(values)
+    out = np.empty((len(values), limbs), dtype="<u4")
+    pack_into(values, limbs, out, 0)
+    return out
 
 
 def pack_one(value: int, limbs: int) -> np.ndarray:
@@ -37,6 +60,8 @@ def unpack(rows: np.ndarray) -> List[int]:
     rows = np.ascontiguousarray(rows, dtype="<u4")
     if rows.ndim == 1:
         rows = rows.reshape(1, -1)
+    if _mxcodec is not None:
+        return _mxcodec.unpack(rows, rows.shape[1]) if rows.shape[0] else []
     nbytes = rows.shape[1] * 4
     raw = rows.tobytes()
     return [int.from_bytes(raw[i * nbytes : (i + 1) * nbytes], "little") for i in range(rows.shape[0])]

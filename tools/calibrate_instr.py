@@ -1,0 +1,158 @@
+#!/usr/bin/env python3
+"""VALU instruction-count model of the modexp kernels, calibrated against SQ_INSTS_VALU.
+
+bench.py's primary roofline is VALU instruction issue.  The number of VALU wave-instructions a
+launch executes is a function of the kernel instance and of the exponent only (control flow is
+uniform, there is no data-dependent work besides a few carry-ripple iterations):
+
+    per wavefront:  n_sqr * I_sqr + n_mul * I_mul + F        with (I_sqr, I_mul, F) per (L, nblk)
+
+where n_sqr / n_mul are the squarings / multiplications of the exponentiation (for the N^2 pair
+kernel the plan reports them: mx_nsquare_plan.n_sqr / .n_mul; for the fixed-window generic kernel
+they follow from the window width and the digit count).  This tool measures the three constants
+for every (L, nblk):
+
+  python3 tools/calibrate_instr.py run   <configs.json>        launches 4 exponents per (kernel, L, nblk)
+        — run it under  rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d <dir>
+  python3 tools/calibrate_instr.py fit   <configs.json> <dir> <model.json>
+        — matches the dispatches to the configs in launch order, solves the 3x3 system from the first
+          three exponents and reports the residual of the fourth (a check of the linear model)
+
+The model is committed as profiles/r02_instr_model.json; bench.py reads it.
+"""
+
+from __future__ import annotations
+
+import csv
+import glob
+import json
+import random
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+W = 29
+WAVES = 4
+
+
+def fixed_window(exp_bits: int) -> int:
+    """mx_host.hpp: fixed_window (minimise ceil(bits/w) multiplications + 2^w - 2 table products)."""
+    best, bestc = 1, None
+    for w in range(1, 8):
+        c = (exp_bits + w - 1) // w + (1 << w) - 2
+        if bestc is None or c < bestc:
+            best, bestc = w, c
+    return best
+
+
+def generic_counts(max_ebits: int, exp_limbs: int):
+    """(n_sqr, n_mul) of powmod_kernel<.., false>: window squarings and table + window multiplications."""
+    win = fixed_window(32 * exp_limbs)
+    ndigits = max(1, -(-max_ebits // win))
+    return (ndigits - 1) * win, ((1 << win) - 2) + (ndigits - 1)
+
+
+def exponents(rng: random.Random):
+    return [1 << 191, (1 << 192) - 1, rng.getrandbits(192) | (1 << 191) | 1, rng.getrandbits(120) | (1 << 119) | 1]
+
+
+def run(cfg_path: str) -> None:
+    import torch  # noqa: F401
+
+    from protocols.distributed_keygen_amd import Engine, limbs as Lm
+
+    eng = Engine()
+    rng = random.Random(20260201)
+    configs = []
+    for kind in ("n2", "generic"):
+        for L in (9, 18):
+            max_nblk = {("n2", 9): 32, ("n2", 18): 16, ("generic", 9): 64, ("generic", 18): 32}[(kind, L)]
+            for nblk in range(1, max_nblk + 1):
+                bits = W * L * nblk - 4
+                if bits < 8:
+                    continue
+                k = 1
+                while k < nblk:
+                    k *= 2
+                batch = WAVES * (64 // k)
+                eng.set_limbs_per_lane(L)
+                n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+                for e in exponents(rng):
+                    if kind == "n2":
+                        assert eng.nsquare_geometry(bits, batch) == (k, L, W, nblk)
+                        n2 = n * n
+                        rows = eng.to_device(Lm.pack([rng.randrange(n2) for _ in range(batch)], Lm.limbs_for(n2)))
+                        plan = eng.nsquare_plan(n, e)
+                        eng.powmod_nsquare_t(rows, n, e)
+                        configs.append({"kind": kind, "L": L, "nblk": nblk, "K": k, "waves": WAVES,
+                                        "n_sqr": int(plan.desc.n_sqr), "n_mul": int(plan.desc.n_mul)})
+                    else:
+                        assert eng.geometry(bits, batch * 2, 2) == (k, L, W, nblk)
+                        groups = 2
+                        mods = [n, n - 2]
+                        rows = eng.to_device(Lm.pack([rng.randrange(n - 2) for _ in range(batch * groups)], Lm.limbs_for(n)))
+                        exps = [e, e - 2]
+                        eng.powmod_multi_t(rows, mods, exps, batch)
+                        nsq, nmu = generic_counts(e.bit_length(), Lm.limbs_for(e))
+                        configs.append({"kind": kind, "L": L, "nblk": nblk, "K": k, "waves": WAVES * groups,
+                                        "n_sqr": nsq, "n_mul": nmu})
+                eng.synchronize()
+    Path(cfg_path).write_text(json.dumps(configs))
+    print(f"{len(configs)} launches")
+
+
+def solve3(rows, rhs):
+    """Gaussian elimination of a 3x3 system."""
+    a = [list(map(float, r)) + [float(b)] for r, b in zip(rows, rhs)]
+    for i in range(3):
+        piv = max(range(i, 3), key=lambda r: abs(a[r][i]))
+        a[i], a[piv] = a[piv], a[i]
+        for r in range(3):
+            if r != i:
+                f = a[r][i] / a[i][i]
+                a[r] = [x - f * y for x, y in zip(a[r], a[i])]
+    return [a[i][3] / a[i][i] for i in range(3)]
+
+
+def fit(cfg_path: str, pmc_dir: str, model_path: str) -> None:
+    configs = json.loads(Path(cfg_path).read_text())
+    disp = {"n2": [], "generic": []}
+    for f in glob.glob(pmc_dir + "/**/*_counter_collection.csv", recursive=True):
+        for r in csv.DictReader(open(f)):
+            if r["Counter_Name"] != "SQ_INSTS_VALU":
+                continue
+            name = r["Kernel_Name"]
+            kind = "n2" if "powmod_n2_kernel" in name else ("generic" if "mx::powmod_kernel" in name else None)
+            if kind:
+                disp[kind].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), name))
+    model = {"n2": {"9": {}, "18": {}}, "generic": {"9": {}, "18": {}}, "max_residual": 0.0,
+             "source": "tools/calibrate_instr.py: SQ_INSTS_VALU of 4 exponents per (kernel, L, nblk); wave-instructions "
+                       "per wavefront = n_sqr*I_sqr + n_mul*I_mul + F"}
+    for kind in ("n2", "generic"):
+        d = sorted(disp[kind])
+        cfgs = [c for c in configs if c["kind"] == kind]
+        assert len(d) == len(cfgs), (kind, len(d), len(cfgs))
+        for i in range(0, len(cfgs), 4):
+            grp = cfgs[i : i + 4]
+            per_wave = [d[i + j][1] / grp[j]["waves"] for j in range(4)]
+            sol = solve3([[g["n_sqr"], g["n_mul"], 1] for g in grp[:3]], per_wave[:3])
+            pred = sol[0] * grp[3]["n_sqr"] + sol[1] * grp[3]["n_mul"] + sol[2]
+            resid = abs(pred - per_wave[3]) / per_wave[3]
+            model["max_residual"] = max(model["max_residual"], resid)
+            model[kind][str(grp[0]["L"])][str(grp[0]["nblk"])] = [round(sol[0], 2), round(sol[1], 2), round(sol[2], 1)]
+    Path(model_path).write_text(json.dumps(model, indent=0))
+    print("max residual of the held-out exponent:", model["max_residual"])
+    for kind in ("n2", "generic"):
+        for L in ("9", "18"):
+            for nblk in ("4", "8", "16"):
+                if nblk in model[kind][L]:
+                    print(kind, "L", L, "nblk", nblk, model[kind][L][nblk])
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "run":
+        run(sys.argv[2])
+    else:
+        fit(sys.argv[2], sys.argv[3], sys.argv[4])
