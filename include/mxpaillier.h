@@ -191,6 +191,23 @@ int64_t mx_mulmod_workspace_bytes(int limbs);
 int mx_mulmod_shared(const uint32_t* d_a, const uint32_t* d_b, uint32_t* d_out, const uint32_t* h_mod,
                      int limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- Shamir-field arithmetic of the candidate moduli ---------------------------------------
+ * The key generation holds p, q and a sharing of zero as Shamir shares modulo a prime P of
+ * 2*(prime_length + log2(parties)) bits (DK:647-651).  Per candidate of a round:
+ *   mx_fma_mod      d_out[e] = (d_a[e] * d_b[e] + d_c[e]) mod P — this party's share of N,
+ *                   `prime_candidate_p * prime_candidate_q` then `candidate_n += zero` (DK:1274-1277;
+ *                   ShamirVariable.__mul__ / __add__, UT:205-250)
+ *   mx_lincomb_mod  d_out[e] = sum_t h_coeffs[t] * d_x[t][e] mod P — `candidate_n.reconstruct()`
+ *                   (DK:1284; UT:263-270, 465-471) with the Lagrange coefficients at 0 of the
+ *                   parties' evaluation points; d_x is [terms][batch][limbs], h_coeffs [terms][limbs].
+ * P odd; operands < P (values up to 16 P are still reduced correctly).  The reconstructed moduli
+ * are exactly the rows mx_sieve / mx_jacobi_dev / mx_powmod_multi_dev take. */
+int64_t mx_field_workspace_bytes(int limbs, int terms);
+int mx_fma_mod(const uint32_t* d_a, const uint32_t* d_b, const uint32_t* d_c, uint32_t* d_out, const uint32_t* h_mod,
+               int limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
+int mx_lincomb_mod(const uint32_t* d_x, const uint32_t* h_coeffs, uint32_t* d_out, const uint32_t* h_mod, int limbs,
+                   int terms, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Jacobi symbol ---------------------------------------------------------------------
  * d_out[g*group_size + k] = Jacobi symbol (d_values[g*group_size + k] / h_mods[g]) in {-1, 0, +1}.
  * Replaces the filter `sympy.jacobi_symbol(g, modulus) != 1` of the biprimality test (DK:1089),

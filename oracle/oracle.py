@@ -203,3 +203,31 @@ def prime_candidate_from_bits(index: int, prime_length: int, random_bits: int) -
 def n_factorial(number_of_parties: int) -> int:
     """IntegerShares.n_fac of the un-vendored shamir package (used PSK:70)."""
     return factorial(number_of_parties)
+
+
+# ---------------------------------------------------------------------------------------------------
+# Shamir field of the key generation (DK:1274-1284 through utils.py:205-270 / 404-471).  The field
+# arithmetic itself lives in the un-vendored tno.mpc.encryption_schemes.shamir (pinned ~=... by the
+# reference's pyproject); it is the textbook prime-field Shamir scheme: share-wise product / sum
+# modulo P, and Lagrange interpolation at 0 over degree+1 shares.
+# ---------------------------------------------------------------------------------------------------
+def shamir_mul_add(p_share: int, q_share: int, zero_share: int, prime: int) -> int:
+    """One party's share of a candidate modulus: `p * q` (DK:1274, UT:229-250) then `+= zero` (DK:1277, UT:205-227)."""
+    return (p_share * q_share % prime + zero_share) % prime
+
+
+def shamir_reconstruct(shares: dict, prime: int, degree: int) -> int:
+    """`candidate_n.reconstruct()` (DK:1284, UT:263-270): value at 0 of the polynomial through the
+    first degree+1 shares in party order."""
+    pts = sorted(shares.items())[: degree + 1]
+    if len(pts) < degree + 1:
+        raise ValueError("not enough shares")
+    total = 0
+    for i, y in pts:
+        num = den = 1
+        for j, _ in pts:
+            if j != i:
+                num = num * j % prime
+                den = den * (j - i) % prime
+        total = (total + y * num * pow(den, -1, prime)) % prime
+    return total

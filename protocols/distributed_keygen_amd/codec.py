@@ -44,23 +44,40 @@ def decode_tree(obj: Any) -> Any:
     return obj
 
 
-def rows_from_wire(values: Sequence[Any], limbs: int) -> np.ndarray:
-    """A received list of non-negative big integers (wire form or plain ints) -> uint32 rows
-    [len, limbs] without going through Python int arithmetic for the wire-form entries."""
+def rows_from_wire(values: Sequence[Any], limbs: int, modulus: int = 0) -> np.ndarray:
+    """A received list of big integers (wire form ``{"type": "int", "data": bytes}`` or plain ints) ->
+    uint32 rows [len, limbs].  Wire-form entries are copied byte-wise (they ARE little-endian limb
+    rows already), plain ints go through the bulk C conversion — no per-integer Python arithmetic on
+    the normal path.  With ``modulus`` given, values outside [0, modulus) are reduced the way the
+    reference's ``mult_list(..., modulus)`` would reduce them (utils.py:23-38, PSK:115-117);
+    without it they raise ValueError."""
     nbytes = 4 * limbs
+    if not isinstance(values, (list, tuple)):
+        values = list(values)
+    if all(type(v) is int for v in values):
+        try:
+            from . import limbs as _limbs
+
+            return _limbs.pack(values, limbs)
+        except ValueError:
+            if not modulus:
+                raise
+            return _limbs.pack([v % modulus for v in values], limbs)
     buf = bytearray(nbytes * len(values))
     for k, v in enumerate(values):
         if isinstance(v, dict) and v.get("type") == "int":
             data = v["data"]
-            if data and data[-1] & 0x80:          # signed little-endian: top bit of the last byte = negative
-                raise ValueError("negative value")
-            if len(data) > nbytes:
-                if any(data[nbytes:]):
-                    raise ValueError(f"value does not fit in {limbs} uint32 limbs")
-                data = data[:nbytes]
-            buf[k * nbytes : k * nbytes + len(data)] = data
+            negative = bool(data) and bool(data[-1] & 0x80)      # signed little-endian: top bit of the last byte
+            too_long = len(data) > nbytes and any(data[nbytes:])
+            if negative or too_long:
+                if not modulus:
+                    raise ValueError("negative value" if negative else f"value does not fit in {limbs} uint32 limbs")
+                data = (int.from_bytes(data, "little", signed=True) % modulus).to_bytes(nbytes, "little")
+            buf[k * nbytes : k * nbytes + min(len(data), nbytes)] = data[:nbytes]
         else:
             iv = int(v)
+            if modulus and not 0 <= iv < modulus:
+                iv %= modulus
             if iv < 0:
                 raise ValueError("negative value")
             try:

@@ -8,6 +8,7 @@
 #include "mx_mulmod.hpp"
 #include "mx_select.hpp"
 #include "mx_setup.hpp"
+#include "mx_field.hpp"
 #include <cstring>
 #include <algorithm>
 
@@ -666,6 +667,72 @@ extern "C" int mx_mulmod_shared(const uint32_t* d_a, const uint32_t* d_b, uint32
     case 64: return launch_mulmod_k<64>(a, s);
   }
   return MX_ERR_SIZE;
+}
+
+// ---- Shamir-field arithmetic of the candidate moduli ----------------------------------------------
+namespace {
+template <int K>
+int launch_field_k(const mx::FieldArgs& a, bool lincomb, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE, LIMB_BITS, true>;
+  int gpw = 64 / K;
+  int64_t nblocks = (a.batch + gpw - 1) / gpw;
+  size_t lds = (size_t)gpw * M_t::LDS_WORDS * 4;
+  if (lincomb)
+    hipLaunchKernelGGL((mx::lincomb_kernel<K, LIMBS_PER_LANE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  else
+    hipLaunchKernelGGL((mx::fma_kernel<K, LIMBS_PER_LANE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+int field_launch(mx::FieldArgs& a, bool lincomb, const uint32_t* h_mod, const uint32_t* h_extra, int extra_words,
+                 int limbs, void* d_ws, int64_t ws_bytes, hipStream_t s) {
+  if (!(h_mod[0] & 1u)) return MX_ERR_MODULUS;
+  int bits = bit_length(h_mod, limbs);
+  if (bits < 2) return MX_ERR_MODULUS;
+  Geometry geo;
+  if (!choose_geometry(bits, geo)) return MX_ERR_SIZE;
+  if (align256((int64_t)(2 * limbs + extra_words) * 4) > ws_bytes) return MX_ERR_WORKSPACE;
+  std::vector<u32> c((size_t)2 * limbs + extra_words);
+  std::memcpy(c.data(), h_mod, (size_t)limbs * 4);
+  two_pow_mod(c.data() + limbs, h_mod, limbs, geo.W * geo.L * geo.nblk);
+  if (extra_words) std::memcpy(c.data() + 2 * limbs, h_extra, (size_t)extra_words * 4);
+  MX_TRY(upload_words(d_ws, c.data(), c.size(), s));
+  a.mod = (const u32*)d_ws; a.rmodn = (const u32*)d_ws + limbs;
+  if (lincomb) a.b = (const u32*)d_ws + 2 * limbs;
+  a.limbs = limbs; a.nblk = geo.nblk;
+  switch (geo.K) {
+    case 1: return launch_field_k<1>(a, lincomb, s);
+    case 2: return launch_field_k<2>(a, lincomb, s);
+    case 4: return launch_field_k<4>(a, lincomb, s);
+    case 8: return launch_field_k<8>(a, lincomb, s);
+    case 16: return launch_field_k<16>(a, lincomb, s);
+    case 32: return launch_field_k<32>(a, lincomb, s);
+    case 64: return launch_field_k<64>(a, lincomb, s);
+  }
+  return MX_ERR_SIZE;
+}
+}  // namespace
+
+extern "C" int64_t mx_field_workspace_bytes(int limbs, int terms) {
+  if (limbs <= 0 || terms < 0) return MX_ERR_ARG;
+  return align256((int64_t)(2 + terms) * limbs * 4);
+}
+
+extern "C" int mx_fma_mod(const uint32_t* d_a, const uint32_t* d_b, const uint32_t* d_c, uint32_t* d_out,
+                          const uint32_t* h_mod, int limbs, int64_t batch, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_a || !d_b || !d_c || !d_out || !h_mod || !d_ws || limbs <= 0 || batch <= 0) return MX_ERR_ARG;
+  mx::FieldArgs a;
+  a.a = d_a; a.b = d_b; a.c = d_c; a.out = d_out; a.batch = batch; a.terms = 0;
+  return field_launch(a, false, h_mod, nullptr, 0, limbs, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+extern "C" int mx_lincomb_mod(const uint32_t* d_x, const uint32_t* h_coeffs, uint32_t* d_out, const uint32_t* h_mod,
+                              int limbs, int terms, int64_t batch, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_x || !h_coeffs || !d_out || !h_mod || !d_ws || limbs <= 0 || terms <= 0 || batch <= 0) return MX_ERR_ARG;
+  mx::FieldArgs a;
+  a.a = d_x; a.b = nullptr; a.c = nullptr; a.out = d_out; a.batch = batch; a.terms = terms;
+  return field_launch(a, true, h_mod, h_coeffs, terms * limbs, limbs, d_ws, ws_bytes, (hipStream_t)stream);
 }
 
 // ---- selection of the Jacobi-1 generators ---------------------------------------------------

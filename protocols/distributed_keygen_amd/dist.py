@@ -58,6 +58,18 @@ def _gather_rows(local, world: int, group: Any):
     return out
 
 
+def all_gather_rows(local, total_rows: int, group: Any = None):
+    """For callers that hold ONLY their shard (rows [lo, hi) of shard_bounds(total_rows, rank, world),
+    padded to ceil(total_rows / world) rows): run the single-GPU operator on the shard, then this —
+    the one all-gather — to give every rank the full result in order.  The sharded_* functions below
+    are this plus the slicing of a replicated input."""
+    rank, world = _world(group)
+    if world == 1:
+        return local[:total_rows]
+    per = -(-total_rows // world)
+    return _gather_rows(_pad_rows(local, per), world, group)[:total_rows]
+
+
 def sharded_powmod_shared(engine: Any, bases_t, mod: int, exp: int, group: Any = None):
     """Full-batch ``engine.powmod_shared_t`` computed as world slices + one all-gather."""
     rank, world = _world(group)
@@ -115,7 +127,9 @@ def sharded_sieve(engine: Any, cands_t, primes: Sequence[int], group: Any = None
 
 
 def sharded_combine(engine: Any, partials_t, n: int, theta_inv: int, group: Any = None):
-    """``engine.combine_t`` with the ciphertexts (dim 1 of partials_t) split across ranks."""
+    """``engine.combine_t`` with the ciphertexts (dim 1 of partials_t) split across ranks.  Plaintext
+    and status travel as ONE row per ciphertext (mx_combine_run's packed output), so the exchange is a
+    single all-gather."""
     rank, world = _world(group)
     if world == 1:
         return engine.combine_t(partials_t, n, theta_inv)
@@ -126,8 +140,38 @@ def sharded_combine(engine: Any, partials_t, n: int, theta_inv: int, group: Any 
     if per * world != batch:
         pad = per * world - batch
         partials_t = torch.cat([partials_t, partials_t[:, -1:].expand(-1, pad, -1)], dim=1)
-    msg, status = engine.combine_t(partials_t[:, rank * per : (rank + 1) * per].contiguous(), n, theta_inv)
-    return _gather_rows(msg, world, group)[:batch], _gather_rows(status, world, group)[:batch]
+    packed = engine.combine_t(partials_t[:, rank * per : (rank + 1) * per].contiguous(), n, theta_inv, packed=True)
+    full = _gather_rows(packed, world, group)[:batch]
+    return full[:, :-1].contiguous(), full[:, -1].to(torch.uint8)
+
+
+def sharded_biprime_v(engine: Any, g_t, mods: Sequence[int], exps: Sequence[int], group_size: int, keep: int,
+                      group: Any = None):
+    """The v-calculation of a keygen round (distributed_keygen.py:1084-1099 looped at :1313-1329) with
+    the candidates split contiguously across ranks: every rank runs the fused Jacobi filter ->
+    selection of the first `keep` generators -> `keep` modexps on ITS candidates
+    (``engine.biprime_v_t``; a candidate's modulus, exponent and generators stay on one GPU), then ONE
+    all-gather whose rows carry a candidate's `keep` v values and its count of valid ones.
+    g_t: int32 [groups*group_size, limbs].  Returns (v rows [groups*keep, limbs], counts [groups])."""
+    rank, world = _world(group)
+    if world == 1:
+        return engine.biprime_v_t(g_t, list(mods), list(exps), group_size, keep)
+    import torch
+
+    groups = len(mods)
+    limbs = g_t.shape[1]
+    per = -(-groups // world)
+    mods_p = list(mods) + [mods[-1]] * (per * world - groups)
+    exps_p = list(exps) + [exps[-1]] * (per * world - groups)
+    padded = _pad_rows(g_t, per * world * group_size)
+    lo = rank * per
+    v_t, cnt_t = engine.biprime_v_t(
+        padded[lo * group_size : (lo + per) * group_size].contiguous(), mods_p[lo : lo + per], exps_p[lo : lo + per],
+        group_size, keep,
+    )
+    row = torch.cat([v_t.reshape(per, keep * limbs), cnt_t.reshape(per, 1).to(v_t.dtype)], dim=1)
+    full = _gather_rows(row, world, group)[:groups]
+    return full[:, : keep * limbs].reshape(groups * keep, limbs).contiguous(), full[:, -1].contiguous()
 
 
 def sharded_biprime_vote(engine: Any, v_t, mods: Sequence[int], group: Any = None):

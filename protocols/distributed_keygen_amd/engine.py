@@ -292,13 +292,16 @@ class Engine:
         _lib.check(rc, "mx_powmod_nsquare_run")
         return out_t
 
-    def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int) -> List[int]:
+    def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int, keep_rows: bool = False):
         """[pow_mod(b, exp, n*n) for b in bases] through the N-adic pair kernel.  Sequences of
         PIPELINE_MIN elements or more are cut into chunks that run on several streams: the chunks
         together fill the machine (one 10 000-element launch occupies 61 % of the SIMDs), and the
-        packing of chunk k+1 and the PCIe copies overlap the modexps of chunk k."""
+        packing of chunk k+1 and the PCIe copies overlap the modexps of chunk k.
+        With ``keep_rows`` the result is ``(ints, rows)`` where ``rows`` is the device-resident copy of
+        the results (an opaque column for ``combine_columns``: the party's own partial decryptions go
+        into the recombination without being packed a second time)."""
         if len(bases) == 0:
-            return []
+            return ([], None) if keep_rows else []
         _check_modulus(n)
         n2 = n * n
         limbs2 = _limbs.limbs_for(n2)
@@ -309,13 +312,23 @@ class Engine:
             t0 = _t.perf_counter()
             rows = _limbs.pack(vals, limbs2)
             t1 = _t.perf_counter()
-            out = self.to_host(self.powmod_nsquare_t(self.to_device(rows), n, exp))
+            out_t = self.powmod_nsquare_t(self.to_device(rows), n, exp)
+            out = self.to_host(out_t)
             t2 = _t.perf_counter()
             res = _limbs.unpack(out)
             self.last_timing = {"chunks": 1, "pack_s": t1 - t0, "copies_and_gpu_s": t2 - t1, "unpack_s": _t.perf_counter() - t2}
-            return res
+            return (res, out_t) if keep_rows else res
         self.nsquare_plan(n, exp)          # prepared once, before the chunks fan out over streams
-        return self._pipelined(vals, limbs2, limbs2, lambda t: self.powmod_nsquare_t(t, n, exp))
+        kept: List[Any] = []
+
+        def launch(t):
+            out_t = self.powmod_nsquare_t(t, n, exp)
+            if keep_rows:
+                kept.append(out_t)
+            return out_t
+
+        res = self._pipelined(vals, limbs2, limbs2, launch)
+        return (res, self.torch.cat(kept, dim=0)) if keep_rows else res
 
     # ------------------------------------------------------------------ chunked execution on several streams
     PIPELINE_MIN = 20000       # elements from which an int-level batch is cut into chunks
@@ -495,6 +508,90 @@ class Engine:
         g_t = self.to_device(_limbs.pack([(1 + (m % n) * n) % n2 for m in messages], limbs))
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, g_t, n2, out_t=rn_t)))
 
+    # ------------------------------------------------------------------ Shamir field of the key generation
+    def shamir_fma_t(self, a_t, b_t, c_t, prime: int, out_t=None):
+        """out[e] = (a[e]*b[e] + c[e]) mod prime — this party's share of every candidate modulus
+        (`p * q` then `+= zero`, DK:1274-1277); int32 rows [batch, limbs]."""
+        batch, limbs = a_t.shape
+        if tuple(b_t.shape) != (batch, limbs) or tuple(c_t.shape) != (batch, limbs):
+            raise ValueError("operands must have the same shape")
+        _check_modulus(prime)
+        h_mod = _limbs.pack_one(prime, limbs)
+        if out_t is None:
+            out_t = self.torch.empty_like(a_t)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_field_workspace_bytes(limbs, 0))
+            rc = self.lib.mx_fma_mod(
+                a_t.data_ptr(), b_t.data_ptr(), c_t.data_ptr(), out_t.data_ptr(), h_mod.ctypes.data, limbs, batch,
+                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_fma_mod")
+        return out_t
+
+    def shamir_lincomb_t(self, x_t, coeffs: Sequence[int], prime: int, out_t=None):
+        """out[e] = sum_t coeffs[t] * x[t][e] mod prime; x_t int32 [terms, batch, limbs].  With the
+        Lagrange coefficients at 0 this is `candidate_n.reconstruct()` (DK:1284) for a whole round; the
+        result rows are the candidate moduli, ready for sieve_t / biprime_v_t on the device."""
+        terms, batch, limbs = x_t.shape
+        if len(coeffs) != terms:
+            raise ValueError("one coefficient per term expected")
+        _check_modulus(prime)
+        h_mod = _limbs.pack_one(prime, limbs)
+        h_cf = _limbs.pack([c % prime for c in coeffs], limbs)
+        if out_t is None:
+            out_t = self.torch.empty((batch, limbs), dtype=self.torch.int32, device=self.device)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_field_workspace_bytes(limbs, terms))
+            rc = self.lib.mx_lincomb_mod(
+                x_t.data_ptr(), h_cf.ctypes.data, out_t.data_ptr(), h_mod.ctypes.data, limbs, terms, batch,
+                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_lincomb_mod")
+        return out_t
+
+    def shamir_fma_batch(self, a: Sequence[int], b: Sequence[int], c: Sequence[int], prime: int) -> List[int]:
+        if not (len(a) == len(b) == len(c)):
+            raise ValueError("operands must have the same length")
+        if len(a) == 0:
+            return []
+        limbs = _limbs.limbs_for(prime)
+        ts = [self.to_device(_limbs.pack([_reduce(v, prime) for v in col], limbs)) for col in (a, b, c)]
+        return _limbs.unpack(self.to_host(self.shamir_fma_t(ts[0], ts[1], ts[2], prime)))
+
+    def shamir_lincomb_batch(self, columns: Sequence[Sequence[int]], coeffs: Sequence[int], prime: int) -> List[int]:
+        """[sum_t coeffs[t] * columns[t][e] mod prime for e]; one column per term."""
+        if len(columns) == 0 or len(columns[0]) == 0:
+            return []
+        if any(len(c) != len(columns[0]) for c in columns):
+            raise ValueError("columns must have the same length")
+        limbs = _limbs.limbs_for(prime)
+        x = np.stack([_limbs.pack([_reduce(v, prime) for v in col], limbs) for col in columns])
+        return _limbs.unpack(self.to_host(self.shamir_lincomb_t(self.to_device(x), coeffs, prime)))
+
+    def shamir_reconstruct_sieve_batch(self, columns: Sequence[Sequence[int]], coeffs: Sequence[int], prime: int,
+                                       primes: Sequence[int]) -> Tuple[List[bool], Dict[int, int]]:
+        """The candidate moduli of a round and their small-prime verdicts in one device pass
+        (DK:1284 + DK:1288-1292): reconstruction rows go straight into the sieve; only the verdict bytes
+        and the moduli of the SURVIVORS (~2 % of a round) come back to the host.
+        Returns (has_small_divisor per candidate, {candidate index: modulus} for the survivors)."""
+        if len(columns) == 0 or len(columns[0]) == 0:
+            return [], {}
+        limbs = _limbs.limbs_for(prime)
+        x = np.stack([_limbs.pack([_reduce(v, prime) for v in col], limbs) for col in columns])
+        mods_t = self.shamir_lincomb_t(self.to_device(x), coeffs, prime)
+        primes = [int(q) for q in primes]
+        if len(primes) == 0:
+            bad = np.zeros(mods_t.shape[0], dtype=np.uint8)
+        else:
+            bad = self.sieve_t(mods_t, primes).cpu().numpy()
+        keep = np.nonzero(bad == 0)[0]
+        survivors: Dict[int, int] = {}
+        if len(keep):
+            idx = self.torch.from_numpy(keep.astype(np.int64)).to(self.device)
+            vals = _limbs.unpack(self.to_host(mods_t.index_select(0, idx)))
+            survivors = {int(k): v for k, v in zip(keep, vals)}
+        return [bool(b) for b in bad], survivors
+
     # ------------------------------------------------------------------ Jacobi symbol
     def jacobi_t(self, values_t, mods, group_size: int, out_t=None):
         """int8 [groups*group_size]: Jacobi symbol (values[g*group_size+k] / mods[g]) (DK:1089).
@@ -658,6 +755,38 @@ class Engine:
         limbs2 = _limbs.limbs_for(n2)
         rows = np.stack([_limbs.pack([_reduce(p[i], n2) for p in partials], limbs2) for i in range(n_partials)])
         out_t, status_t = self.combine_t(self.to_device(rows), n, theta_inv)
+        ok = [not bool(x) for x in status_t.cpu().numpy()]
+        return _limbs.unpack(self.to_host(out_t)), ok
+
+    def combine_columns(self, columns: Sequence[Any], n: int, theta_inv: int) -> Tuple[List[int], List[bool]]:
+        """Share recombination from one COLUMN per player (players 1..degree+1 in order): a column is the
+        device rows kept by ``powmod_nsquare_batch(..., keep_rows=True)`` or a received list of partial
+        decryptions (plain ints or wire-form ``{"type": "int", "data": bytes}`` entries, DK:496-505) —
+        received values reach the device through codec.rows_from_wire, i.e. without a per-element
+        Python conversion and without the per-ciphertext dictionaries of DK:477-505.
+        Returns (messages, ok) like ``combine_batch``."""
+        from . import codec
+
+        if len(columns) == 0:
+            return [], []
+        _check_modulus(n)
+        n2 = n * n
+        limbs2 = _limbs.limbs_for(n2)
+        torch = self.torch
+        cols = []
+        for col in columns:
+            if hasattr(col, "data_ptr"):
+                if col.shape[1] != limbs2:
+                    raise ValueError("device column of the wrong row width")
+                cols.append(col)
+            else:
+                cols.append(self.to_device(codec.rows_from_wire(col, limbs2, modulus=n2)))
+        batch = cols[0].shape[0]
+        if any(c.shape[0] != batch for c in cols):
+            raise ValueError("every player's column needs one partial decryption per ciphertext")
+        if batch == 0:
+            return [], []
+        out_t, status_t = self.combine_t(torch.stack(cols, dim=0), n, theta_inv)
         ok = [not bool(x) for x in status_t.cpu().numpy()]
         return _limbs.unpack(self.to_host(out_t)), ok
 

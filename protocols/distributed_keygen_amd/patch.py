@@ -6,8 +6,9 @@ script uses at scripts/bench_batch_size.py:94-110):
   PaillierSharedKey.partial_decrypt / .decrypt           paillier_shared_key.py:52-127
       -> GPU-backed, plus new .partial_decrypt_batch / .decrypt_batch
   DistributedPaillier._decrypt_sequence_raw              distributed_keygen.py:430-517
-      -> same message flow (the reference's own coroutine still runs), but its two loops
-         (:463-466 partial decryptions, :510-515 recombinations) execute as ONE launch each
+      -> same receivers logic, message id and message content, with its two loops (:463-466 partial
+         decryptions, :510-515 recombinations) executed as ONE launch each; received partial
+         decryptions go to the device column-wise (codec.rows_from_wire), the party's own stay there
   DistributedPaillier.__small_prime_divisors_test        :1197-1209
   DistributedPaillier.__biprime_test_v_calculation       :1056-1108
   DistributedPaillier.__biprime_test_with_v_i            :1110-1175
@@ -26,7 +27,7 @@ from __future__ import annotations
 import importlib
 from typing import Any, Dict, Iterable, List, Optional
 
-from . import biprime
+from . import biprime, shamir
 from .shared_key import GpuPaillierSharedKey
 
 DEFAULT_PACKAGE = "tno.mpc.protocols.distributed_keygen"
@@ -39,6 +40,32 @@ def _save(cls: Any, name: str) -> None:
         _saved[cls][name] = cls.__dict__.get(name, None)
 
 
+# Engine limits that the reference does not have (include/mxpaillier.h); checked once at install time
+# and again at the start of compute_modulus, before any message of a keygen round has been exchanged.
+MAX_SIEVE_PRIME = (1 << 21) - 1          # mx_sieve: primes < 2^21
+MAX_JACOBI_BITS = 129 * 32               # mx_jacobi: moduli up to 129 words (key_length <= 4096)
+
+
+def check_limits(engine: Any = None, prime_list: Optional[Iterable[int]] = None, prime_length: Optional[int] = None,
+                 n_parties: int = 0) -> None:
+    """Raises ValueError (before any network round) when a keygen with these parameters would hit an
+    engine limit in the middle of ``compute_modulus``."""
+    if prime_list is not None:
+        top = max(prime_list, default=0)
+        if top > MAX_SIEVE_PRIME:
+            raise ValueError(
+                f"prime_threshold too large for the GPU sieve: largest prime {top} > {MAX_SIEVE_PRIME} "
+                "(use prime_threshold < 2^21, or uninstall the patch for this key generation)")
+    if prime_length is not None:
+        # candidate moduli have 2 * (prime_length + ceil(log2(parties))) bits at most (DK:874-876)
+        extra = max(1, (max(1, n_parties) - 1).bit_length())
+        bits = 2 * (prime_length + extra)
+        if bits > MAX_JACOBI_BITS:
+            raise ValueError(
+                f"key_length {2 * prime_length} gives candidate moduli of up to {bits} bits; the GPU Jacobi kernel "
+                f"takes {MAX_JACOBI_BITS} (key_length <= 4096)")
+
+
 def _gpu_key(key: Any, engine: Any) -> GpuPaillierSharedKey:
     cached = getattr(key, "_mx_gpu_key", None)
     if cached is None or cached.n != key.n or cached.share is not key.share:
@@ -47,17 +74,17 @@ def _gpu_key(key: Any, engine: Any) -> GpuPaillierSharedKey:
     return cached
 
 
-class _Deferred(int):
-    """Placeholder returned by PaillierSharedKey.decrypt while a sequence is being recombined."""
-
-
 def install(engine: Any = None, package: str = DEFAULT_PACKAGE) -> None:
     psk_mod = importlib.import_module(package + ".paillier_shared_key")
     dk_mod = importlib.import_module(package + ".distributed_keygen")
     PSK = psk_mod.PaillierSharedKey
     DP = dk_mod.DistributedPaillier
+    check_limits(engine)
 
     # ------------------------------------------------------------------ PaillierSharedKey
+    # The scalar methods keep the reference's semantics and hold NO state between calls: any number of
+    # decrypt() / decrypt_sequence() coroutines may interleave on one scheme (they have distinct
+    # message ids in the reference, DK:352-355 / DK:469-475).
     def partial_decrypt_batch(self: Any, ciphertexts: Iterable[Any]) -> List[int]:
         return _gpu_key(self, engine).partial_decrypt_batch(ciphertexts)
 
@@ -65,16 +92,9 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE) -> None:
         return _gpu_key(self, engine).decrypt_batch(partial_dicts)
 
     def partial_decrypt(self: Any, ciphertext: Any) -> int:
-        cache = getattr(self, "_mx_partial_cache", None)
-        if cache is not None and id(ciphertext) in cache:
-            return cache.pop(id(ciphertext))
         return partial_decrypt_batch(self, [ciphertext])[0]
 
     def decrypt(self: Any, partial_dict: Dict[int, int]) -> int:
-        pending = getattr(self, "_mx_pending_combines", None)
-        if pending is not None:
-            pending.append(partial_dict)
-            return _Deferred(len(pending) - 1)
         return decrypt_batch(self, [partial_dict])[0]
 
     for name, fn in (
@@ -88,28 +108,40 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE) -> None:
 
     # ------------------------------------------------------------------ decrypt_sequence
     _save(DP, "_decrypt_sequence_raw")
-    original_sequence = _saved[DP]["_decrypt_sequence_raw"]
+    EncodedPlaintext = dk_mod.EncodedPlaintext
 
     async def _decrypt_sequence_raw(self: Any, ciphertext_sequence: Iterable[Any], receivers: Optional[List[str]] = None):
+        """DK:430-517 with the same receivers logic (:447-461), message id (:469-475) and message content
+        (:476-483); all state is local to this call."""
         sequence = list(ciphertext_sequence)
-        key = self.secret_key
-        # loop DK:463-466 as one launch; the reference's coroutine then finds every result cached
-        partials = key.partial_decrypt_batch(sequence)
-        key._mx_partial_cache = {id(c): p for c, p in zip(sequence, partials)}
-        key._mx_pending_combines = []
-        try:
-            result = await original_sequence(self, sequence, receivers)
-            pending = key._mx_pending_combines
-        finally:
-            key._mx_partial_cache = None
-            key._mx_pending_combines = None
-        if result is not None and pending:
-            # loop DK:510-515 as one launch; fill the placeholders the coroutine wrapped
-            messages = key.decrypt_batch(pending)
-            for encoded in result:
-                if isinstance(encoded.value, _Deferred):
-                    encoded.value = messages[int(encoded.value)]
-        return result
+        if receivers is not None:
+            self_receive = "self" in receivers
+            receivers_without_self = [recv for recv in receivers if recv != "self"] if self_receive else receivers
+        else:
+            self_receive = True
+            receivers_without_self = receivers
+        key = _gpu_key(self.secret_key, engine)
+        # loop DK:463-466 as one launch; the results also stay on the device as this party's column
+        partially_decrypted_shares, own_column = key.partial_decrypt_batch(sequence, keep_rows=True)
+        encryption_hash = bin(next(iter(sequence)).peek_value()).zfill(32)[2:34] + f"{len(partially_decrypted_shares)}"
+        message_id = f"distributed_decryption_session#{self.session_id}_hash#{encryption_hash}"
+        if receivers_without_self is None or len(receivers_without_self) != 0:
+            self.pool.async_broadcast(
+                {"content": "partial_decryption_sequence", "value": partially_decrypted_shares},
+                msg_id=message_id,
+                handler_names=receivers_without_self,
+            )
+        if not self_receive:
+            return None
+        columns: Dict[int, Any] = {self.index: own_column}
+        for party, message in await self.pool.recv_all(msg_id=message_id):
+            msg_content = message["content"]
+            err_msg = f"received a share for {msg_content}, but expected partial_decryption_sequence"
+            assert msg_content == "partial_decryption_sequence", err_msg
+            columns[self.party_indices[party]] = message["value"]      # ints or wire-form integers, as received
+        # loop DK:510-515 as one launch
+        plaintexts = key.decrypt_columns(columns, len(sequence))
+        return [EncodedPlaintext(m, scheme=self) for m in plaintexts]
 
     setattr(DP, "_decrypt_sequence_raw", _decrypt_sequence_raw)
 
@@ -160,6 +192,7 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE) -> None:
         cls: Any, shares, index, pool, prime_list, party_indices, prime_length, shamir_scheme_t,
         shamir_scheme_2t, correct_param_biprime, session_id, batch_size: int = 1,
     ) -> int:
+        check_limits(engine, prime_list, prime_length, len(party_indices))
         sieved_out = biprime_rejected = rounds = 0
         sid = f"distributed_keygen_session#{session_id}"
         while True:
@@ -171,11 +204,17 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE) -> None:
             candidate_n = p_sh * q_sh
             candidate_n += zero
             await exchange_reconstruct(candidate_n, index, pool, party_indices, msg_id=f"{sid}_n_{rounds}")
-            moduli = candidate_n.reconstruct()
-            # DK:1288-1292 as one launch
-            has_divisor = biprime.small_prime_divisors_test_batch(prime_list, moduli, engine)
-            survivors = [k for k, bad in enumerate(has_divisor) if not bad]
-            sieved_out += len(moduli) - len(survivors)
+            # DK:1284 (`candidate_n.reconstruct()`) and DK:1288-1292 (the sieve) as one device pass: Lagrange
+            # interpolation of all candidates in one launch, rows straight into the sieve, only the
+            # survivors' moduli become Python ints
+            share_table = [v.get_shares() for v in candidate_n.variables]
+            scheme_n = candidate_n.variables[0].shamir_scheme           # degree 2t after the product (UT:248)
+            by_party = {i: [tbl[i] for tbl in share_table] for i in sorted(share_table[0])}
+            has_divisor, surviving = shamir.reconstruct_and_sieve_batch(
+                by_party, scheme_n.modulus, scheme_n.polynomial_degree, prime_list, engine)
+            survivors = sorted(surviving)
+            moduli = surviving                                          # candidate index -> modulus, survivors only
+            sieved_out += len(has_divisor) - len(survivors)
             if not survivors:
                 continue
             g_values = await getattr(cls, mangled + "biprime_test_g_generation")(

@@ -21,10 +21,14 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Any, Dict, Iterable, List, Optional, Sequence
 
-try:  # the reference's ciphertext type, when its (un-vendored) package is installed
-    from tno.mpc.encryption_schemes.paillier.paillier import PaillierCiphertext as _RefCiphertext  # type: ignore
-except Exception:  # pragma: no cover - not installed in the build image
-    _RefCiphertext = None
+def _ref_ciphertext_type() -> Any:
+    """The reference's ciphertext type, when its (un-vendored) package is importable in this process."""
+    try:
+        from tno.mpc.encryption_schemes.paillier.paillier import PaillierCiphertext  # type: ignore
+
+        return PaillierCiphertext
+    except Exception:  # not installed in the build image
+        return None
 
 
 @dataclass
@@ -80,27 +84,33 @@ class GpuPaillierSharedKey:
         return (self.share.n_fac * numerator * self.share.shares[self.player_id]) // denominator
 
     def _check_ciphertext(self, ciphertext: Any) -> None:
-        is_ct = isinstance(ciphertext, _RefCiphertext) if _RefCiphertext is not None else (
-            hasattr(ciphertext, "get_value") and hasattr(ciphertext, "scheme")
+        ref_type = _ref_ciphertext_type()
+        is_ct = isinstance(ciphertext, PlainCiphertext) or (
+            isinstance(ciphertext, ref_type) if ref_type is not None
+            else (hasattr(ciphertext, "get_value") and hasattr(ciphertext, "scheme"))
         )
         if not is_ct:  # PSK:62-65
             raise TypeError(f"Expected ciphertext to be a PaillierCiphertext not: {type(ciphertext)}")
         if self.n != ciphertext.scheme.public_key.n:  # PSK:67-68
             raise ValueError("encrypted against a different key!")
 
-    def partial_decrypt_batch(self, ciphertexts: Iterable[Any]) -> List[int]:
-        """[self.partial_decrypt(c) for c in ciphertexts] as one GPU batch (DK:463-466)."""
+    def partial_decrypt_batch(self, ciphertexts: Iterable[Any], keep_rows: bool = False):
+        """[self.partial_decrypt(c) for c in ciphertexts] as one GPU batch (DK:463-466).  With
+        ``keep_rows`` returns ``(ints, column)``: the column is the engine's device-resident copy of
+        the results for ``decrypt_columns`` (the party's own share of the recombination)."""
         values: List[int] = []
         for ciphertext in ciphertexts:
             self._check_ciphertext(ciphertext)
             values.append(ciphertext.get_value())  # get_value(), not peek_value(): PSK:69
         if not values:
-            return []
+            return ([], None) if keep_rows else []
         exp = self.lagrange_exponent()
         if exp < 0:  # PSK:89-91, as one product-tree inversion on the device
             values = self.engine.modinv_batch(values, self.n_square)
             exp = -exp
         # PSK:92, pow_mod(c, exp, n_square): modulo N^2 through pairs modulo N (mx_powmod_nsquare)
+        if keep_rows:
+            return self.engine.powmod_nsquare_batch(values, exp, self.n, keep_rows=True)
         return self.engine.powmod_nsquare_batch(values, exp, self.n)
 
     def partial_decrypt(self, ciphertext: Any) -> int:
@@ -128,6 +138,34 @@ class GpuPaillierSharedKey:
     def decrypt(self, partial_dict: Dict[int, int]) -> int:
         """PSK:95-127."""
         return self.decrypt_batch([partial_dict])[0]
+
+    def decrypt_columns(self, columns: Dict[int, Any], count: int) -> List[int]:
+        """The loop DK:510-515 over ``count`` ciphertexts with the partial decryptions given per PLAYER
+        instead of per ciphertext: ``columns[player]`` is that player's list of partial decryptions
+        in ciphertext order as received (ints or wire-form integers, DK:496-505), or the column kept by
+        ``partial_decrypt_batch(..., keep_rows=True)`` for this party's own.  Same results and
+        exceptions as ``[self.decrypt({p: col[k] for p, col in columns.items()}) for k in range(count)]``:
+        KeyError when a needed player (1..degree+1, PSK:108-110) has no value for some ciphertext,
+        ValueError when a combination is not 1 modulo N (PSK:119-123)."""
+        needed = [i + 1 for i in range(self.share.degree + 1)]
+        if count == 0:
+            return []
+        cols = []
+        for player in needed:
+            col = columns.get(player)
+            if col is None:
+                raise KeyError(player)          # shares_dict[player], PSK:110
+            length = col.shape[0] if hasattr(col, "shape") else len(col)
+            if length < count:                  # the zip of DK:503-505 left later ciphertexts without this share
+                raise KeyError(player)
+            cols.append(col[:count])
+        messages, ok = self.engine.combine_columns(cols, self.n, self.theta_inv)
+        if not all(ok):  # PSK:119-123
+            raise ValueError(
+                "Combined decryption minus one is not divisible by N. This might be caused by the "
+                "fact that the ciphertext that is being decrypted, differs between the parties."
+            )
+        return messages
 
     # ------------------------------------------------------------------ PSK:186-222
     def __eq__(self, other: object) -> bool:

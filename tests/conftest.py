@@ -46,3 +46,8 @@ def golden_decrypt_synth() -> dict:
 @pytest.fixture(scope="session")
 def golden_biprime() -> dict:
     return json.loads((GOLDEN / "biprime.json").read_text())
+
+
+@pytest.fixture(scope="session")
+def golden_reconstruct() -> dict:
+    return json.loads((GOLDEN / "reconstruct.json").read_text())

@@ -19,11 +19,20 @@ class FakeEngine:
             raise ValueError("negative exponent")
         return [oracle.pow_mod(b, exp, mod) for b in bases]
 
-    def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int) -> List[int]:
+    def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int, keep_rows: bool = False):
         self.calls.append(("powmod_batch", len(bases)))
         if exp < 0:
             raise ValueError("negative exponent")
-        return [oracle.pow_mod(b, exp, n * n) for b in bases]
+        out = [oracle.pow_mod(b, exp, n * n) for b in bases]
+        return (out, list(out)) if keep_rows else out          # the "device column" of the double is the list itself
+
+    def combine_columns(self, columns, n, theta_inv):
+        from protocols.distributed_keygen_amd import codec
+
+        batch = len(columns[0]) if columns else 0
+        n2 = n * n
+        cols = [[c % n2 for c in (codec.decode_int(v) for v in col)] for col in columns]
+        return self.combine_batch([[col[k] for col in cols] for k in range(batch)], n, theta_inv)
 
     def powmod_batch_multi(self, bases, exps, mods):
         self.calls.append(("powmod_batch_multi", sum(len(b) for b in bases)))
@@ -65,3 +74,17 @@ class FakeEngine:
                 row.append(vc[0][k] % m == prod % m or vc[0][k] % m == (-prod) % m)
             out.append(row)
         return out
+
+    def shamir_fma_batch(self, a, b, c, prime):
+        self.calls.append(("shamir_fma_batch", len(a)))
+        return [oracle.shamir_mul_add(x, y, z, prime) for x, y, z in zip(a, b, c)]
+
+    def shamir_lincomb_batch(self, columns, coeffs, prime):
+        self.calls.append(("shamir_lincomb_batch", len(columns[0]) if columns else 0))
+        return [sum(cf * col[e] for cf, col in zip(coeffs, columns)) % prime for e in range(len(columns[0]))]
+
+    def shamir_reconstruct_sieve_batch(self, columns, coeffs, prime, primes):
+        self.calls.append(("shamir_reconstruct_sieve_batch", len(columns[0]) if columns else 0))
+        mods = [sum(cf * col[e] for cf, col in zip(coeffs, columns)) % prime for e in range(len(columns[0]))]
+        bad = [oracle.small_prime_divisors_test(primes, m) for m in mods]
+        return bad, {k: m for k, (m, b) in enumerate(zip(mods, bad)) if not b}

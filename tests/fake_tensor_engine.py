@@ -32,7 +32,18 @@ class FakeTensorEngine:
     def sieve_t(self, cands_t, primes, out_t=None):
         return torch.tensor([int(oracle.small_prime_divisors_test(primes, c)) for c in _ints(cands_t)], dtype=torch.uint8)
 
-    def combine_t(self, partials_t, n, theta_inv, out_t=None, status_t=None):
+    def biprime_v_t(self, g_t, mods, exps, group_size, keep):
+        limbs = g_t.shape[1]
+        vals = _ints(g_t)
+        rows, counts = [], []
+        for c, (m, e) in enumerate(zip(mods, exps)):
+            gs = vals[c * group_size : (c + 1) * group_size]
+            kept = [g for g in gs if oracle.jacobi_symbol(g, m) == 1][:keep]
+            counts.append(len(kept))
+            rows += [oracle.pow_mod(g, e, m) for g in kept] + [oracle.pow_mod(0, e, m)] * (keep - len(kept))
+        return _rows(rows, limbs), torch.tensor(counts, dtype=torch.int32)
+
+    def combine_t(self, partials_t, n, theta_inv, out_t=None, status_t=None, packed=False):
         npart, batch, _ = partials_t.shape
         cols = [_ints(partials_t[i]) for i in range(npart)]
         msgs, status = [], []
@@ -43,6 +54,8 @@ class FakeTensorEngine:
             except ValueError:
                 msgs.append(0)
                 status.append(1)
+        if packed:
+            return torch.cat([_rows(msgs, L.limbs_for(n)), torch.tensor(status, dtype=torch.int32).reshape(-1, 1)], dim=1)
         return _rows(msgs, L.limbs_for(n)), torch.tensor(status, dtype=torch.uint8)
 
     def biprime_verdict_t(self, v_t, mods, pass_t=None):

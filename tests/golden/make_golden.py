@@ -20,6 +20,11 @@ What is recorded (all integers as hex strings):
   * biprime.json       — outputs of DistributedPaillier.__biprime_test_v_calculation,
                          __biprime_test_with_v_i and __small_prime_divisors_test on seeded
                          candidates (true biprimes and composites) at key_length 64/128/1024/2048.
+  * reconstruct.json   — the candidate-modulus step of a keygen round (DK:1262-1284) run by the
+                         reference itself: in-process parties over an in-memory pool execute its
+                         _generate_pq, `p * q`, `+= zero`, exchange_reconstruct and .reconstruct();
+                         recorded are every party's Shamir shares of p, q, zero and of the product
+                         (modulo the Shamir prime of DK:647-651) and the reconstructed moduli.
 
 Usage:  python tests/golden/make_golden.py
 """
@@ -567,6 +572,91 @@ def gen_biprime(dk) -> dict:
     return out
 
 
+# --------------------------------------------------------------------------- N reconstruction (DK:1262-1284)
+class _Hub:
+    def __init__(self, names):
+        self.names = names
+        self.box = {n: {} for n in names}
+
+
+class _MemPool:
+    """The calls of tno.mpc.communication.Pool that _generate_pq / exchange_* use, in memory."""
+
+    def __init__(self, hub, me):
+        self.hub, self.me = hub, me
+        self.pool_handlers = {n: None for n in hub.names if n != me}
+
+    def asend(self, party, message, msg_id=None):
+        self.hub.box[party].setdefault(msg_id, []).append((self.me, message))
+
+    def async_broadcast(self, message, msg_id=None, handler_names=None):
+        for n in (handler_names if handler_names is not None else self.pool_handlers):
+            self.hub.box[n].setdefault(msg_id, []).append((self.me, message))
+
+    async def recv_all(self, msg_id=None):
+        import asyncio
+
+        while len(self.hub.box[self.me].get(msg_id, [])) < len(self.pool_handlers):
+            await asyncio.sleep(0)
+        return tuple(self.hub.box[self.me].pop(msg_id))
+
+
+def gen_reconstruct(dk) -> dict:
+    import asyncio
+    import secrets as _secrets
+
+    DP = dk.DistributedPaillier
+    out = {}
+    for label, key_length, n_parties, t, batch in (
+        ("k64_n3_t1", 64, 3, 1, 6), ("k128_n5_t2", 128, 5, 2, 4), ("k1024_n3_t1", 1024, 3, 1, 3), ("k2048_n5_t2", 2048, 5, 2, 2),
+    ):
+        rng = random.Random(SEED + key_length * 7 + n_parties)
+        saved = (_secrets.randbits, _secrets.randbelow)
+        _secrets.randbits = rng.getrandbits
+        _secrets.randbelow = lambda n: rng.randrange(n)
+        dk.secrets.randbits = rng.getrandbits
+        try:
+            names = [f"p{i}" for i in range(1, n_parties + 1)]
+            hub = _Hub(names)
+            record = {}
+
+            async def party(i, me):
+                pool = _MemPool(hub, me)
+                party_indices = {("self" if n == me else n): k for k, n in enumerate(names, start=1)}
+                _, prime_length, _, sh_t, sh_2t, _ = DP.setup_input(pool, key_length, 200, t)
+                p_sh, q_sh, zero, _, _ = await DP._generate_pq(
+                    pool, i, prime_length, party_indices, sh_t, sh_2t, 99, batch_size=batch, msg_id=f"pq_{label}")
+                candidate_n = p_sh * q_sh                     # DK:1274
+                candidate_n += zero                           # DK:1277
+                mine = {
+                    "p": [v.get_share(i) for v in p_sh.variables], "q": [v.get_share(i) for v in q_sh.variables],
+                    "zero": [v.get_share(i) for v in zero.variables], "n": [v.get_share(i) for v in candidate_n.variables],
+                }
+                await dk.exchange_reconstruct(candidate_n, i, pool, party_indices, msg_id=f"n_{label}")   # DK:1281
+                moduli = candidate_n.reconstruct()            # DK:1284
+                record[i] = (mine, moduli, sh_t.modulus, [dict(v.get_shares()) for v in candidate_n.variables])
+
+            async def run():
+                await asyncio.gather(*[party(i, me) for i, me in enumerate(names, start=1)])
+
+            asyncio.run(run())
+        finally:
+            _secrets.randbits, _secrets.randbelow = saved
+            dk.secrets.randbits = saved[0]
+        moduli = record[1][1]
+        assert all(record[i][1] == moduli for i in record), "parties reconstructed different moduli"
+        prime = record[1][2]
+        assert int(prime) == int(sympy.nextprime(2 ** (2 * (key_length // 2 + math.ceil(math.log2(n_parties))))))   # DK:647-651
+        for i in record:                                       # every party saw the same share table
+            assert record[i][3] == record[1][3]
+        out[label] = {
+            "key_length": key_length, "n_parties": n_parties, "t": t, "degree": 2 * t, "prime": hx(int(prime)),
+            "shares": {str(i): {k: [hx(v) for v in vals] for k, vals in record[i][0].items()} for i in sorted(record)},
+            "moduli": [hx(m) for m in moduli],
+        }
+    return out
+
+
 def main() -> None:
     psk, dk = load_reference()
     os.makedirs(HERE, exist_ok=True)
@@ -574,6 +664,7 @@ def main() -> None:
         ("ref_keys.json", gen_ref_keys(psk)),
         ("decrypt_synth.json", gen_decrypt_synth(psk)),
         ("biprime.json", gen_biprime(dk)),
+        ("reconstruct.json", gen_reconstruct(dk)),
     ):
         (HERE / name).write_text(json.dumps(data, indent=0, sort_keys=True) + "\n")
         print("wrote", name, (HERE / name).stat().st_size, "bytes")

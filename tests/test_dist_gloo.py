@@ -74,6 +74,22 @@ def _worker(rank: int, world: int, port: int, ret) -> None:
         m_t, st = mxdist.sharded_combine(eng, pt, key.n, key.theta_inv)
         assert st.tolist() == [0, 0, 0, 1, 0]
         assert [m for m, s in zip(_ints(m_t), st.tolist()) if not s] == [3, 1, 4, 5]
+        # --- the v-calculation of a keygen round: 5 candidates x 12 generators, keep 4, over 2 ranks (ragged)
+        cm = [rng.getrandbits(130) | (1 << 129) | 1 for _ in range(5)]
+        ce = [rng.getrandbits(128) for _ in cm]
+        gens = [rng.randrange(m) for m in cm for _ in range(12)]
+        gens[12:24] = [0] * 12                                   # a candidate with no Jacobi-1 generator at all
+        v_t, cnt = mxdist.sharded_biprime_v(eng, _rows(gens, 5), cm, ce, 12, 4)
+        want_v, want_c = [], []
+        for c, (m, e) in enumerate(zip(cm, ce)):
+            kept = [g for g in gens[c * 12 : (c + 1) * 12] if oracle.jacobi_symbol(g, m) == 1][:4]
+            want_c.append(len(kept))
+            want_v += [pow(g, e, m) for g in kept] + [pow(0, e, m)] * (4 - len(kept))
+        assert cnt.tolist() == want_c and want_c[1] == 0 and _ints(v_t) == want_v
+        # --- a caller holding only its shard: single-GPU operator + all_gather_rows
+        lo, hi = mxdist.shard_bounds(7, dist.get_rank(), 2)
+        local = eng.powmod_shared_t(_rows(bases[lo:hi], L.limbs_for(mod)), mod, exp)
+        assert _ints(mxdist.all_gather_rows(local, 7)) == [pow(b, exp, mod) for b in bases]
         # --- biprimality vote
         m0 = (1 << 100) + 277
         v = torch.stack([_rows([5, 6, 7, 9, 2, 4], 4), _rows([5, m0 - 6, 8, 9, 2, 4], 4), _rows([1] * 6, 4)]).reshape(3, 3, 2, 4)

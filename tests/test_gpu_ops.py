@@ -263,3 +263,112 @@ def test_c_abi_from_plain_cpp(tmp_path):
     run = subprocess.run([str(exe)], capture_output=True, text=True, timeout=300)
     assert run.returncode == 0, run.stdout + run.stderr
     assert "identical through both kernels" in run.stdout
+
+
+# ------------------------------------------------------------------ Shamir field (DK:1274-1284)
+def test_shamir_field_kernels_golden(eng, golden_reconstruct):
+    """mx_fma_mod / mx_lincomb_mod against the values the reference itself produced in a keygen round."""
+    from protocols.distributed_keygen_amd import shamir
+
+    for label, grp in golden_reconstruct.items():
+        prime, degree = unhex(grp["prime"]), grp["degree"]
+        shares = {int(i): {k: [unhex(v) for v in vals] for k, vals in d.items()} for i, d in grp["shares"].items()}
+        for i, d in shares.items():
+            assert shamir.mul_add_shares_batch(d["p"], d["q"], d["zero"], prime, eng) == d["n"], (label, i)
+        assert shamir.reconstruct_batch({i: d["n"] for i, d in shares.items()}, prime, degree, eng) == [unhex(m) for m in grp["moduli"]]
+
+
+@pytest.mark.parametrize("bits,terms,batch", [(61, 3, 70), (133, 5, 33), (1030, 3, 129), (2054, 5, 64), (2054, 9, 17), (4102, 3, 9)])
+def test_shamir_field_kernels_random(eng, bits, terms, batch):
+    import sympy
+
+    rng = random.Random(bits * 13 + terms)
+    prime = int(sympy.nextprime(1 << bits))
+    a = [rng.randrange(prime) for _ in range(batch)]
+    b = [rng.randrange(prime) for _ in range(batch)]
+    c = [rng.randrange(prime) for _ in range(batch)]
+    a[0], b[0], c[0] = prime - 1, prime - 1, prime - 1
+    a[1], b[1], c[1] = 0, 5, 0
+    assert eng.shamir_fma_batch(a, b, c, prime) == [(x * y + z) % prime for x, y, z in zip(a, b, c)]
+    cols = [[rng.randrange(prime) for _ in range(batch)] for _ in range(terms)]
+    cols[0][0] = prime - 1
+    coeffs = [rng.randrange(prime) for _ in range(terms)]
+    coeffs[-1] = prime - 1
+    want = [sum(cf * col[e] for cf, col in zip(coeffs, cols)) % prime for e in range(batch)]
+    assert eng.shamir_lincomb_batch(cols, coeffs, prime) == want
+
+
+def test_reconstructed_moduli_stay_on_the_device_for_the_sieve(eng, golden_reconstruct):
+    """DK:1284-1292 without a host round trip: lincomb rows -> sieve_t."""
+    from protocols.distributed_keygen_amd import limbs as L, shamir
+
+    grp = golden_reconstruct["k1024_n3_t1"]
+    prime, degree = unhex(grp["prime"]), grp["degree"]
+    cols = [[unhex(v) for v in grp["shares"][str(i)]["n"]] for i in (1, 2, 3)]
+    limbs = L.limbs_for(prime)
+    import numpy as np
+
+    x_t = eng.to_device(np.stack([L.pack(c, limbs) for c in cols]))
+    mods_t = eng.shamir_lincomb_t(x_t, shamir.lagrange_coefficients_at_zero([1, 2, 3], prime), prime)
+    primes = oracle.small_prime_list(2000)
+    got = [bool(x) for x in eng.sieve_t(mods_t, primes).cpu().numpy()]
+    assert got == [oracle.small_prime_divisors_test(primes, unhex(m)) for m in grp["moduli"]]
+
+
+def test_combine_packed_rows_and_columns(eng, golden_decrypt_synth):
+    """mx_combine_run with the status packed into the row (one all-gather unit), and the column-wise
+    recombination the patched _decrypt_sequence_raw uses: device column + received ints + wire form."""
+    import numpy as np
+    import torch
+
+    from protocols.distributed_keygen_amd import codec, limbs as L
+
+    grp = golden_decrypt_synth["k1024_n3_t1"]
+    n = unhex(grp["n"])
+    n2 = n * n
+    theta_inv = pow(unhex(grp["theta"]), -1, n)
+    cases = grp["cases"]
+    cols = [[unhex(c["partials"][str(i)]) for c in cases] for i in (1, 2, 3)]
+    want = [unhex(c["m"]) for c in cases]
+    limbs2, limbs = L.limbs_for(n2), L.limbs_for(n)
+    bad_cols = [list(c) for c in cols]
+    bad_cols[1][1] = (bad_cols[1][1] + 1) % n2                      # one inconsistent ciphertext
+    pt = eng.to_device(np.stack([L.pack(c, limbs2) for c in bad_cols]))
+    packed = eng.combine_t(pt, n, theta_inv, packed=True)
+    assert tuple(packed.shape) == (len(cases), limbs + 1)
+    msg_t, st_t = eng.combine_t(pt, n, theta_inv)
+    assert torch.equal(packed[:, :limbs], msg_t) and packed[:, limbs].tolist() == [int(x) for x in st_t.tolist()]
+    assert st_t.tolist() == [0, 1] + [0] * (len(cases) - 2)
+    # columns: own partials kept on the device, one received as ints, one in wire form
+    e = oracle.partial_decrypt_exponent(1, grp["degree"], unhex(grp["n_fac"]), unhex(grp["shares"]["1"]))
+    cs = [unhex(c["c"]) for c in cases]
+    bases = cs if e >= 0 else [oracle.mod_inv(c, n2) for c in cs]
+    own, own_col = eng.powmod_nsquare_batch(bases, abs(e), n, keep_rows=True)
+    assert own == cols[0] and hasattr(own_col, "data_ptr")
+    msgs, ok = eng.combine_columns([own_col, cols[1], [codec.encode_int(v) for v in cols[2]]], n, theta_inv)
+    assert all(ok) and msgs == want
+    msgs, ok = eng.combine_columns([own_col, [v + 5 * n2 for v in cols[1]], [v - n2 for v in cols[2]]], n, theta_inv)
+    assert all(ok) and msgs == want                                  # un-reduced / negative representatives
+
+
+def test_chunked_int_level_batch_on_several_streams(eng):
+    """Engine._pipelined: an int-level batch above PIPELINE_MIN runs as chunks on side streams with
+    pinned staging; results, order and the kept device column equal the single-launch path."""
+    from protocols.distributed_keygen_amd import limbs as L
+
+    rng = random.Random(31337)
+    n = rng.getrandbits(515) | (1 << 514) | 1
+    n2 = n * n
+    e = rng.getrandbits(130) | 1
+    count = eng.PIPELINE_MIN + 1237
+    bases = [rng.randrange(n2) for _ in range(count)]
+    got, col = eng.powmod_nsquare_batch(bases, e, n, keep_rows=True)
+    assert eng.last_timing["chunks"] >= 4
+    idx = [0, 1, count // 2, count - 2, count - 1] + [rng.randrange(count) for _ in range(40)]
+    assert [got[k] for k in idx] == [pow(bases[k], e, n2) for k in idx]
+    assert L.unpack(eng.to_host(col)) == got
+    small = eng.powmod_nsquare_batch(bases[:5000], e, n)
+    assert small == got[:5000] and eng.last_timing["chunks"] == 1
+    # a second chunked call reuses streams, workspaces and pinned buffers
+    again = eng.powmod_nsquare_batch(bases, e, n)
+    assert again == got

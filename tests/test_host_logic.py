@@ -284,3 +284,96 @@ def test_public_header_is_plain_c():
         if shutil.which(compiler) is None:
             pytest.skip(f"{compiler} not installed")
         subprocess.run([compiler, "-fsyntax-only", "-Wall", "-Werror", *lang, header], check=True)
+
+
+def test_decrypt_columns_matches_the_per_ciphertext_loop(golden_decrypt_synth):
+    """GpuPaillierSharedKey.decrypt_columns (players' columns, as the patched _decrypt_sequence_raw
+    collects them) == [decrypt(dict) for every ciphertext], incl. wire-form integers, un-reduced and
+    negative values (reduced like mult_list(..., n_square) does), KeyError and ValueError."""
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import codec
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, ShareView
+
+    grp = golden_decrypt_synth["k128_n3_t1"]
+    n = unhex(grp["n"])
+    n2 = n * n
+    share = ShareView({int(i): unhex(s) for i, s in grp["shares"].items()}, grp["degree"], unhex(grp["n_fac"]))
+    key = GpuPaillierSharedKey(n, grp["t"], 1, share, unhex(grp["theta"]), engine=FakeEngine())
+    cases = grp["cases"]
+    cols = {i: [unhex(c["partials"][str(i)]) for c in cases] for i in (1, 2, 3)}
+    want = [unhex(c["m"]) for c in cases]
+    assert key.decrypt_columns(cols, len(cases)) == want
+    assert key.decrypt_columns(cols, 2) == want[:2] and key.decrypt_columns(cols, 0) == []
+    # wire form, un-reduced and negative representatives of the same residues
+    weird = dict(cols)
+    weird[2] = [codec.encode_int(v) for v in cols[2]]
+    weird[3] = [v + n2 if k % 2 else v - 3 * n2 for k, v in enumerate(cols[3])]
+    assert key.decrypt_columns(weird, len(cases)) == want
+    with pytest.raises(KeyError):
+        key.decrypt_columns({1: cols[1], 3: cols[3]}, len(cases))
+    with pytest.raises(KeyError):
+        key.decrypt_columns({1: cols[1], 2: cols[2][:1], 3: cols[3]}, len(cases))
+    bad = dict(cols)
+    bad[2] = [v + 1 for v in cols[2]]
+    with pytest.raises(ValueError):
+        key.decrypt_columns(bad, len(cases))
+
+
+def test_rows_from_wire_fast_path_and_reduction():
+    from protocols.distributed_keygen_amd import codec, limbs
+
+    vals = [0, 1, (1 << 200) - 1, 12345678901234567890]
+    rows = codec.rows_from_wire(vals, 8)
+    assert limbs.unpack(rows) == vals
+    mixed = [codec.encode_int(vals[2]), vals[3], codec.encode_int(0)]
+    assert limbs.unpack(codec.rows_from_wire(mixed, 8)) == [vals[2], vals[3], 0]
+    with pytest.raises(ValueError):
+        codec.rows_from_wire([-1], 8)
+    with pytest.raises(ValueError):
+        codec.rows_from_wire([1 << 300], 8)
+    m = (1 << 190) + 7
+    assert limbs.unpack(codec.rows_from_wire([-1, m + 5, codec.encode_int(-2), codec.encode_int(1 << 300)], 8, modulus=m)) == [
+        m - 1, 5, m - 2, (1 << 300) % m]
+    assert limbs.unpack(codec.rows_from_wire(codec.rows_to_wire(rows), 8)) == vals
+
+
+def test_c_codec_matches_int_to_bytes():
+    import random
+
+    from protocols.distributed_keygen_amd import limbs
+
+    assert limbs._mxcodec is not None, "the C codec (csrc/mx_pycodec.c) must be built with the library"
+    rng = random.Random(5)
+    vals = [0, 1, (1 << 4128) - 1] + [rng.getrandbits(rng.randrange(1, 4128)) for _ in range(200)]
+    rows = limbs.pack(vals, 129)
+    assert [int.from_bytes(r.tobytes(), "little") for r in rows] == vals
+    assert limbs.unpack(rows) == vals
+    out = np.zeros((len(vals) + 3, 129), dtype="<u4")
+    limbs.pack_into(vals, 129, out, 3)
+    assert limbs.unpack(out[3:]) == vals and not out[:3].any()
+    for bad in ([-5], [1 << 4128]):
+        with pytest.raises(ValueError):
+            limbs.pack(bad, 129)
+    with pytest.raises(ValueError):
+        limbs.pack_into(vals, 129, np.zeros((10, 129), dtype="<u4"), 0)      # buffer too small
+
+
+def test_shamir_mirror_matches_reference_vectors(golden_reconstruct):
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import shamir
+
+    eng = FakeEngine()
+    for label, grp in golden_reconstruct.items():
+        prime, degree = unhex(grp["prime"]), grp["degree"]
+        shares = {int(i): {k: [unhex(v) for v in vals] for k, vals in d.items()} for i, d in grp["shares"].items()}
+        for i, d in shares.items():
+            assert shamir.mul_add_shares_batch(d["p"], d["q"], d["zero"], prime, eng) == d["n"]
+        want = [unhex(m) for m in grp["moduli"]]
+        assert shamir.reconstruct_batch({i: d["n"] for i, d in shares.items()}, prime, degree, eng) == want
+        # any degree+1 shares determine the same polynomial: dropping surplus parties changes nothing
+        some = dict(list({i: d["n"] for i, d in shares.items()}.items())[-(degree + 1):])
+        assert shamir.reconstruct_batch(some, prime, degree, eng) == want
+        with pytest.raises(ValueError):
+            shamir.reconstruct_batch(dict(list(some.items())[1:]), prime, degree, eng)
+    assert shamir.reconstruct_batch({1: [], 2: [], 3: []}, 101, 2, eng) == []
+    assert shamir.lagrange_coefficients_at_zero([1, 2, 3], 101) == [3, 98, 1]

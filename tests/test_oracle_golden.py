@@ -112,3 +112,19 @@ def test_mult_list():
     assert oracle.mult_list([]) == 1
     assert oracle.mult_list([3, -4, 5]) == -60
     assert oracle.mult_list([3, 4, 5], 7) == 60 % 7
+
+
+def test_shamir_field_steps_match_reference(golden_reconstruct):
+    """DK:1274-1284 as the reference ran it (its own _generate_pq / Batched[ShamirVariable] flow over an
+    in-memory pool): every party's share of every candidate modulus, and the reconstructed moduli."""
+    for label, grp in golden_reconstruct.items():
+        prime, degree = unhex(grp["prime"]), grp["degree"]
+        shares = {int(i): {k: [unhex(v) for v in vals] for k, vals in d.items()} for i, d in grp["shares"].items()}
+        count = len(grp["moduli"])
+        for i, d in shares.items():
+            assert [oracle.shamir_mul_add(d["p"][k], d["q"][k], d["zero"][k], prime) for k in range(count)] == d["n"], (label, i)
+        for k in range(count):
+            assert oracle.shamir_reconstruct({i: d["n"][k] for i, d in shares.items()}, prime, degree) == unhex(grp["moduli"][k])
+        # the moduli have the documented size: sum of n shares of key_length/2 bits, squared (SURVEY hard part 1)
+        for m in grp["moduli"]:
+            assert grp["key_length"] <= unhex(m).bit_length() <= grp["key_length"] + 2 * (grp["n_parties"] - 1).bit_length() + 1

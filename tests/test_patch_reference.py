@@ -244,7 +244,111 @@ def test_compute_modulus_is_drop_in(ref):
         patch.uninstall()
     assert got == base
     kinds = {c[0] for c in eng.calls}
-    assert {"sieve_batch", "jacobi_batch", "powmod_batch_multi", "biprime_verdict_batch"} <= kinds
-    rounds = sum(1 for c in eng.calls if c[0] == "sieve_batch") // 3
-    assert all(c[1] == 40 for c in eng.calls if c[0] == "sieve_batch")      # whole round in one call
+    assert {"shamir_reconstruct_sieve_batch", "jacobi_batch", "powmod_batch_multi", "biprime_verdict_batch"} <= kinds
+    rounds = sum(1 for c in eng.calls if c[0] == "shamir_reconstruct_sieve_batch") // 3
+    # N reconstruction (DK:1284) + sieve (DK:1288-1292) of a whole round in one call
+    assert all(c[1] == 40 for c in eng.calls if c[0] == "shamir_reconstruct_sieve_batch")
     assert sum(1 for c in eng.calls if c[0] == "powmod_batch_multi") <= 3 * rounds
+
+
+def test_single_decrypt_interleaved_with_pending_sequence(ref):
+    """a single decrypt() running concurrently with a decrypt_sequence() on the
+    same scheme.  Party 1 starts a 3-element sequence and a single decryption; the other parties
+    answer the SINGLE first, so party 1's `_decrypt_raw` reaches PaillierSharedKey.decrypt while
+    its `_decrypt_sequence_raw` is still waiting in recv_all.  Both must return plaintext ints."""
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import patch
+
+    msgs = [11, 22, 33]
+    single = 44
+    patch.install(engine=FakeEngine())
+    try:
+        key, parties = _parties(ref, None)
+        cts = _ciphertexts(ref, key, msgs + [single])
+        seq_cts, single_ct = cts[:3], cts[3]
+
+        async def party1():
+            seq_task = asyncio.ensure_future(parties[0]._decrypt_sequence_raw(list(seq_cts)))
+            one_task = asyncio.ensure_future(parties[0]._decrypt_raw(single_ct))
+            return await asyncio.gather(seq_task, one_task)
+
+        async def other(dp):
+            one = await dp._decrypt_raw(single_ct)            # answers the single first ...
+            for _ in range(5):
+                await asyncio.sleep(0)
+            seq = await dp._decrypt_sequence_raw(list(seq_cts))   # ... and the sequence afterwards
+            return seq, one
+
+        async def run():
+            return await asyncio.gather(party1(), other(parties[1]), other(parties[2]))
+
+        for seq, one in asyncio.run(run()):
+            assert type(one.value) is int and one.value == single
+            assert [e.value for e in seq] == msgs and all(type(e.value) is int for e in seq)
+
+        # two overlapping sequences and a single, all on party 1, every interleaving of the answers
+        async def party1_three():
+            a = asyncio.ensure_future(parties[0]._decrypt_sequence_raw(list(seq_cts)))
+            b = asyncio.ensure_future(parties[0]._decrypt_sequence_raw([cts[1], cts[0]]))
+            c = asyncio.ensure_future(parties[0]._decrypt_raw(single_ct))
+            return await asyncio.gather(a, b, c)
+
+        async def other_three(dp, order):
+            # the three protocols run concurrently on every party; they are STARTED in different orders
+            tasks = {}
+            for what in order:
+                if what == "a":
+                    tasks["a"] = asyncio.ensure_future(dp._decrypt_sequence_raw(list(seq_cts)))
+                elif what == "b":
+                    tasks["b"] = asyncio.ensure_future(dp._decrypt_sequence_raw([cts[1], cts[0]]))
+                else:
+                    tasks["c"] = asyncio.ensure_future(dp._decrypt_raw(single_ct))
+                for _ in range(3):
+                    await asyncio.sleep(0)
+            return await asyncio.gather(tasks["a"], tasks["b"], tasks["c"])
+
+        async def run3():
+            return await asyncio.gather(party1_three(), other_three(parties[1], "cba"), other_three(parties[2], "bca"))
+
+        for a, b, c in asyncio.run(run3()):
+            assert [e.value for e in a] == msgs and [e.value for e in b] == [22, 11] and c.value == single
+    finally:
+        patch.uninstall()
+
+
+def test_patched_sequence_keeps_reference_error_behaviour(ref):
+    """A party that sends too few partial decryptions leaves later ciphertexts without its share: the
+    reference's loop raises KeyError at PSK:110 for them; so does the batched path."""
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import patch
+
+    patch.install(engine=FakeEngine())
+    try:
+        key, parties = _parties(ref, None)
+        cts = _ciphertexts(ref, key, [5, 6, 7])
+        orig_broadcast = parties[1].pool.async_broadcast
+
+        def short_broadcast(message, msg_id=None, handler_names=None):
+            message = dict(message, value=message["value"][:2])
+            orig_broadcast(message, msg_id=msg_id, handler_names=handler_names)
+
+        parties[1].pool.async_broadcast = short_broadcast
+
+        async def run():
+            return await asyncio.gather(*[dp._decrypt_sequence_raw(list(cts)) for dp in parties], return_exceptions=True)
+
+        res = asyncio.run(run())
+        assert isinstance(res[0], KeyError) and isinstance(res[2], KeyError)      # parties 1 and 3 miss share 2
+        assert [e.value for e in res[1]] == [5, 6, 7]                                # party 2 has everything
+    finally:
+        patch.uninstall()
+
+
+def test_limits_are_checked_before_any_round(ref):
+    from protocols.distributed_keygen_amd import patch
+
+    patch.check_limits(None, [3, 5, 1999], 1024, 3)
+    with pytest.raises(ValueError, match="prime_threshold"):
+        patch.check_limits(None, [3, 5, (1 << 21) + 7], 1024, 3)
+    with pytest.raises(ValueError, match="key_length"):
+        patch.check_limits(None, [3, 5], 2100, 3)

@@ -16,7 +16,7 @@ for every (L, nblk):
         — run it under  rocprofv3 --pmc SQ_INSTS_VALU --kernel-trace --output-format csv -d <dir>
   python3 tools/calibrate_instr.py fit   <configs.json> <dir> <model.json>
         — matches the dispatches to the configs in launch order, solves the 3x3 system from the first
-          three exponents and reports the residual of the fourth (a check of the linear model)
+          three exponents and reports the residual of the held-out fourth (a check of the linear model)
 
 The model is committed as profiles/r02_instr_model.json; bench.py reads it.
 """
@@ -54,8 +54,19 @@ def generic_counts(max_ebits: int, exp_limbs: int):
     return (ndigits - 1) * win, ((1 << win) - 2) + (ndigits - 1)
 
 
-def exponents(rng: random.Random):
-    return [1 << 191, (1 << 192) - 1, rng.getrandbits(192) | (1 << 191) | 1, rng.getrandbits(120) | (1 << 119) | 1]
+def exponents(rng: random.Random, kind: str):
+    """Four exponents per instance: three to fit (I_sqr, I_mul, F), the last one held out.
+    n2 (sliding window): the multiplication count follows the exponent's density, the squaring count
+    its length.  generic (fixed window): both follow the length only (every digit multiplies), and
+    the window width changes with it — three lengths with three different widths."""
+    def rnd(bits):
+        return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+
+    if kind == "n2":
+        return [(1 << 191, 0), ((1 << 192) - 1, 0), (rnd(120), 0), (rnd(192), 0)]
+    # (exponent, exponent row width in words): the row width selects the window (mx_host.hpp fixed_window),
+    # so a short exponent in wide rows has few squarings and a large table — what separates I_mul from I_sqr
+    return [(rnd(60), 65), (rnd(60), 2), (rnd(600), 19), (rnd(192), 6)]
 
 
 def run(cfg_path: str) -> None:
@@ -79,7 +90,7 @@ def run(cfg_path: str) -> None:
                 batch = WAVES * (64 // k)
                 eng.set_limbs_per_lane(L)
                 n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
-                for e in exponents(rng):
+                for e, erow in exponents(rng, kind):
                     if kind == "n2":
                         assert eng.nsquare_geometry(bits, batch) == (k, L, W, nblk)
                         n2 = n * n
@@ -93,9 +104,9 @@ def run(cfg_path: str) -> None:
                         groups = 2
                         mods = [n, n - 2]
                         rows = eng.to_device(Lm.pack([rng.randrange(n - 2) for _ in range(batch * groups)], Lm.limbs_for(n)))
-                        exps = [e, e - 2]
+                        exps = (eng.to_device(Lm.pack([e, e - 2], erow)), e.bit_length())
                         eng.powmod_multi_t(rows, mods, exps, batch)
-                        nsq, nmu = generic_counts(e.bit_length(), Lm.limbs_for(e))
+                        nsq, nmu = generic_counts(e.bit_length(), erow)
                         configs.append({"kind": kind, "L": L, "nblk": nblk, "K": k, "waves": WAVES * groups,
                                         "n_sqr": nsq, "n_mul": nmu})
                 eng.synchronize()
@@ -137,9 +148,10 @@ def fit(cfg_path: str, pmc_dir: str, model_path: str) -> None:
         for i in range(0, len(cfgs), 4):
             grp = cfgs[i : i + 4]
             per_wave = [d[i + j][1] / grp[j]["waves"] for j in range(4)]
-            sol = solve3([[g["n_sqr"], g["n_mul"], 1] for g in grp[:3]], per_wave[:3])
-            pred = sol[0] * grp[3]["n_sqr"] + sol[1] * grp[3]["n_mul"] + sol[2]
-            resid = abs(pred - per_wave[3]) / per_wave[3]
+            fit_rows, held = (0, 1, 2), 3
+            sol = solve3([[grp[j]["n_sqr"], grp[j]["n_mul"], 1] for j in fit_rows], [per_wave[j] for j in fit_rows])
+            pred = sol[0] * grp[held]["n_sqr"] + sol[1] * grp[held]["n_mul"] + sol[2]
+            resid = abs(pred - per_wave[held]) / per_wave[held]
             model["max_residual"] = max(model["max_residual"], resid)
             model[kind][str(grp[0]["L"])][str(grp[0]["nblk"])] = [round(sol[0], 2), round(sol[1], 2), round(sol[2], 1)]
     Path(model_path).write_text(json.dumps(model, indent=0))
