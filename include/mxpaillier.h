@@ -208,6 +208,17 @@ int mx_fma_mod(const uint32_t* d_a, const uint32_t* d_b, const uint32_t* d_c, ui
 int mx_lincomb_mod(const uint32_t* d_x, const uint32_t* h_coeffs, uint32_t* d_out, const uint32_t* h_mod, int limbs,
                    int terms, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
 
+/* ---- modular inverse ------------------------------------------------------------------------
+ * d_out[e] = d_values[e]^-1 mod h_mod, d_status[e] = 0; or d_out[e] = 0, d_status[e] = 1 when
+ * gcd(value, modulus) != 1 (where `pow(v, -1, m)` raises ValueError).  Replaces `mod_inv(theta, n)`
+ * of a key (PSK:50) and — as the root of a product tree of mx_mulmod_shared launches (Montgomery's
+ * trick: 3 multiplications per element) — `mod_inv(ciphertext_value, n_square)` per ciphertext for
+ * a negative Lagrange exponent (PSK:89-91).  One wavefront per element (the big integers are spread
+ * over its 64 lanes): meant for a handful of elements, ~1-4 ms each at 2048-8200 bits. */
+int64_t mx_modinv_workspace_bytes(int limbs);
+int mx_modinv(const uint32_t* d_values, uint32_t* d_out, uint8_t* d_status, const uint32_t* h_mod, int limbs,
+              int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- Jacobi symbol ---------------------------------------------------------------------
  * d_out[g*group_size + k] = Jacobi symbol (d_values[g*group_size + k] / h_mods[g]) in {-1, 0, +1}.
  * Replaces the filter `sympy.jacobi_symbol(g, modulus) != 1` of the biprimality test (DK:1089),

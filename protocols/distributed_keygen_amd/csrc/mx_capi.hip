@@ -9,6 +9,7 @@
 #include "mx_select.hpp"
 #include "mx_setup.hpp"
 #include "mx_field.hpp"
+#include "mx_modinv.hpp"
 #include <cstring>
 #include <algorithm>
 
@@ -733,6 +734,43 @@ extern "C" int mx_lincomb_mod(const uint32_t* d_x, const uint32_t* h_coeffs, uin
   mx::FieldArgs a;
   a.a = d_x; a.b = nullptr; a.c = nullptr; a.out = d_out; a.batch = batch; a.terms = terms;
   return field_launch(a, true, h_mod, h_coeffs, terms * limbs, limbs, d_ws, ws_bytes, (hipStream_t)stream);
+}
+
+// ---- modular inverse (one wavefront per element) ---------------------------------------------------
+namespace {
+template <int LPL>
+int launch_modinv(const mx::ModinvArgs& a, hipStream_t s) {
+  hipLaunchKernelGGL((mx::modinv_kernel<LPL>), dim3((unsigned)a.batch), dim3(64), 0, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+}  // namespace
+
+extern "C" int64_t mx_modinv_workspace_bytes(int limbs) {
+  if (limbs <= 0) return MX_ERR_ARG;
+  return align256((int64_t)limbs * 4);
+}
+
+extern "C" int mx_modinv(const uint32_t* d_values, uint32_t* d_out, uint8_t* d_status, const uint32_t* h_mod, int limbs,
+                         int64_t batch, void* d_ws, int64_t ws_bytes, void* stream) {
+  if (!d_values || !d_out || !d_status || !h_mod || !d_ws || limbs <= 0 || batch <= 0) return MX_ERR_ARG;
+  if (!(h_mod[0] & 1u)) return MX_ERR_MODULUS;
+  const int bits = bit_length(h_mod, limbs);
+  if (bits < 2) return MX_ERR_MODULUS;
+  if (bits > MAX_MOD_BITS) return MX_ERR_SIZE;
+  if (align256((int64_t)limbs * 4) > ws_bytes) return MX_ERR_WORKSPACE;
+  hipStream_t s = (hipStream_t)stream;
+  MX_TRY(upload_words(d_ws, h_mod, (size_t)limbs, s));
+  mx::ModinvArgs a;
+  a.vals = d_values; a.mod = (const u32*)d_ws; a.out = d_out; a.status = d_status; a.batch = batch; a.limbs = limbs;
+  // the almost-inverse keeps values below 2 M: capacity 64 * LPL words >= bits + 2, and >= limbs words
+  const int need = std::max(limbs, (bits + 2 + 31) / 32);
+  if (need <= 64) return launch_modinv<1>(a, s);
+  if (need <= 128) return launch_modinv<2>(a, s);
+  if (need <= 192) return launch_modinv<3>(a, s);
+  if (need <= 320) return launch_modinv<5>(a, s);
+  if (need <= 576) return launch_modinv<9>(a, s);
+  return MX_ERR_SIZE;
 }
 
 // ---- selection of the Jacobi-1 generators ---------------------------------------------------

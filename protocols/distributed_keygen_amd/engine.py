@@ -459,21 +459,43 @@ class Engine:
         bt = self.to_device(_limbs.pack([_reduce(x, mod) for x in b], limbs))
         return _limbs.unpack(self.to_host(self.mulmod_t(at, bt, mod)))
 
+    DIRECT_MODINV_MAX = 4      # elements inverted directly (one wavefront each); longer batches use the product tree
+
+    def modinv_direct_t(self, x_t, mod: int):
+        """Row-wise modular inverse on the device, one wavefront per row (mx_modinv): for the few
+        values that need it (the root of the product tree, theta of a key).  Raises ValueError (like
+        ``pow(v, -1, m)``) if some row is not invertible."""
+        batch, limbs = x_t.shape
+        _check_modulus(mod)
+        h_mod = _limbs.pack_one(mod, limbs)
+        out_t = self.torch.empty_like(x_t)
+        status_t = self.torch.empty(batch, dtype=self.torch.uint8, device=self.device)
+        with self.torch.cuda.device(self.device):
+            ws = self._workspace(self.lib.mx_modinv_workspace_bytes(limbs))
+            rc = self.lib.mx_modinv(
+                x_t.data_ptr(), out_t.data_ptr(), status_t.data_ptr(), h_mod.ctypes.data, limbs, batch,
+                ws.data_ptr(), ws.numel(), self._stream_ptr(),
+            )
+        _lib.check(rc, "mx_modinv")
+        if int(status_t.sum().item()) != 0:
+            raise ValueError("base is not invertible for the given modulus")
+        return out_t
+
     def modinv_t(self, x_t, mod: int):
         """Row-wise modular inverse by Montgomery's trick as a product tree on the device: 3 modular
-        multiplications per element in ~2 log2(batch) launches plus ONE host inversion of the root.
+        multiplications per element in ~2 log2(batch) launches, and the root inverted on the device too
+        (mx_modinv) — no host big-integer step (PSK:89-91 over a batch).
         Raises ValueError (like ``pow(v, -1, m)``) if some row is not invertible."""
         torch = self.torch
         levels = [x_t.contiguous()]
-        while levels[-1].shape[0] > 1:
+        while levels[-1].shape[0] > self.DIRECT_MODINV_MAX:
             cur = levels[-1]
             m = cur.shape[0]
             prod = self.mulmod_t(cur[0 : m - (m & 1) : 2].contiguous(), cur[1:m:2].contiguous(), mod)
             if m & 1:
                 prod = torch.cat([prod, cur[m - 1 : m]], dim=0)
             levels.append(prod)
-        root = _limbs.unpack(self.to_host(levels[-1]))[0]
-        inv = self.to_device(_limbs.pack([pow(root, -1, mod)], x_t.shape[1]))   # ValueError if not invertible
+        inv = self.modinv_direct_t(levels[-1], mod)        # ValueError if not invertible
         for cur in reversed(levels[:-1]):
             m = cur.shape[0]
             half = m // 2

@@ -12,8 +12,9 @@ forms the reference's loops (distributed_keygen.py:463-466 and 510-515) are repl
 a ciphertext is anything with ``.get_value()`` and ``.scheme.public_key.n`` (the reference's
 ``PaillierCiphertext``; when that class is importable the reference's isinstance check is applied
 verbatim).  ``engine`` is injected so the host logic is testable without a GPU; the default is the
-process-wide HIP engine, and there is no CPU arithmetic path in this module beyond ``theta_inv``,
-the one-off modular inverse per key the reference also computes in its constructor (PSK:50).
+process-wide HIP engine; there is no CPU big-integer arithmetic in this module besides the Lagrange
+exponent (PSK:70-85: a product of small integers and one exact division) — ``theta_inv`` (PSK:50) is
+computed by the engine's device inverse too.
 """
 
 from __future__ import annotations
@@ -22,13 +23,12 @@ from dataclasses import dataclass, field
 from typing import Any, Dict, Iterable, List, Optional, Sequence
 
 def _ref_ciphertext_type() -> Any:
-    """The reference's ciphertext type, when its (un-vendored) package is importable in this process."""
-    try:
-        from tno.mpc.encryption_schemes.paillier.paillier import PaillierCiphertext  # type: ignore
+    """The reference's ciphertext type, when its (un-vendored) package has been imported in this
+    process — a ciphertext of that type cannot exist otherwise, so nothing is imported here."""
+    import sys
 
-        return PaillierCiphertext
-    except Exception:  # not installed in the build image
-        return None
+    mod = sys.modules.get("tno.mpc.encryption_schemes.paillier.paillier")
+    return getattr(mod, "PaillierCiphertext", None) if mod is not None else None
 
 
 @dataclass
@@ -59,8 +59,8 @@ class GpuPaillierSharedKey:
         self.t = t
         self.player_id = player_id
         self.theta = theta
-        self.theta_inv = pow(theta, -1, n)  # mod_inv(self.theta, self.n), PSK:50
         self._engine = engine
+        self.theta_inv = self.engine.modinv_batch([theta], n)[0]  # mod_inv(self.theta, self.n), PSK:50 (ValueError if not invertible)
 
     @classmethod
     def from_reference(cls, key: Any, engine: Any = None) -> "GpuPaillierSharedKey":
@@ -83,8 +83,9 @@ class GpuPaillierSharedKey:
         denominator = _mult_list([(j - self.player_id) for j in others])
         return (self.share.n_fac * numerator * self.share.shares[self.player_id]) // denominator
 
-    def _check_ciphertext(self, ciphertext: Any) -> None:
-        ref_type = _ref_ciphertext_type()
+    def _check_ciphertext(self, ciphertext: Any, ref_type: Any = None) -> None:
+        if ref_type is None:
+            ref_type = _ref_ciphertext_type()
         is_ct = isinstance(ciphertext, PlainCiphertext) or (
             isinstance(ciphertext, ref_type) if ref_type is not None
             else (hasattr(ciphertext, "get_value") and hasattr(ciphertext, "scheme"))
@@ -99,8 +100,13 @@ class GpuPaillierSharedKey:
         ``keep_rows`` returns ``(ints, column)``: the column is the engine's device-resident copy of
         the results for ``decrypt_columns`` (the party's own share of the recombination)."""
         values: List[int] = []
+        ref_type = _ref_ciphertext_type()
+        ok_type = ok_scheme = None
         for ciphertext in ciphertexts:
-            self._check_ciphertext(ciphertext)
+            # PSK:62-68 per ciphertext, in order; a type / scheme object that already passed is not re-examined
+            if type(ciphertext) is not ok_type or ciphertext.scheme is not ok_scheme:
+                self._check_ciphertext(ciphertext, ref_type)
+                ok_type, ok_scheme = type(ciphertext), ciphertext.scheme
             values.append(ciphertext.get_value())  # get_value(), not peek_value(): PSK:69
         if not values:
             return ([], None) if keep_rows else []
@@ -184,6 +190,29 @@ class GpuPaillierSharedKey:
                                         "theta": self.theta, "share": self.share}})
 
 
+class _PlainPublicKey:
+    def __init__(self, n: int) -> None:
+        self.n, self.g = n, n + 1
+
+
+class _PlainScheme:
+    def __init__(self, n: int) -> None:
+        self.public_key = _PlainPublicKey(n)
+
+
+_plain_schemes: Dict[int, _PlainScheme] = {}
+
+
+def _plain_scheme(n: int) -> _PlainScheme:
+    """One scheme object per public modulus (as the reference's ciphertexts share their scheme)."""
+    sch = _plain_schemes.get(n)
+    if sch is None:
+        if len(_plain_schemes) > 64:
+            _plain_schemes.clear()
+        sch = _plain_schemes[n] = _PlainScheme(n)
+    return sch
+
+
 @dataclass
 class PlainCiphertext:
     """Minimal ciphertext carrier for callers that do not have the tno Paillier package: the raw
@@ -195,8 +224,7 @@ class PlainCiphertext:
     scheme: Any = field(init=False, repr=False)
 
     def __post_init__(self) -> None:
-        pk = type("PublicKey", (), {"n": self.n, "g": self.n + 1})()
-        self.scheme = type("Scheme", (), {"public_key": pk})()
+        self.scheme = _plain_scheme(self.n)
 
     def get_value(self) -> int:
         self.fresh = False

@@ -372,3 +372,66 @@ def test_chunked_int_level_batch_on_several_streams(eng):
     # a second chunked call reuses streams, workspaces and pinned buffers
     again = eng.powmod_nsquare_batch(bases, e, n)
     assert again == got
+
+
+# ------------------------------------------------------------------ device modular inverse (PSK:50, PSK:89-91)
+@pytest.mark.parametrize("bits", [5, 64, 65, 1027, 2051, 2080, 4102, 6200, 8198, 16700])
+def test_modinv_direct_wave_kernel(eng, bits):
+    """mx_modinv (one wavefront per element, every lanes-per-limb instance) vs pow(v, -1, m)."""
+    import numpy as np
+
+    from protocols.distributed_keygen_amd import limbs as L
+
+    rng = random.Random(bits)
+    mod = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+    limbs = L.limbs_for(mod)
+    vals = [1, 2, mod - 1, mod - 2, (mod + 1) // 2] + [rng.randrange(1, mod) for _ in range(3)]
+    import math
+
+    vals = [v for v in vals if math.gcd(v, mod) == 1][:4]
+    got = L.unpack(eng.to_host(eng.modinv_direct_t(eng.to_device(L.pack(vals, limbs)), mod)))
+    assert got == [pow(v, -1, mod) for v in vals]
+
+
+def test_modinv_not_invertible_raises_like_pow(eng):
+    from protocols.distributed_keygen_amd import limbs as L
+
+    p, q = (1 << 89) - 1, (1 << 107) - 1
+    mod = p * q
+    for bad in (0, p, 3 * q, mod - p):
+        with pytest.raises(ValueError):
+            eng.modinv_batch([5, bad, 7], mod)
+    big = [(k * 7919 + 1) % mod for k in range(1, 40)]
+    big[17] = 5 * p                                         # one non-invertible element poisons the tree root
+    with pytest.raises(ValueError):
+        eng.modinv_batch(big, mod)
+    big[17] = 11
+    assert eng.modinv_batch(big, mod) == [pow(v, -1, mod) for v in big]
+
+
+def test_theta_inv_and_negative_exponent_have_no_host_inverse(eng, golden_decrypt_synth, monkeypatch):
+    """PSK:50 and PSK:89-91 through the device inverse: builtins.pow with a negative exponent is
+    forbidden for the duration of key construction and of a partial decryption with a negative
+    Lagrange exponent; results equal the reference's recorded partial decryptions."""
+    import builtins
+
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+
+    real_pow = builtins.pow
+
+    def guarded_pow(b, e, *m):
+        assert not (m and isinstance(e, int) and e < 0), "host modular inverse on the product path"
+        return real_pow(b, e, *m)
+
+    grp = next(g for name, g in golden_decrypt_synth.items() if "corrupt" not in name and g["key_length"] >= 1024 and any(
+        oracle.partial_decrypt_exponent(int(i), g["degree"], unhex(g["n_fac"]), unhex(s)) < 0 for i, s in g["shares"].items()))
+    n = unhex(grp["n"])
+    neg = next(int(i) for i, s in grp["shares"].items()
+               if oracle.partial_decrypt_exponent(int(i), grp["degree"], unhex(grp["n_fac"]), unhex(s)) < 0)
+    monkeypatch.setattr(builtins, "pow", guarded_pow)
+    share = ShareView({neg: unhex(grp["shares"][str(neg)])}, grp["degree"], unhex(grp["n_fac"]))
+    key = GpuPaillierSharedKey(n, grp["t"], neg, share, unhex(grp["theta"]), engine=eng)
+    got = key.partial_decrypt_batch([PlainCiphertext(unhex(c["c"]), n) for c in grp["cases"]])
+    monkeypatch.undo()
+    assert key.theta_inv == pow(unhex(grp["theta"]), -1, n)
+    assert got == [unhex(c["partials"][str(neg)]) for c in grp["cases"]]
