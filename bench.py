@@ -76,6 +76,8 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--limbs-per-lane", type=int, default=-1,
                     help="lane geometry 9|18, 0 = library heuristic; default: 18 (wide) when the launches in flight "
                          "over-subscribe the wide geometry's 2048 wavefront slots")
+    ap.add_argument("--segments", type=int, default=0,
+                    help="c3/c5: launches per exponentiation (mx_powmod_nsquare_run), 0 = the library's choice")
     ap.add_argument("--generic-modulus", action="store_true",
                     help="c3/c5: time mx_powmod_shared on the modulus N^2 instead of the N-adic pair kernel")
     return ap.parse_args()
@@ -354,6 +356,7 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
     nstreams = args.streams if args.streams > 0 else next(
         (d for d in (4, 5, 6, 7, 8, 3) if args.steps % d == 0), min(4, max(1, args.steps)))
     eng.set_limbs_per_lane(pick_decrypt_geometry(args, key_length, batch, nstreams))
+    eng.set_segments(args.segments)
     wl = DecryptWorkload(eng, key_length, batch, rank, args.generic_modulus)
     wl.make_lanes(nstreams, dist, world)
     elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), args.steps, args.warmup, nstreams)
@@ -376,6 +379,7 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
             "geometry_K_L_W_blocks": list(geo),
             "algorithm": "Montgomery modulo N^2" if args.generic_modulus else "N-adic pairs, two Montgomery passes modulo N per product",
             "call_path": "per-key plan (mx_powmod_nsquare_prepare once) + mx_powmod_nsquare_run + mx_combine_run per step",
+            "segments_per_exponentiation": args.segments or "library default (4 for long exponents on large batches)",
             "verified": note,
         },
         "roofline": decrypt_roofline(eng, wl, args.steps, elapsed, kernel_ms, nstreams, key_length),

@@ -105,7 +105,11 @@ int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* 
  * arithmetic, no operand upload.  The plan descriptor is a plain struct the caller keeps on the
  * host; the device block must stay valid, and the stream passed to prepare must be complete or
  * ordered before the streams passed to run (prepare's uploads are enqueued on it).
- * limbs_per_lane of run: 9 (narrow geometry), 18 (wide) or 0 = automatic from the batch size. */
+ * limbs_per_lane of run: 9 (narrow geometry), 18 (wide) or 0 = automatic from the batch size.
+ * segments of run: the exponentiation is enqueued as this many consecutive launches, each executing a
+ * stretch of the tape (the accumulator travels through the workspace); a wavefront then lives
+ * 1/segments as long, which is the grain at which a burst of launches on several streams drains.
+ * 1..64, 0 = automatic (4 for long exponents on large batches, else 1).  Same result bit for bit. */
 typedef struct mx_nsquare_plan {
   const void* d_plan;     /* device block written by prepare */
   int64_t plan_bytes;
@@ -126,8 +130,8 @@ int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const 
 /* workspace of one run (the table of odd powers of every base; one per launch in flight) */
 int64_t mx_powmod_nsquare_run_workspace_bytes(const mx_nsquare_plan* plan, int64_t batch);
 int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t* d_bases, uint32_t* d_out, int limbs2,
-                          int64_t batch, int limbs_per_lane, void* d_workspace, int64_t workspace_bytes,
-                          void* stream);
+                          int64_t batch, int limbs_per_lane, int segments, void* d_workspace,
+                          int64_t workspace_bytes, void* stream);
 
 /* ---- small-prime sieve -----------------------------------------------------------------
  * d_out[e] = 1 if some h_primes[k] divides candidate e else 0.  Replaces
@@ -231,6 +235,14 @@ int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, i
 /* The same with device-resident moduli (no workspace). */
 int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs, int64_t groups,
                   int64_t group_size, void* stream);
+/* Only the rows [first, first + count) of every group (d_out entries outside the range are left
+ * untouched); with d_skip_counts given, groups whose d_skip_counts[g] >= skip_threshold are not
+ * evaluated at all.  The v-calculation stops at correct_param_biprime generators with symbol 1
+ * (DK:1086): the head of the generator list almost always yields them, so the tail is evaluated
+ * only for the candidates where it did not — the same selection as the reference, ~35 % fewer symbols. */
+int mx_jacobi_dev_range(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs, int64_t groups,
+                        int64_t group_size, int first, int count, const int32_t* d_skip_counts, int skip_threshold,
+                        void* stream);
 
 /* ---- selection of the generators -------------------------------------------------------
  * For every group, copies the first `keep` rows whose flag is 1 (in order) to d_out[g][0..keep) and

@@ -50,12 +50,13 @@ SYMBOLS = {
     "mx_nsquare_plan_bytes": (c_int64, [c_int, c_int]),
     "mx_powmod_nsquare_prepare": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_powmod_nsquare_run_workspace_bytes": (c_int64, [POINTER(NsquarePlan), c_int64]),
-    "mx_powmod_nsquare_run": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_nsquare_run": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_combine_plan_bytes": (c_int64, [c_int, c_int]),
     "mx_combine_prepare": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_combine_run": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),
     "mx_biprime_verdict_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_jacobi_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p]),
+    "mx_jacobi_dev_range": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mx_nsquare_geometry_for": (c_int, [c_int, c_int64, c_int, *_P4]),
     "mx_powmod_geometry_for": (c_int, [c_int, c_int64, c_int64, c_int, *_P4]),
     "mx_modinv_workspace_bytes": (c_int64, [c_int]),

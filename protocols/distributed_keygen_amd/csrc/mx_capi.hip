@@ -582,7 +582,7 @@ extern "C" int mx_biprime_verdict(const uint32_t* d_v, uint8_t* d_pass, const ui
 namespace {
 template <int NL>
 int launch_jacobi(const mx::JacobiArgs& a, hipStream_t s) {
-  int64_t nblocks = (a.count + 63) / 64;
+  int64_t nblocks = a.skip ? (a.count / a.per_group) * ((a.per_group + 63) / 64) : (a.count + 63) / 64;
   hipLaunchKernelGGL((mx::jacobi_kernel<NL>), dim3((unsigned)nblocks), dim3(64), 0, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
@@ -594,14 +594,17 @@ extern "C" int64_t mx_jacobi_workspace_bytes(int limbs, int64_t groups) {
   return align256((int64_t)groups * limbs * 4);
 }
 
-extern "C" int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs,
-                             int64_t groups, int64_t group_size, void* stream) {
+extern "C" int mx_jacobi_dev_range(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs,
+                                   int64_t groups, int64_t group_size, int first, int count, const int32_t* d_skip_counts,
+                                   int skip_threshold, void* stream) {
   if (!d_values || !d_out || !d_mods || limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
+  if (first < 0 || count <= 0 || (int64_t)first + count > group_size) return MX_ERR_ARG;
   if (limbs > 129) return MX_ERR_SIZE;
   hipStream_t s = (hipStream_t)stream;
   mx::JacobiArgs a;
   a.a = d_values; a.mods = d_mods; a.out = (signed char*)d_out;
-  a.count = groups * group_size; a.group_size = group_size; a.limbs = limbs;
+  a.count = groups * count; a.group_size = group_size; a.limbs = limbs;
+  a.first = first; a.per_group = count; a.skip = d_skip_counts; a.skip_threshold = skip_threshold;
   if (limbs <= 3) return launch_jacobi<3>(a, s);
   if (limbs <= 5) return launch_jacobi<5>(a, s);
   if (limbs <= 9) return launch_jacobi<9>(a, s);
@@ -609,6 +612,12 @@ extern "C" int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint
   if (limbs <= 33) return launch_jacobi<33>(a, s);
   if (limbs <= 65) return launch_jacobi<65>(a, s);
   return launch_jacobi<129>(a, s);
+}
+
+extern "C" int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs,
+                             int64_t groups, int64_t group_size, void* stream) {
+  if (group_size > 0x7FFFFFFF) return MX_ERR_ARG;
+  return mx_jacobi_dev_range(d_values, d_out, d_mods, limbs, groups, group_size, 0, (int)group_size, nullptr, 0, stream);
 }
 
 extern "C" int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,

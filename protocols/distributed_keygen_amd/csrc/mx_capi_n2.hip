@@ -27,7 +27,6 @@ bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, N2Shape
 template <int K, int L>
 int launch_n2_kl(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   size_t lds = mx::powmod_n2_lds_bytes<K, L>();
-  MxKernelTimer timer(s);
   hipLaunchKernelGGL((mx::powmod_n2_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
@@ -57,6 +56,17 @@ int n2_auto_limbs_per_lane(int n_bits, int64_t batch) {
   if (narrow.K < 8 || wide.K > 16) return LIMBS_PER_LANE;
   const int64_t waves = (batch * wide.K + 63) / 64;
   return waves >= 480 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+}
+
+// Segments when the caller leaves the choice to the library: a launch whose wavefronts would live for
+// tens of milliseconds is cut so that a burst of such launches drains at a finer grain (measured with
+// bench.py --steps 20: the last round of 4 launches in flight costs ~3 % of the run unsegmented).
+int n2_auto_segments(int n_sqr, int64_t nblocks) {
+  if (const char* e = getenv("MX_N2_SEGMENTS")) {
+    int v = atoi(e);
+    if (v >= 1 && v <= 64) return v;
+  }
+  return (n_sqr >= 2048 && nblocks >= 256) ? 4 : 1;
 }
 
 inline int64_t n2_consts_bytes(int limbs_n) { return align256((int64_t)8 * limbs_n * 4); }
@@ -195,11 +205,12 @@ extern "C" int64_t mx_powmod_nsquare_run_workspace_bytes(const mx_nsquare_plan* 
 }
 
 extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t* d_bases, uint32_t* d_out,
-                                     int limbs2, int64_t batch, int limbs_per_lane, void* d_ws, int64_t ws_bytes,
-                                     void* stream) {
+                                     int limbs2, int64_t batch, int limbs_per_lane, int segments, void* d_ws,
+                                     int64_t ws_bytes, void* stream) {
   if (!plan || !plan->d_plan || !d_bases || !d_out || !d_ws) return MX_ERR_ARG;
   if (limbs2 <= 0 || batch <= 0 || plan->limbs_n <= 0 || plan->ntape <= 0) return MX_ERR_ARG;
   if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  if (segments < 0 || segments > 64) return MX_ERR_ARG;
   const int bits = plan->n_bits;
   if (2 * bits - 1 > 32 * limbs2) return MX_ERR_ARG;          // rows too narrow for N^2
   const int lpl = limbs_per_lane ? limbs_per_lane : n2_auto_limbs_per_lane(bits, batch);
@@ -218,15 +229,29 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   a.slots = (u32*)d_ws;
   a.batch = batch; a.limbsn = plan->limbs_n; a.limbs2 = limbs2; a.nblk = p.geo.nblk; a.ksplit = bits - 1;
   hipStream_t s = (hipStream_t)stream;
-  switch (p.geo.K) {
-    case 1: return launch_n2_k<1>(a, p.nblocks, p.geo.L, s);
-    case 2: return launch_n2_k<2>(a, p.nblocks, p.geo.L, s);
-    case 4: return launch_n2_k<4>(a, p.nblocks, p.geo.L, s);
-    case 8: return launch_n2_k<8>(a, p.nblocks, p.geo.L, s);
-    case 16: return launch_n2_k<16>(a, p.nblocks, p.geo.L, s);
-    case 32: return launch_n2_k<32>(a, p.nblocks, p.geo.L, s);
+  // segments: consecutive launches that each execute a stretch of the tape (mx_powmod_n2.hpp); positions
+  // are counted in squarings, the accumulator travels through a scratch slot of the workspace
+  int nseg = segments > 0 ? segments : n2_auto_segments(plan->n_sqr, p.nblocks);
+  if (nseg > plan->n_sqr / 16) nseg = plan->n_sqr / 16;
+  if (nseg < 1) nseg = 1;
+  MxKernelTimer timer(s);                        // one timed interval per exponentiation (all its segments)
+  for (int sg = 0; sg < nseg; ++sg) {
+    a.first = sg == 0;
+    a.last = sg == nseg - 1;
+    a.pos_begin = (int)((int64_t)plan->n_sqr * sg / nseg);
+    a.pos_end = a.last ? 0x7FFFFFFF : (int)((int64_t)plan->n_sqr * (sg + 1) / nseg);
+    int rc = MX_ERR_SIZE;
+    switch (p.geo.K) {
+      case 1: rc = launch_n2_k<1>(a, p.nblocks, p.geo.L, s); break;
+      case 2: rc = launch_n2_k<2>(a, p.nblocks, p.geo.L, s); break;
+      case 4: rc = launch_n2_k<4>(a, p.nblocks, p.geo.L, s); break;
+      case 8: rc = launch_n2_k<8>(a, p.nblocks, p.geo.L, s); break;
+      case 16: rc = launch_n2_k<16>(a, p.nblocks, p.geo.L, s); break;
+      case 32: rc = launch_n2_k<32>(a, p.nblocks, p.geo.L, s); break;
+    }
+    if (rc != MX_OK) return rc;
   }
-  return MX_ERR_SIZE;
+  return MX_OK;
 }
 
 // ---- one-shot form: prepare into the head of the workspace, run with the rest
@@ -252,6 +277,6 @@ extern "C" int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const
   }
   mx_nsquare_plan plan;
   MX_TRY(mx_powmod_nsquare_prepare(&plan, h_n, h_exp, limbs_n, exp_limbs, d_ws, pb, stream));
-  return mx_powmod_nsquare_run(&plan, d_bases, d_out, limbs2, batch, override_limbs_per_lane(),
+  return mx_powmod_nsquare_run(&plan, d_bases, d_out, limbs2, batch, override_limbs_per_lane(), 0,
                                (char*)d_ws + pb, ws_bytes - pb, stream);
 }

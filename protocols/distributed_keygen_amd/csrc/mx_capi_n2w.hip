@@ -6,7 +6,6 @@ namespace mxw {
 template <int K>
 static int launch(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   size_t lds = mx::powmod_n2_lds_bytes<K, LIMBS_PER_LANE_WIDE>();
-  MxKernelTimer timer(s);
   hipLaunchKernelGGL((mx::powmod_n2_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;

@@ -23,9 +23,16 @@ struct JacobiArgs {
   const uint32_t* a;      // [count][limbs] device: numerators (< modulus of their group)
   const uint32_t* mods;   // [groups][limbs] device
   signed char* out;       // [count] device: -1, 0, +1
-  long long count;
-  long long group_size;   // symbols per modulus
+  long long count;        // symbols evaluated by this launch
+  long long group_size;   // rows per modulus in a / out
   int limbs;
+  // Range form: only the rows [first, first + per_group) of every group are evaluated (count =
+  // groups * per_group); with `skip` given the launch has ceil(per_group / 64) workgroups per group and
+  // groups whose skip[g] >= skip_threshold are left out entirely — the tail of the generator list is
+  // only needed where the head did not already yield enough symbols equal to 1 (DK:1086).
+  int first, per_group;
+  const int* skip;
+  int skip_threshold;
 };
 
 // Limbs are processed in chunks of JC; chunks above the highest limb that is non-zero in ANY lane of
@@ -37,11 +44,24 @@ constexpr int JREFRESH = 16;
 template <int NL>
 __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
   constexpr int NCH = (NL + JC - 1) / JC;
-  const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
-  const bool valid = idx < A.count;
-  const long long e = valid ? idx : A.count - 1;
-  const uint32_t* pa = A.a + e * A.limbs;
-  const uint32_t* pn = A.mods + (e / A.group_size) * A.limbs;
+  long long grp, row;
+  bool valid;
+  if (A.skip) {
+    const int bpg = (A.per_group + 63) / 64;
+    grp = blockIdx.x / bpg;
+    if (A.skip[grp] >= A.skip_threshold) return;            // uniform for the workgroup
+    const int k = (int)(blockIdx.x % bpg) * 64 + threadIdx.x;
+    valid = k < A.per_group;
+    row = grp * A.group_size + A.first + (valid ? k : A.per_group - 1);
+  } else {
+    const long long idx = (long long)blockIdx.x * 64 + threadIdx.x;
+    valid = idx < A.count;
+    const long long e = valid ? idx : A.count - 1;
+    grp = e / A.per_group;
+    row = grp * A.group_size + A.first + (e - grp * A.per_group);
+  }
+  const uint32_t* pa = A.a + row * A.limbs;
+  const uint32_t* pn = A.mods + grp * A.limbs;
   uint32_t a[NL], n[NL];
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
@@ -136,7 +156,7 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
   for (int j = 0; j < NL; ++j) az |= a[j];
   done = done && (az == 0);
   const bool n_is_one = done && (hi == 0) && (n[0] == 1u);
-  if (valid) A.out[idx] = (signed char)(n_is_one ? t : 0);
+  if (valid) A.out[row] = (signed char)(n_is_one ? t : 0);
 }
 
 }  // namespace mx

@@ -37,6 +37,9 @@ enum : u32 { N2_SQR = 0, N2_MUL = 1, N2_ADD = 2, N2_LOAD = 3, N2_STORE = 4 };
 //        6 scratch, 7 x^2, 8.. odd powers x^(2k+1)
 constexpr int N2_SLOT_K1 = 0, N2_SLOT_K2 = 1, N2_SLOT_E = 2, N2_SLOT_ONE = 3, N2_SLOT_LO = 4, N2_SLOT_HI = 5,
               N2_SLOT_TMP = 6, N2_SLOT_SQ = 7, N2_SLOT_TABLE = 8;
+// the accumulator between two segments of one exponentiation: x_hi's slot, which only the conversion
+// at tape position 0 reads
+constexpr int N2_SLOT_CARRY = N2_SLOT_HI;
 
 // LDS of one workgroup (one wavefront): per group the Montgomery scratch (which the input row and
 // the output limbs reuse), plus ONE copy of C' for all groups.  Small enough that the register
@@ -54,6 +57,12 @@ struct PowmodN2Args {
   int limbsn, limbs2;
   int ntape, nblk;
   int ksplit;         // x = x_lo + 2^ksplit * x_hi, ksplit = bits(N) - 1
+  // One exponentiation may be run as several consecutive launches ("segments"), each executing the
+  // part of the tape whose position — the number of squarings executed so far — lies in
+  // [pos_begin, pos_end); the accumulator travels between them through the scratch slot.  A wavefront
+  // then lives 1/segments as long, which is the granularity at which a burst of launches drains.
+  int pos_begin, pos_end;
+  int first, last;    // first segment: input conversion prologue; last segment: output epilogue
 };
 
 template <int K, int L, int W>
@@ -140,7 +149,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
   auto slot_at = [&](int slot, int half, int j) -> u32& { return slots[(((i64)slot * 2 + half) * L + j) * nlanes]; };
 
   // ---- prologue: constant pairs and the two halves of x into their slots (no arithmetic)
-  {
+  if (A.first) {
     u32 v[L];
     const int rows[4][3] = {{N2_SLOT_K1, 3, 4}, {N2_SLOT_K2, 5, 6}, {N2_SLOT_ONE, 1, 2}, {N2_SLOT_E, -1, -1}};
     for (int r = 0; r < 4; ++r) {
@@ -173,17 +182,29 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
     }
   }
 
-  // ---- the tape
+  // ---- the tape (this segment's part of it)
   u32 acc0[L], acc1[L];
+  if (A.first) {
 #pragma unroll
-  for (int j = 0; j < L; ++j) { acc0[j] = 0; acc1[j] = 0; }
+    for (int j = 0; j < L; ++j) { acc0[j] = 0; acc1[j] = 0; }
+  } else {
+#pragma unroll
+    for (int j = 0; j < L; ++j) { acc0[j] = slot_at(N2_SLOT_CARRY, 0, j); acc1[j] = slot_at(N2_SLOT_CARRY, 1, j); }
+  }
+  int pos = 0;                                      // squarings executed by the tape so far
   for (int k = 0; k < A.ntape; ++k) {
     const u32 word = A.tape[k];
     const u32 op = word >> 28;
     const int arg = (int)(word & 0x0FFFFFFFu);
     if (op == N2_SQR) {
-      for (int s = 0; s < arg; ++s) P.sqr(acc0, acc1, acc0, acc1);
-    } else if (op == N2_STORE) {
+      const int lo = pos > A.pos_begin ? pos : A.pos_begin;
+      const int hi = pos + arg < A.pos_end ? pos + arg : A.pos_end;
+      for (int s = lo; s < hi; ++s) P.sqr(acc0, acc1, acc0, acc1);
+      pos += arg;
+      continue;
+    }
+    if (pos < A.pos_begin || pos >= A.pos_end) continue;   // another segment's operation
+    if (op == N2_STORE) {
 #pragma unroll
       for (int j = 0; j < L; ++j) { slot_at(arg, 0, j) = acc0[j]; slot_at(arg, 1, j) = acc1[j]; }
     } else {
@@ -200,6 +221,11 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
         for (int j = 0; j < L; ++j) { acc0[j] = f0[j]; acc1[j] = f1[j]; }
       }
     }
+  }
+  if (!A.last) {
+#pragma unroll
+    for (int j = 0; j < L; ++j) { slot_at(N2_SLOT_CARRY, 0, j) = acc0[j]; slot_at(N2_SLOT_CARRY, 1, j) = acc1[j]; }
+    return;
   }
 
   // ---- epilogue: acc already is the pair whose N-adic value Y0 + Y1*N is the residue (the tape ends

@@ -51,6 +51,7 @@ class Engine:
         self.device = torch.device("cuda", idx)
         self._ws: Dict[int, Any] = {}          # stream -> workspace tensor
         self._lpl = 0                          # lane geometry of this engine's modexp launches (0 = automatic)
+        self._segments = 0                     # launches per N^2 exponentiation (0 = automatic; include/mxpaillier.h)
         self._n2_plans: "OrderedDict[Tuple[int, int], _Plan]" = OrderedDict()
         self._combine_plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
         self._side_streams: List[Any] = []     # chunked int-level batches (_pipelined)
@@ -101,6 +102,12 @@ class Engine:
         if limbs_per_lane not in (0, 9, 18):
             raise ValueError("limbs_per_lane must be 0, 9 or 18")
         self._lpl = int(limbs_per_lane)
+
+    def set_segments(self, segments: int) -> None:
+        """Launches one mx_powmod_nsquare_run exponentiation is cut into (0 = automatic, 1..64)."""
+        if not 0 <= segments <= 64:
+            raise ValueError("segments must be 0..64")
+        self._segments = int(segments)
 
     def selftest_lanes(self) -> int:
         with self.torch.cuda.device(self.device):
@@ -286,8 +293,8 @@ class Engine:
             self._use_plan(plan)
             ws = self._workspace(self.lib.mx_powmod_nsquare_run_workspace_bytes(plan.desc, batch))
             rc = self.lib.mx_powmod_nsquare_run(
-                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl, ws.data_ptr(), ws.numel(),
-                self._stream_ptr(),
+                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl, self._segments, ws.data_ptr(),
+                ws.numel(), self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_nsquare_run")
         return out_t
@@ -615,25 +622,32 @@ class Engine:
         return [bool(b) for b in bad], survivors
 
     # ------------------------------------------------------------------ Jacobi symbol
-    def jacobi_t(self, values_t, mods, group_size: int, out_t=None):
+    def jacobi_t(self, values_t, mods, group_size: int, out_t=None, first: int = 0, count: Optional[int] = None,
+                 skip_counts_t=None, skip_threshold: int = 0):
         """int8 [groups*group_size]: Jacobi symbol (values[g*group_size+k] / mods[g]) (DK:1089).
-        `mods`: sequence of ints or a device-resident (rows, max bits) pair."""
-        count, limbs = values_t.shape
+        `mods`: sequence of ints or a device-resident (rows, max bits) pair.  With first / count only
+        the rows [first, first+count) of every group are evaluated (the other entries of out_t are left
+        as they are); groups with skip_counts_t[g] >= skip_threshold are skipped."""
+        total, limbs = values_t.shape
         if not (isinstance(mods, tuple) and hasattr(mods[0], "data_ptr")):
             for m in mods:
                 if m < 1 or m % 2 == 0:
                     raise ValueError("n should be an odd positive integer")
         mods_t, _ = self._mods_operand(mods, limbs, odd_only=False)
         groups = mods_t.shape[0]
-        if count != groups * group_size:
+        if total != groups * group_size:
             raise ValueError("values must hold groups*group_size rows")
+        if count is None:
+            count = group_size - first
         if out_t is None:
-            out_t = self.torch.empty(count, dtype=self.torch.int8, device=self.device)
+            full = first == 0 and count == group_size and skip_counts_t is None
+            out_t = (self.torch.empty if full else self.torch.zeros)(total, dtype=self.torch.int8, device=self.device)
         with self.torch.cuda.device(self.device):
-            rc = self.lib.mx_jacobi_dev(
-                values_t.data_ptr(), out_t.data_ptr(), mods_t.data_ptr(), limbs, groups, group_size, self._stream_ptr()
+            rc = self.lib.mx_jacobi_dev_range(
+                values_t.data_ptr(), out_t.data_ptr(), mods_t.data_ptr(), limbs, groups, group_size, first, count,
+                skip_counts_t.data_ptr() if skip_counts_t is not None else None, skip_threshold, self._stream_ptr(),
             )
-        _lib.check(rc, "mx_jacobi_dev")
+        _lib.check(rc, "mx_jacobi_dev_range")
         return out_t
 
     def jacobi_batch(self, values: Sequence[Sequence[int]], mods: Sequence[int]) -> List[List[int]]:
@@ -679,8 +693,16 @@ class Engine:
         are the modexp of a zero row and are ignored by the caller."""
         limbs = g_t.shape[1]
         mods_op = self._mods_operand(mods, limbs)
-        j_t = self.jacobi_t(g_t, mods_op, group_size)
+        # The selection stops at `keep` generators with symbol 1 (DK:1086) and a symbol is 1 for about
+        # half of them: the first 2.6 * keep generators yield `keep` ones for > 99 % of the candidates,
+        # and the tail of the list is evaluated only for the candidates where they did not.
+        head = min(group_size, (13 * keep + 4) // 5)
+        j_t = self.jacobi_t(g_t, mods_op, group_size, first=0, count=head)
         sel_t, cnt_t = self.select_first_t(g_t, j_t, group_size, keep)
+        if head < group_size:
+            self.jacobi_t(g_t, mods_op, group_size, out_t=j_t, first=head, count=group_size - head,
+                          skip_counts_t=cnt_t, skip_threshold=keep)
+            sel_t, cnt_t = self.select_first_t(g_t, j_t, group_size, keep)
         v_t = self.powmod_multi_t(sel_t, mods_op, exps, keep)
         return v_t, cnt_t
 

@@ -435,3 +435,38 @@ def test_theta_inv_and_negative_exponent_have_no_host_inverse(eng, golden_decryp
     monkeypatch.undo()
     assert key.theta_inv == pow(unhex(grp["theta"]), -1, n)
     assert got == [unhex(c["partials"][str(neg)]) for c in grp["cases"]]
+
+
+def test_biprime_v_two_phase_jacobi_selection(eng):
+    """The fused v-calculation evaluates the head of the generator list first and the tail only for
+    candidates whose head did not yield `keep` generators with symbol 1 (DK:1084-1099): candidates
+    built so that the 40th such generator lies in the head, exactly at the head/tail boundary, deep in
+    the tail, or does not exist — all must equal the reference's sequential selection."""
+    from protocols.distributed_keygen_amd import biprime
+
+    rng = random.Random(160)
+    mods, gens = [], []
+    for c in range(12):
+        m = rng.getrandbits(1027) | (1 << 1026) | 1
+        ones = [g for g in (rng.randrange(2, m) for _ in range(900)) if oracle.jacobi_symbol(g, m) == 1]
+        others = [g for g in (rng.randrange(2, m) for _ in range(600)) if oracle.jacobi_symbol(g, m) != 1]
+        # number of symbol-1 generators placed in the first 104 positions
+        in_head = [104, 60, 40, 39, 38, 20, 5, 0, 41, 39, 1, 0][c]
+        in_tail = [0, 0, 0, 1, 2, 30, 56, 56, 0, 0, 38, 10][c]
+        head = ones[:in_head] + others[: 104 - in_head]
+        rng.shuffle(head)
+        tail = ones[in_head : in_head + in_tail] + others[104 - in_head : 104 - in_head + 56 - in_tail]
+        rng.shuffle(tail)
+        mods.append(m)
+        gens.append(head + tail)
+        assert len(gens[-1]) == 160
+    p = [rng.getrandbits(510) for _ in mods]
+    q = [rng.getrandbits(510) for _ in mods]
+    for index in (1, 2):
+        got = biprime.biprime_test_v_calculation_batch(gens, index, mods, p, q, 40, eng)
+        want = [oracle.biprime_test_v_calculation(g, index, m, pi, qi, 40) for g, m, pi, qi in zip(gens, mods, p, q)]
+        assert got == want
+    assert [len(w) for w in want] == [40, 40, 40, 40, 40, 40, 40, 40, 40, 39, 39, 10]
+    # a short generator list (no tail at all) and keep larger than the list
+    got = biprime.biprime_test_v_calculation_batch([g[:30] for g in gens], 1, mods, p, q, 40, eng)
+    assert got == [oracle.biprime_test_v_calculation(g[:30], 1, m, pi, qi, 40) for g, m, pi, qi in zip(gens, mods, p, q)]

@@ -234,3 +234,22 @@ def test_one_engine_driven_from_several_streams(eng):
     assert len(eng._ws) >= 4
     for e, out in outs:
         assert L.unpack(eng.to_host(out)) == [pow(b, e, n2) for b in bases]
+
+
+@pytest.mark.parametrize("segments", [1, 2, 3, 4, 7, 64])
+def test_powmod_nsquare_segments_are_bit_identical(eng, segments):
+    """One exponentiation enqueued as several consecutive launches (tape segments, the accumulator
+    travelling through the workspace): the same result bit for bit, in both lane geometries."""
+    rng = random.Random(1000 + segments)
+    n = rng.getrandbits(1027) | (1 << 1026) | 1
+    n2 = n * n
+    bases = [0, 1, n, n2 - 1] + [rng.randrange(n2) for _ in range(29)]
+    try:
+        for lpl in (9, 18):
+            eng.set_limbs_per_lane(lpl)
+            for e in (rng.getrandbits(700) | (1 << 699) | 1, (1 << 300), 5, 0):
+                eng.set_segments(segments)
+                assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (lpl, e.bit_length())
+    finally:
+        eng.set_segments(0)
+        eng.set_limbs_per_lane(0)
