@@ -585,6 +585,9 @@ int launch_jacobi(const mx::JacobiArgs& a, hipStream_t s) {
   int64_t nblocks = a.skip ? (a.count / a.per_group) * ((a.per_group + 63) / 64) : (a.count + 63) / 64;
   hipLaunchKernelGGL((mx::jacobi_kernel<NL>), dim3((unsigned)nblocks), dim3(64), 0, s, a);
   MX_HIP(hipGetLastError());
+  // safety net for symbols the divstep kernel did not finish within its batch bound (mx_jacobi.hpp)
+  hipLaunchKernelGGL((mx::jacobi_fallback_kernel<NL>), dim3((unsigned)nblocks), dim3(64), 0, s, a);
+  MX_HIP(hipGetLastError());
   return MX_OK;
 }
 }  // namespace
@@ -605,6 +608,8 @@ extern "C" int mx_jacobi_dev_range(const uint32_t* d_values, int8_t* d_out, cons
   a.a = d_values; a.mods = d_mods; a.out = (signed char*)d_out;
   a.count = groups * count; a.group_size = group_size; a.limbs = limbs;
   a.first = first; a.per_group = count; a.skip = d_skip_counts; a.skip_threshold = skip_threshold;
+  a.max_batches = (32 * limbs * 9 / 2) / mx::JSTEPS + 8;
+  if (const char* e = getenv("MX_JACOBI_MAX_BATCHES")) a.max_batches = atoi(e);   // developer knob: exercises the safety net
   if (limbs <= 3) return launch_jacobi<3>(a, s);
   if (limbs <= 5) return launch_jacobi<5>(a, s);
   if (limbs <= 9) return launch_jacobi<9>(a, s);

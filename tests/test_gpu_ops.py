@@ -470,3 +470,25 @@ def test_biprime_v_two_phase_jacobi_selection(eng):
     # a short generator list (no tail at all) and keep larger than the list
     got = biprime.biprime_test_v_calculation_batch([g[:30] for g in gens], 1, mods, p, q, 40, eng)
     assert got == [oracle.biprime_test_v_calculation(g[:30], 1, m, pi, qi, 40) for g, m, pi, qi in zip(gens, mods, p, q)]
+
+
+def test_jacobi_unbalanced_operands_and_safety_net(eng, monkeypatch):
+    """Tiny numerators against large moduli, numerators just below the modulus, common factors — and
+    the same inputs with the divstep batches cut short (MX_JACOBI_MAX_BATCHES), so that the plain
+    binary algorithm that backs them up has to finish every symbol from an intermediate state."""
+    rng = random.Random(77)
+    rows, mods = [], []
+    for bits in (61, 300, 1028, 2053, 4100):
+        m = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        vals = [0, 1, 2, 3, 4, 5, 12345, m - 1, m - 2, m - 12345, (m + 1) // 2, rng.getrandbits(20), rng.getrandbits(bits // 3),
+                3 * 5 * 7 * rng.getrandbits(40)] + [rng.randrange(m) for _ in range(18)]
+        rows.append([v % m for v in vals])
+        mods.append(m)
+    mods.append(3 * 5 * 7 * 11 * 13 * ((1 << 500) + 1))
+    rows.append([3, 5, 15, 1001, 17, (1 << 400) + 1] + [rng.randrange(mods[-1]) for _ in range(26)])
+    want = [[oracle.jacobi_symbol(v, m) for v in r] for r, m in zip(rows, mods)]
+    assert eng.jacobi_batch(rows, mods) == want
+    for cut in ("0", "1", "7", "60"):
+        monkeypatch.setenv("MX_JACOBI_MAX_BATCHES", cut)
+        assert eng.jacobi_batch(rows, mods) == want, cut
+    monkeypatch.delenv("MX_JACOBI_MAX_BATCHES")

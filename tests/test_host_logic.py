@@ -377,3 +377,68 @@ def test_shamir_mirror_matches_reference_vectors(golden_reconstruct):
             shamir.reconstruct_batch(dict(list(some.items())[1:]), prime, degree, eng)
     assert shamir.reconstruct_batch({1: [], 2: [], 3: []}, 101, 2, eng) == []
     assert shamir.lagrange_coefficients_at_zero([1, 2, 3], 101) == [3, 98, 1]
+
+
+def _posdivsteps_jacobi_model(x: int, n: int, steps: int = 30) -> int:
+    """Python model of csrc/mx_jacobi.hpp: batches of `steps` all-positive divsteps decided from the
+    low 64 bits, a 2x2 matrix per batch applied to the full operands, sign tracked on the low bits."""
+    m64 = (1 << 64) - 1
+    if n == 1:
+        return 1
+    if x == 0 or n % 2 == 0:
+        return 0
+    f, g, eta, jac = n, x, -1, 0
+    for _ in range((n.bit_length() + 31) // 32 * 32 * 4 // steps + 8):
+        u, v, q, r = 1, 0, 0, 1
+        fl, gl, i = f & m64, g & m64, steps
+        while True:
+            t = (gl | (m64 << i)) & m64
+            zeros = (t & -t).bit_length() - 1
+            gl >>= zeros
+            u <<= zeros
+            v <<= zeros
+            eta -= zeros
+            i -= zeros
+            jac ^= zeros & ((fl >> 1) ^ (fl >> 2)) & 1
+            if i == 0:
+                break
+            if eta < 0:
+                eta = -eta
+                fl, gl, u, q, v, r = gl, fl, q, u, r, v
+                jac ^= ((fl & gl) >> 1) & 1
+                mask = (m64 >> (64 - min(eta + 1, i))) & 63
+                w = (fl * gl * (fl * fl - 2)) & mask
+            else:
+                mask = (m64 >> (64 - min(eta + 1, i))) & 15
+                w = (-(fl + (((fl + 1) & 4) << 1)) * gl) & mask
+            gl = (gl + fl * w) & m64
+            q += u * w
+            r += v * w
+        assert max(u, v, q, r) <= 1 << steps
+        f, g = (u * f + v * g) >> steps, (q * f + r * g) >> steps
+        assert f <= n and g <= n
+        if f == 1:
+            return 1 - 2 * (jac & 1)
+        if f == g:
+            return 0
+    raise AssertionError("no convergence")
+
+
+def test_divstep_jacobi_model_matches_sympy():
+    """The algorithm of the Jacobi kernel (batched all-positive divsteps), validated against sympy."""
+    import random
+
+    import sympy
+
+    rng = random.Random(2053)
+    for t in range(4000):
+        bits = rng.choice([2, 3, 5, 8, 16, 31, 32, 33, 61, 64, 65, 131, 520, 1028])
+        n = rng.getrandbits(bits) | 1
+        x = rng.randrange(n) if n > 1 else 0
+        if t % 6 == 0:                      # a common factor: the symbol is 0
+            d = rng.choice([3, 5, 7, 9, 15, 21, 2**31 - 1])
+            n, x = n * d, (x * d) % (n * d)
+        assert _posdivsteps_jacobi_model(x, n) == sympy.jacobi_symbol(x, n), (x, n)
+    for n in (3, 5, 7, 9, 2**64 - 1, 2**64 + 13):
+        for x in (0, 1, 2, n - 1, n - 2, (n + 1) // 2):
+            assert _posdivsteps_jacobi_model(x % n, n) == sympy.jacobi_symbol(x % n, n)
