@@ -50,7 +50,9 @@ HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # 157.3 TFLOP/s fp32 vector peak = that rate with packed FMA), 2.4 GHz.  Measured on this chip
 # (profiles/r01_ubench_valu_rates.txt): plain VALU 4.0-4.3 cycles, v_mad_u64_u32 4.5-5.0.
 VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4          # wave-instructions per second
-MAD_CYCLES, OTHER_CYCLES = 4.75, 4.15       # measured issue cost of v_mad_u64_u32 / of the other VALU instructions
+# measured issue cost (8 waves per SIMD) of v_mad_u64_u32 in the form the kernels use it (accumulator chain,
+# carry-out to an SGPR pair: 4.53-4.54 cycles) and of the other VALU instructions of the stream (4.03-4.3)
+MAD_CYCLES, OTHER_CYCLES = 4.53, 4.15
 INSTR_MODEL = ROOT / "profiles" / "r02_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits)
 HBM_MEASURED = ROOT / "profiles" / "r02_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
 

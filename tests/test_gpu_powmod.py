@@ -253,3 +253,17 @@ def test_powmod_nsquare_segments_are_bit_identical(eng, segments):
     finally:
         eng.set_segments(0)
         eng.set_limbs_per_lane(0)
+
+
+def test_exponent_with_a_very_long_run_of_zero_bits(eng):
+    """the squaring count of a schedule step used to be packed into 16 bits, so an
+    exponent with >= 65536 consecutive zero bits (2^70000) silently gave a wrong power.  Both the
+    generic sliding-window kernel and the N^2 tape must handle it."""
+    rng = random.Random(70000)
+    mod = rng.getrandbits(120) | (1 << 119) | 1
+    n = rng.getrandbits(60) | (1 << 59) | 1
+    bases = [2, 3, mod - 1] + [rng.randrange(mod) for _ in range(5)]
+    for e in (1 << 70000, (1 << 70000) + 1, (1 << 131072) + (1 << 3)):
+        assert eng.powmod_batch(bases, e, mod) == [pow(b, e, mod) for b in bases], e.bit_length()
+        nb = [b % (n * n) for b in bases]
+        assert eng.powmod_nsquare_batch(nb, e, n) == [pow(b, e, n * n) for b in nb], e.bit_length()

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Supplementary measurement (not the headline bench): biprimality-test modexps/s on one GPU.
+"""Supplementary measurement (superseded by `bench.py --workload biprime`, kept for the stage-by-stage
+figures): biprimality-test modexps/s on one GPU.
 
 configs[1]/[3] shape of BASELINE.json: `cands` candidate moduli (key_length bits + 2..5), 40
 Jacobi-1 bases each, party-1 exponent (N - p_1 - q_1 + 1)/4 (distributed_keygen.py:1094).
@@ -87,7 +88,7 @@ def main():
         "modexps_per_s": n / pm_s, "powmod_ms": pm_s * 1e3,
         "jacobi_per_s": args.cands * 160 / jac_s, "jacobi_ms": jac_s * 1e3,
         "sieve_candidates_per_s": len(mods) * 16 / sv_s, "sieve_ms": sv_s * 1e3, "sieve_primes": len(primes),
-        "geometry": eng.geometry(max(m.bit_length() for m in mods)),
+        "geometry": eng.geometry(max(m.bit_length() for m in mods), args.cands * 40, args.cands),   # of THIS launch (batch, groups)
         "cpu_single_core_modexps_per_s": None if cpu is None else cpu["rate_single_core"],
         "cpu_engine": None if cpu is None else cpu["engine_desc"],
     }))
