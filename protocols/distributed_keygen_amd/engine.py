@@ -335,7 +335,14 @@ class Engine:
             return out_t
 
         res = self._pipelined(vals, limbs2, limbs2, launch)
-        return (res, self.torch.cat(kept, dim=0)) if keep_rows else res
+        if not keep_rows:
+            return res
+        # the chunk results were allocated on the side streams; the concatenation reads them on the
+        # current stream (ordered after the side streams by _pipelined): tell the allocator
+        cur = self.torch.cuda.current_stream(self.device)
+        for t in kept:
+            t.record_stream(cur)
+        return res, self.torch.cat(kept, dim=0)
 
     # ------------------------------------------------------------------ chunked execution on several streams
     PIPELINE_MIN = 20000       # elements from which an int-level batch is cut into chunks
