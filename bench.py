@@ -40,10 +40,11 @@ from pathlib import Path
 ROOT = Path(__file__).resolve().parent
 sys.path.insert(0, str(ROOT))
 
-# The HIP runtime multiplexes streams onto 4 hardware queues by default; with more than 3 steps in
-# flight two streams then share a queue and serialise (measured: 4 streams 203 k modexps/s with 4
-# queues, 246-272 k with 8; tools/ab_queues.sh).  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# The HIP runtime multiplexes streams onto 4 hardware queues by default; two streams that share a queue
+# serialise (measured: 4 streams 203 k modexps/s with 4 queues, 246-272 k with 8; tools/ab_queues.sh; the
+# chunks of a 40 000-ciphertext int-level call after other streams have been used: 170-199 k/s with 8
+# queues, 273 k/s with 16; profiles/r02_hw_queue_collisions.txt).  Must be set before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU issue: 1024 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD (16 lanes per cycle;
@@ -409,8 +410,10 @@ def leg_single_batch(eng, torch, wl: DecryptWorkload, key_length: int) -> dict:
 def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
     """Python ints in -> Python ints out through the drop-in classes: GpuPaillierSharedKey
     .partial_decrypt_batch (pack, H2D, modexp, D2H, unpack) and .decrypt_batch (the same around the
-    recombination) — the loops distributed_keygen.py:463-466 and :510-515 as the patch runs them,
-    for one batch and for a 4x longer sequence (which the engine cuts into chunks on several streams)."""
+    recombination; `.decrypt_columns` is the form the patched _decrypt_sequence_raw uses: the own partials
+    stay on the device, received ones arrive as per-player lists) — the loops distributed_keygen.py:463-466
+    and :510-515 as the patch runs them, for one batch and for a 4x longer sequence (which the engine cuts
+    into chunks on several streams)."""
     from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
 
     key, L = wl.key, wl.L
@@ -425,19 +428,28 @@ def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
     for mult in (1, 4):
         count = wl.batch * mult
         others = {i: v * mult for i, v in others1.items()}
-        res, tm = {}, None
-        for rep in range(2):                                # the first pass warms allocations and pinned buffers
+        runs = []
+        for rep in range(4):                                # the first pass warms allocations and pinned buffers
             cts = [PlainCiphertext(c, key.n) for c in wl.cts * mult]
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            partials = gk.partial_decrypt_batch(cts)
+            partials, own_column = gk.partial_decrypt_batch(cts, keep_rows=True)
             t1 = time.perf_counter()
             tm = eng.last_timing
             dicts = [{wl.own: p, **{i: others[i][k] for i in others}} for k, p in enumerate(partials)]
             t2 = time.perf_counter()
-            msgs = gk.decrypt_batch(dicts)
+            msgs = gk.decrypt_batch(dicts)                  # per-ciphertext dictionaries, as the reference's loop has them
             t3 = time.perf_counter()
-            res = {"partial_decrypt_s": t1 - t0, "combine_s": t3 - t2}
+            msgs_c = gk.decrypt_columns({wl.own: own_column, **others}, count)   # per-player columns, as the patch has them
+            t4 = time.perf_counter()
+            assert msgs_c == msgs
+            if rep:
+                runs.append({"partial_decrypt_s": t1 - t0, "combine_s": t3 - t2, "columns_s": t4 - t3, "tm": tm})
+        # median of the three timed calls (a call that finds the GPU in a low power state after the host-only
+        # phase in between pays a wake-up of tens of milliseconds; all three are listed)
+        runs.sort(key=lambda r: r["partial_decrypt_s"])
+        res, tm = runs[1], runs[1]["tm"]
+        spread = [round(count / r["partial_decrypt_s"]) for r in runs]
         k = 7
         x = 1
         for i in wl.parties:
@@ -445,9 +457,11 @@ def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
         assert msgs[k] == (x - 1) // wl.n * wl.theta_inv % wl.n and len(msgs) == count
         out[f"n{count}"] = {
             "partial_decrypt_rate": count / res["partial_decrypt_s"],
+            "partial_decrypt_rate_of_each_call": spread,
             "partial_decrypt_vs_tensor_level": count / res["partial_decrypt_s"] / tensor_rate,
             "combine_rate": count / res["combine_s"],
-            "both_rate": count / (res["partial_decrypt_s"] + res["combine_s"]),
+            "combine_columns_rate": count / res["columns_s"],
+            "both_rate": count / (res["partial_decrypt_s"] + res["columns_s"]),
             "partial_decrypt_breakdown": {k2: (round(v, 5) if isinstance(v, float) else v) for k2, v in (tm or {}).items()},
         }
     out["value"] = out[f"n{wl.batch * 4}"]["partial_decrypt_rate"]
