@@ -366,7 +366,10 @@ class Engine:
         per = -(-total // nchunks)
         while len(self._side_streams) < nchunks:
             with torch.cuda.device(self.device):
-                self._side_streams.append(torch.cuda.Stream(device=self.device))
+                # high-priority streams are served by their own set of hardware queues: the chunks do not
+                # collide with (and serialise behind) the caller's other streams even when the process runs
+                # with few hardware queues (profiles/r02_hw_queue_collisions.txt)
+                self._side_streams.append(torch.cuda.Stream(device=self.device, priority=-1))
         in_pin = self._pinned("in", total, limbs_in)
         out_pin = self._pinned("out", total, limbs_out)
         in_np = in_pin.numpy().view(np.uint32)
