@@ -24,12 +24,26 @@ except ImportError:  # pragma: no cover - a checkout that has not been built yet
     _mxcodec = None
 
 
+def _codec():
+    """The C helper, looked up again if this module was imported before build.py had produced it."""
+    global _mxcodec
+    if _mxcodec is None:
+        try:
+            from . import _mxcodec as mod  # type: ignore
+
+            _mxcodec = mod
+        except ImportError:
+            pass
+    return _mxcodec
+
+
 def pack_into(values: Sequence[int], limbs: int, out: np.ndarray, row_offset: int = 0) -> None:
     """ints -> rows [row_offset, row_offset + len(values)) of the C-contiguous uint32 array `out`
     (e.g. a pinned staging buffer), without intermediate copies."""
-    if _mxcodec is not None and isinstance(values, (list, tuple)) and all(type(v) is int for v in values[:1]):
+    codec = _codec()
+    if codec is not None and isinstance(values, (list, tuple)) and all(type(v) is int for v in values[:1]):
         try:
-            _mxcodec.pack_into(values, limbs, out, row_offset)
+            codec.pack_into(values, limbs, out, row_offset)
             return
         except TypeError:
             pass                                    # int-like objects (e.g. gmpy2.mpz): the generic path converts them
@@ -60,8 +74,9 @@ def unpack(rows: np.ndarray) -> List[int]:
     rows = np.ascontiguousarray(rows, dtype="<u4")
     if rows.ndim == 1:
         rows = rows.reshape(1, -1)
-    if _mxcodec is not None:
-        return _mxcodec.unpack(rows, rows.shape[1]) if rows.shape[0] else []
+    codec = _codec()
+    if codec is not None:
+        return codec.unpack(rows, rows.shape[1]) if rows.shape[0] else []
     nbytes = rows.shape[1] * 4
     raw = rows.tobytes()
     return [int.from_bytes(raw[i * nbytes : (i + 1) * nbytes], "little") for i in range(rows.shape[0])]

@@ -342,7 +342,7 @@ def test_c_codec_matches_int_to_bytes():
 
     from protocols.distributed_keygen_amd import limbs
 
-    assert limbs._mxcodec is not None, "the C codec (csrc/mx_pycodec.c) must be built with the library"
+    assert limbs._codec() is not None, "the C codec (csrc/mx_pycodec.c) must be built with the library"
     rng = random.Random(5)
     vals = [0, 1, (1 << 4128) - 1] + [rng.getrandbits(rng.randrange(1, 4128)) for _ in range(200)]
     rows = limbs.pack(vals, 129)
