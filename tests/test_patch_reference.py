@@ -353,3 +353,35 @@ def test_limits_are_checked_before_any_round(ref):
         patch.check_limits(None, [3, 5, (1 << 21) + 7], 1024, 3)
     with pytest.raises(ValueError, match="key_length"):
         patch.check_limits(None, [3, 5], 2100, 3)
+
+
+def test_install_can_leave_the_scalar_methods_to_the_reference(ref):
+    """install(scalars=False): single-ciphertext decrypt() keeps the reference's own scalar path, the
+    sequence path is batched."""
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import patch
+
+    psk, dk, _ = ref
+    orig_pd, orig_d = psk.PaillierSharedKey.partial_decrypt, psk.PaillierSharedKey.decrypt
+    eng = FakeEngine()
+    patch.install(engine=eng, scalars=False)
+    try:
+        assert psk.PaillierSharedKey.partial_decrypt is orig_pd and psk.PaillierSharedKey.decrypt is orig_d
+        key, parties = _parties(ref, None)
+        cts = _ciphertexts(ref, key, [9, 8, 7])
+
+        async def one():
+            return await asyncio.gather(*[dp._decrypt_raw(cts[0]) for dp in parties])
+
+        eng.calls.clear()
+        assert [e.value for e in asyncio.run(one())] == [9, 9, 9]
+        assert not [c for c in eng.calls if c[0] in ("powmod_batch", "combine_batch")]      # the reference's own arithmetic
+
+        async def seq():
+            return await asyncio.gather(*[dp._decrypt_sequence_raw(list(cts)) for dp in parties])
+
+        assert [[e.value for e in r] for r in asyncio.run(seq())] == [[9, 8, 7]] * 3
+        assert sum(1 for c in eng.calls if c == ("powmod_batch", 3)) == 3
+    finally:
+        patch.uninstall()
+    assert psk.PaillierSharedKey.partial_decrypt is orig_pd

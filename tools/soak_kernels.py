@@ -35,7 +35,7 @@ def main():
                 b = bits - rng.randrange(0, 33)
                 m = rng.getrandbits(b) | (1 << (b - 1)) | 1
                 if g == 1:
-                    m = (3 * 5 * 7 * 11) * (rng.getrandbits(b - 12) | 1)
+                    m = (3 * 5 * 7 * 11) * (rng.getrandbits(max(2, b - 12)) | 1)
                 vals = []
                 for k in range(64):
                     kind = k % 8
