@@ -27,9 +27,37 @@ def test_three_party_keygen_hot_path_finds_a_biprime():
     primes = oracle.small_prime_list(2000)
     found = None
     tested = sieved = 0
+    from protocols.distributed_keygen_amd import shamir
+    import sympy
+
+    # the Shamir field of the round (DK:647-651) and textbook sharings of degree t (p_i, q_i) and 2t (zero)
+    t = 1
+    field = int(sympy.nextprime(2 ** (2 * (key_length // 2 + math.ceil(math.log2(n_parties))))))
+
+    def share_out(secret, degree):
+        coeffs = [secret] + [rng.randrange(field) for _ in range(degree)]
+        return {j: sum(c * pow(j, e, field) for e, c in enumerate(coeffs)) % field for j in range(1, n_parties + 1)}
+
     for _round in range(40):
         shares = [synthetic.candidate_shares(rng, n_parties, key_length // 2) for _ in range(batch)]
         moduli = [sum(p) * sum(q) for p, q in shares]
+        if _round == 0:
+            # DK:1262-1284 on the device: every party's share of every candidate modulus (p * q + zero in
+            # the Shamir field), then the reconstruction of all candidates and their sieve in one pass
+            p_sh = [[share_out(pi, t) for pi in ps] for ps, _ in shares]          # [cand][owner] -> {holder: share}
+            q_sh = [[share_out(qi, t) for qi in qs] for _, qs in shares]
+            z_sh = [[share_out(0, 2 * t) for _ in range(n_parties)] for _ in shares]
+            n_shares = {}
+            for j in range(1, n_parties + 1):                                         # party j sums what it holds
+                pj = [sum(o[j] for o in cand) % field for cand in p_sh]
+                qj = [sum(o[j] for o in cand) % field for cand in q_sh]
+                zj = [sum(o[j] for o in cand) % field for cand in z_sh]
+                n_shares[j] = shamir.mul_add_shares_batch(pj, qj, zj, field, eng)
+                assert n_shares[j][:3] == [oracle.shamir_mul_add(a, b, c, field) for a, b, c in zip(pj[:3], qj[:3], zj[:3])]
+            assert shamir.reconstruct_batch(n_shares, field, 2 * t, eng) == moduli
+            bad, surviving = shamir.reconstruct_and_sieve_batch(n_shares, field, 2 * t, primes, eng)
+            assert bad == [oracle.small_prime_divisors_test(primes, m) for m in moduli]
+            assert surviving == {k: m for k, (m, b) in enumerate(zip(moduli, bad)) if not b}
         has_div = biprime.small_prime_divisors_test_batch(primes, moduli, eng)          # DK:1288-1292
         surv = [k for k, bad in enumerate(has_div) if not bad]
         sieved += batch - len(surv)
