@@ -276,10 +276,11 @@ class Engine:
             self._combine_plans.popitem(last=False)
         return plan
 
-    def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None):
+    def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None, segments: Optional[int] = None):
         """out[e] = bases[e]^exp mod n^2 (rows of the width of n^2), computed through pairs modulo n
         (include/mxpaillier.h: mx_powmod_nsquare_prepare / _run) — the fast path of the partial
-        decryption PSK:92.  The per-key plan is prepared on first use; afterwards a call is one launch."""
+        decryption PSK:92.  The per-key plan is prepared on first use; afterwards a call is launches only
+        (`segments` of them, default: the engine's setting, 0 = the library's choice)."""
         if exp < 0:
             raise ValueError("negative exponent: invert the base first (paillier_shared_key.py:89-91)")
         batch, limbs2 = bases_t.shape
@@ -293,8 +294,8 @@ class Engine:
             self._use_plan(plan)
             ws = self._workspace(self.lib.mx_powmod_nsquare_run_workspace_bytes(plan.desc, batch))
             rc = self.lib.mx_powmod_nsquare_run(
-                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl, self._segments, ws.data_ptr(),
-                ws.numel(), self._stream_ptr(),
+                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl,
+                self._segments if segments is None else int(segments), ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_nsquare_run")
         return out_t
@@ -319,7 +320,9 @@ class Engine:
             t0 = _t.perf_counter()
             rows = _limbs.pack(vals, limbs2)
             t1 = _t.perf_counter()
-            out_t = self.powmod_nsquare_t(self.to_device(rows), n, exp)
+            # a lone launch that is waited for right away: nothing else is in flight whose drain segments
+            # could shorten, and the three extra segment boundaries would cost ~1 %
+            out_t = self.powmod_nsquare_t(self.to_device(rows), n, exp, segments=1 if self._segments == 0 else None)
             out = self.to_host(out_t)
             t2 = _t.perf_counter()
             res = _limbs.unpack(out)
