@@ -12,7 +12,7 @@ a reinterpret — no per-integer Python arithmetic — and a stored key becomes 
 
 from __future__ import annotations
 
-from typing import Any, Dict, Iterable, List, Sequence, Tuple
+from typing import Any, Dict, List, Sequence, Tuple
 
 import numpy as np
 

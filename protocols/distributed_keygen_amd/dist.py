@@ -16,7 +16,7 @@ them with the ``gloo`` backend on CPU tensors and a test double of the engine.
 
 from __future__ import annotations
 
-from typing import Any, List, Optional, Sequence, Tuple
+from typing import Any, Sequence, Tuple
 
 
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:

@@ -20,7 +20,7 @@ computed by the engine's device inverse too.
 from __future__ import annotations
 
 from dataclasses import dataclass, field
-from typing import Any, Dict, Iterable, List, Optional, Sequence
+from typing import Any, Dict, Iterable, List, Sequence
 
 def _ref_ciphertext_type() -> Any:
     """The reference's ciphertext type, when its (un-vendored) package has been imported in this
