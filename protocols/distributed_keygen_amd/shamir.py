@@ -29,20 +29,24 @@ def _engine(engine: Any) -> Any:
     return default_engine()
 
 
-def lagrange_coefficients_at_zero(points: Sequence[int], prime: int) -> List[int]:
+def lagrange_coefficients_at_zero(points: Sequence[int], prime: int, engine: Any = None) -> List[int]:
     """lambda_i = prod_{j != i} x_j / (x_j - x_i) mod prime for the evaluation points x (party indices):
-    a handful of word-sized values per round — host arithmetic, as in the reference."""
+    products of a handful of word-sized values on the host, as in the reference; the modular inverses
+    of the denominators go through the engine's device inverse when an engine is given (so that the
+    batched path has no host big-integer inversion at all), else through ``pow(den, -1, prime)``."""
     if len(set(points)) != len(points):
         raise ValueError("evaluation points must be distinct")
-    out = []
+    nums, dens = [], []
     for i in points:
         num = den = 1
         for j in points:
             if j != i:
                 num = num * j % prime
                 den = den * (j - i) % prime
-        out.append(num * pow(den, -1, prime) % prime)
-    return out
+        nums.append(num)
+        dens.append(den)
+    invs = engine.modinv_batch(dens, prime) if engine is not None else [pow(d, -1, prime) for d in dens]
+    return [n * v % prime for n, v in zip(nums, invs)]
 
 
 def mul_add_shares_batch(p_shares: Sequence[int], q_shares: Sequence[int], zero_shares: Sequence[int], prime: int,
@@ -63,8 +67,9 @@ def reconstruct_batch(shares_by_party: Dict[int, Sequence[int]], prime: int, deg
         raise ValueError("every party needs one share per candidate")
     if count == 0:
         return []
-    coeffs = lagrange_coefficients_at_zero(points, prime)
-    return _engine(engine).shamir_lincomb_batch([shares_by_party[i] for i in points], coeffs, prime)
+    eng = _engine(engine)
+    coeffs = lagrange_coefficients_at_zero(points, prime, eng)
+    return eng.shamir_lincomb_batch([shares_by_party[i] for i in points], coeffs, prime)
 
 
 def reconstruct_and_sieve_batch(shares_by_party: Dict[int, Sequence[int]], prime: int, degree: int,
@@ -79,5 +84,6 @@ def reconstruct_and_sieve_batch(shares_by_party: Dict[int, Sequence[int]], prime
         raise ValueError("every party needs one share per candidate")
     if count == 0:
         return [], {}
-    coeffs = lagrange_coefficients_at_zero(points, prime)
-    return _engine(engine).shamir_reconstruct_sieve_batch([shares_by_party[i] for i in points], coeffs, prime, list(prime_list))
+    eng = _engine(engine)
+    coeffs = lagrange_coefficients_at_zero(points, prime, eng)
+    return eng.shamir_reconstruct_sieve_batch([shares_by_party[i] for i in points], coeffs, prime, list(prime_list))
