@@ -550,6 +550,21 @@ class Engine:
         g_t = self.to_device(_limbs.pack([(1 + (m % n) * n) % n2 for m in messages], limbs))
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, g_t, n2, out_t=rn_t)))
 
+    def randomize_batch(self, ciphertexts: Sequence[int], randomness: Sequence[int], n: int) -> List[int]:
+        """Re-randomisation of Paillier ciphertexts, c * r^n mod n^2 for every (c, r) — what the
+        un-vendored scheme's ``randomize`` does before a ciphertext is sent (README.md:165-171 of the
+        reference: a ciphertext must be fresh when it leaves); r^n through the N^2 pair kernel."""
+        if len(ciphertexts) != len(randomness):
+            raise ValueError("one randomness per ciphertext expected")
+        if len(ciphertexts) == 0:
+            return []
+        _check_modulus(n)
+        n2 = n * n
+        limbs = _limbs.limbs_for(n2)
+        rn_t = self.powmod_nsquare_t(self.to_device(_limbs.pack([_reduce(r, n2) for r in randomness], limbs)), n, n)
+        c_t = self.to_device(_limbs.pack([_reduce(c, n2) for c in ciphertexts], limbs))
+        return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, c_t, n2, out_t=rn_t)))
+
     # ------------------------------------------------------------------ Shamir field of the key generation
     def shamir_fma_t(self, a_t, b_t, c_t, prime: int, out_t=None):
         """out[e] = (a[e]*b[e] + c[e]) mod prime — this party's share of every candidate modulus

@@ -492,3 +492,24 @@ def test_jacobi_unbalanced_operands_and_safety_net(eng, monkeypatch):
         monkeypatch.setenv("MX_JACOBI_MAX_BATCHES", cut)
         assert eng.jacobi_batch(rows, mods) == want, cut
     monkeypatch.delenv("MX_JACOBI_MAX_BATCHES")
+
+
+def test_randomize_batch_keeps_the_plaintext(eng):
+    """c * r^N mod N^2: bit-exact vs pow, and the re-randomised ciphertexts decrypt to the same messages."""
+    from protocols.distributed_keygen_amd import synthetic
+
+    key = synthetic.make_key(1024, 3, 1)
+    n, n2 = key.n, key.n_square
+    rng = random.Random(404)
+    msgs = [0, 1, n - 1] + [rng.randrange(n) for _ in range(13)]
+    cts = eng.encrypt_batch(msgs, [rng.randrange(1, n) for _ in msgs], n)
+    rs = [rng.randrange(1, n) for _ in msgs]
+    fresh = eng.randomize_batch(cts, rs, n)
+    assert fresh == [c * pow(r, n, n2) % n2 for c, r in zip(cts, rs)] and fresh != cts
+    partials = []
+    for i in (1, 2, 3):
+        e = key.exponent(i)
+        bases = fresh if e >= 0 else eng.modinv_batch(fresh, n2)
+        partials.append(eng.powmod_nsquare_batch(bases, abs(e), n))
+    got, ok = eng.combine_columns(partials, n, key.theta_inv)
+    assert all(ok) and got == msgs
