@@ -18,5 +18,6 @@ _os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 from . import limbs  # noqa: F401,E402
 from .engine import Engine, default_engine  # noqa: F401,E402
+from .operators import mod_inv, mod_inv_batch, pow_mod, pow_mod_batch, pow_mod_batch_multi  # noqa: F401,E402
 
 __version__ = "0.1.0"

@@ -32,6 +32,7 @@ from .shared_key import GpuPaillierSharedKey
 
 DEFAULT_PACKAGE = "tno.mpc.protocols.distributed_keygen"
 _saved: Dict[Any, Dict[str, Any]] = {}
+_saved_names: Dict[Any, Dict[str, Any]] = {}      # module -> {name: original leaf function}
 
 
 def _save(cls: Any, name: str) -> None:
@@ -74,8 +75,14 @@ def _gpu_key(key: Any, engine: Any) -> GpuPaillierSharedKey:
     return cached
 
 
-def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = True) -> None:
-    """``scalars=False`` leaves the reference's own single-ciphertext ``PaillierSharedKey.partial_decrypt``
+def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = True, leaf: bool = False) -> None:
+    """``leaf=True`` additionally rebinds the arithmetic leaf itself — the names ``pow_mod`` / ``mod_inv``
+    that distributed_keygen.py:35 and paillier_shared_key.py:20 import from the un-vendored
+    tno.mpc.encryption_schemes.utils — to ``operators.pow_mod`` / ``operators.mod_inv``, so that any
+    remaining scalar call site of those modules (e.g. ``mod_inv(theta, n)`` in the reference's own
+    ``PaillierSharedKey.__init__``, paillier_shared_key.py:50) runs on the engine too.
+
+    ``scalars=False`` leaves the reference's own single-ciphertext ``PaillierSharedKey.partial_decrypt``
     / ``.decrypt`` in place (and with them ``DistributedPaillier.decrypt()`` of ONE ciphertext): a lone
     modexp is a latency-bound chain of ~4200 dependent squarings — 39.5 ms on the GPU at key_length
     2048 whatever the batch size up to ~1000, against ~13 ms for one ``gmpy2.powmod`` on a host core —
@@ -86,6 +93,15 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
     PSK = psk_mod.PaillierSharedKey
     DP = dk_mod.DistributedPaillier
     check_limits(engine)
+    if leaf:
+        from . import operators
+
+        for mod, names in ((psk_mod, ("pow_mod", "mod_inv")), (dk_mod, ("pow_mod", "mod_inv"))):
+            for name in names:
+                if hasattr(mod, name):
+                    _saved_names.setdefault(mod, {}).setdefault(name, getattr(mod, name))
+                    op = getattr(operators, name)
+                    setattr(mod, name, (lambda f: (lambda *a: f(*a, engine=engine)))(op))
 
     # ------------------------------------------------------------------ PaillierSharedKey
     # The scalar methods keep the reference's semantics and hold NO state between calls: any number of
@@ -259,6 +275,10 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
 
 
 def uninstall() -> None:
+    for mod, names in _saved_names.items():
+        for name, orig in names.items():
+            setattr(mod, name, orig)
+    _saved_names.clear()
     for cls, names in _saved.items():
         for name, orig in names.items():
             if orig is None:

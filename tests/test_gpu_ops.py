@@ -513,3 +513,24 @@ def test_randomize_batch_keeps_the_plaintext(eng):
         partials.append(eng.powmod_nsquare_batch(bases, abs(e), n))
     got, ok = eng.combine_columns(partials, n, key.theta_inv)
     assert all(ok) and got == msgs
+
+
+def test_operator_surface_pow_mod_and_mod_inv(eng):
+    """operators.pow_mod / mod_inv (the names the reference imports at DK:35, PSK:20) and their batched forms."""
+    from protocols.distributed_keygen_amd import operators
+
+    rng = random.Random(35)
+    mod = rng.getrandbits(1027) | (1 << 1026) | 1
+    vals = [rng.randrange(1, mod) for _ in range(9)]
+    e = rng.getrandbits(300)
+    assert operators.pow_mod(vals[0], e, mod, engine=eng) == pow(vals[0], e, mod)
+    assert operators.pow_mod_batch(vals, e, mod, engine=eng) == [pow(v, e, mod) for v in vals]
+    import math
+
+    inv_ok = [v for v in vals if math.gcd(v, mod) == 1]
+    assert operators.pow_mod_batch(inv_ok, -e, mod, engine=eng) == [pow(v, -e, mod) for v in inv_ok]
+    assert operators.mod_inv(inv_ok[0], mod, engine=eng) == pow(inv_ok[0], -1, mod)
+    with pytest.raises(ValueError):
+        operators.mod_inv(0, mod, engine=eng)
+    with pytest.raises(ValueError):
+        operators.pow_mod(3, 5, 1 << 64, engine=eng)           # even modulus: no Montgomery arithmetic, no CPU path

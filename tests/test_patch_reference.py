@@ -385,3 +385,34 @@ def test_install_can_leave_the_scalar_methods_to_the_reference(ref):
     finally:
         patch.uninstall()
     assert psk.PaillierSharedKey.partial_decrypt is orig_pd
+
+
+def test_leaf_operators_can_be_rebound(ref):
+    """install(leaf=True) rebinds pow_mod / mod_inv where the reference imported them by name
+    (distributed_keygen.py:35, paillier_shared_key.py:20): the reference's own PaillierSharedKey
+    constructor (mod_inv at :50) and scalar partial_decrypt (pow_mod at :92) then run on the engine."""
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import operators, patch
+
+    psk, dk, mg = ref
+    orig = (psk.pow_mod, psk.mod_inv, dk.pow_mod)
+    eng = FakeEngine()
+    patch.install(engine=eng, scalars=False, leaf=True)
+    try:
+        assert psk.pow_mod is not orig[0] and psk.mod_inv is not orig[1] and dk.pow_mod is not orig[2]
+        eng.calls.clear()
+        key, parties = _parties(ref, None)                       # the reference's constructor: mod_inv(theta, n)
+        assert ("modinv_batch", 1) in eng.calls
+        cts = _ciphertexts(ref, key, [41])
+        eng.calls.clear()
+        p = parties[0].secret_key.partial_decrypt(cts[0])        # the reference's own scalar method, GPU leaf
+        assert ("powmod_batch", 1) in eng.calls
+        from oracle import oracle
+
+        assert p == oracle.partial_decrypt(cts[0].peek_value(), key["n"], 1, key["degree"], key["n_fac"], key["shares"][1])
+        assert operators.pow_mod(7, -3, 101, engine=eng) == pow(7, -3, 101)
+        assert operators.mod_inv(7, 101, engine=eng) == pow(7, -1, 101)
+        assert operators.pow_mod_batch_multi([[2, 3], [5]], [10, 3], [101, 103], engine=eng) == [[pow(2, 10, 101), pow(3, 10, 101)], [pow(5, 3, 103)]]
+    finally:
+        patch.uninstall()
+    assert (psk.pow_mod, psk.mod_inv, dk.pow_mod) == orig
