@@ -44,7 +44,9 @@ sys.path.insert(0, str(ROOT))
 # serialise (measured: 4 streams 203 k modexps/s with 4 queues, 246-272 k with 8; tools/ab_queues.sh; the
 # chunks of a 40 000-ciphertext int-level call after other streams have been used: 170-199 k/s with 8
 # queues, 273 k/s with 16; profiles/r02_hw_queue_collisions.txt).  Must be set before the runtime initialises.
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+from protocols.distributed_keygen_amd import configure_hw_queues  # noqa: E402  (no GPU call: sets GPU_MAX_HW_QUEUES)
+
+configure_hw_queues(16)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU issue: 1024 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD (16 lanes per cycle;

@@ -259,8 +259,22 @@ int mx_select_first(const uint32_t* d_rows, const int8_t* d_flags, uint32_t* d_o
 int mx_selftest_lanes(void* stream);
 /* Modexp lane geometry: 9 (narrow: more lanes per element, best for one small batch at a time),
  * 18 (wide: fewer, busier lanes; best when the GPU is saturated, e.g. several batches in flight on
- * different streams) or 0 (automatic from the batch size, the default).  Process-wide. */
+ * different streams) or 0 (automatic from the batch size, the default).  Process-wide; only the older entry
+ * points without a limbs_per_lane argument read it. */
 int mx_set_limbs_per_lane(int limbs_per_lane);
+/* Developer overrides, explicit calls only (the library reads no environment variables).  value 0 restores
+ * the default.  MX_KNOB_N2_SEGMENTS: launches per mx_powmod_nsquare_run exponentiation when the caller passes
+ * segments = 0 (1..64).  MX_KNOB_JACOBI_MAX_BATCHES: value v > 0 limits the Jacobi kernel to v - 1 divstep batches
+ * so that its fallback kernel has to finish the symbols (test knob for the safety net).  Process-wide; returns MX_OK / MX_ERR_ARG. */
+#define MX_KNOB_N2_SEGMENTS 1
+#define MX_KNOB_JACOBI_MAX_BATCHES 2
+int mx_debug_knob(int knob, int value);
+/* Enqueues a kernel of ONE wavefront that idles for `microseconds` (0..1 000 000) on `stream` and touches no
+ * memory.  A concurrency probe: two streams that the HIP runtime has mapped to the same hardware queue run
+ * their spins one after the other, two streams on different queues run them side by side — which is what
+ * decides whether chunks of a batch launched on those streams fill the machine together or serialise
+ * (GPU_MAX_HW_QUEUES is read once when the runtime initialises and cannot be queried).  Never synchronises. */
+int mx_spin(int64_t microseconds, void* stream);
 /* Engine geometry chosen for a modulus of `mod_bits` bits: lanes per element (K), limbs per lane
  * (L), limb width (W) and Montgomery blocks; returns MX_OK or MX_ERR_SIZE. */
 int mx_geometry(int mod_bits, int* lanes_per_element, int* limbs_per_lane, int* limb_bits, int* blocks);

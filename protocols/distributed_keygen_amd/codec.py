@@ -54,15 +54,16 @@ def rows_from_wire(values: Sequence[Any], limbs: int, modulus: int = 0) -> np.nd
     nbytes = 4 * limbs
     if not isinstance(values, (list, tuple)):
         values = list(values)
+    from . import limbs as _limbs
+
     if all(type(v) is int for v in values):
         try:
-            from . import limbs as _limbs
-
-            return _limbs.pack(values, limbs)
+            rows = _limbs.pack(values, limbs)
         except ValueError:
             if not modulus:
                 raise
             return _limbs.pack([v % modulus for v in values], limbs)
+        return _reduce_rows(rows, modulus) if modulus else rows
     buf = bytearray(nbytes * len(values))
     for k, v in enumerate(values):
         if isinstance(v, dict) and v.get("type") == "int":
@@ -84,7 +85,25 @@ def rows_from_wire(values: Sequence[Any], limbs: int, modulus: int = 0) -> np.nd
                 buf[k * nbytes : (k + 1) * nbytes] = iv.to_bytes(nbytes, "little")
             except OverflowError as exc:
                 raise ValueError(f"value does not fit in {limbs} uint32 limbs") from exc
-    return np.frombuffer(bytes(buf), dtype="<u4").reshape(len(values), limbs).copy()
+    rows = np.frombuffer(bytes(buf), dtype="<u4").reshape(len(values), limbs).copy()
+    return _reduce_rows(rows, modulus) if modulus else rows
+
+
+def _reduce_rows(rows: np.ndarray, modulus: int) -> np.ndarray:
+    """Rows that fit the row width but are >= modulus -> their residue (in place).  The comparison is
+    vectorised (most significant differing limb decides); only the offenders become Python ints."""
+    count, limbs = rows.shape
+    if count == 0 or modulus.bit_length() > 32 * limbs:
+        return rows                                  # every value of this width is below the modulus
+    m = np.frombuffer(modulus.to_bytes(4 * limbs, "little"), dtype="<u4")
+    diff = rows != m
+    top = limbs - 1 - np.argmax(diff[:, ::-1], axis=1)          # most significant differing limb (0 if none differ)
+    sel = np.arange(count)
+    ge = ~diff.any(axis=1) | (rows[sel, top] > m[top])
+    for k in np.nonzero(ge)[0]:
+        v = int.from_bytes(rows[k].tobytes(), "little") % modulus
+        rows[k] = np.frombuffer(v.to_bytes(4 * limbs, "little"), dtype="<u4")
+    return rows
 
 
 def rows_to_wire(rows: np.ndarray) -> List[Dict[str, Any]]:

@@ -16,6 +16,8 @@
 namespace mxh {
 thread_local hipError_t g_last_hip = hipSuccess;
 int g_limbs_per_lane = 0;
+int g_knob_n2_segments = 0;
+int g_knob_jacobi_max_batches = 0;
 }
 MxProfile g_mx_profile;
 
@@ -206,6 +208,13 @@ __device__ int lanes_check(unsigned v) {
   return bad;
 }
 
+// Occupies one wavefront slot for `ticks` periods of the 100 MHz real-time counter and does nothing else:
+// the probe with which a caller finds out whether two of its streams run concurrently (mx_spin).
+__global__ void spin_kernel(unsigned long long ticks) {
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+
 __global__ void lanes_selftest_kernel(int* out) {
   unsigned v = threadIdx.x * 40503u + 977u;
   int bad = 0;
@@ -243,6 +252,15 @@ int mx_set_limbs_per_lane(int limbs_per_lane) {
   if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
   g_limbs_per_lane = limbs_per_lane;
   return MX_OK;
+}
+
+int mx_debug_knob(int knob, int value) {
+  if (value < 0) return MX_ERR_ARG;
+  switch (knob) {
+    case MX_KNOB_N2_SEGMENTS: if (value > 64) return MX_ERR_ARG; g_knob_n2_segments = value; return MX_OK;
+    case MX_KNOB_JACOBI_MAX_BATCHES: g_knob_jacobi_max_batches = value; return MX_OK;
+  }
+  return MX_ERR_ARG;
 }
 
 int mx_profile(int enable) {
@@ -337,6 +355,13 @@ int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limb
   if (!choose_geometry(mod_bits, g, limbs_per_lane ? limbs_per_lane : auto_limbs_per_lane(mod_bits, batch, groups)))
     return MX_ERR_SIZE;
   *k = g.K; *l = g.L; *w = g.W; *blocks = g.nblk;
+  return MX_OK;
+}
+
+int mx_spin(int64_t microseconds, void* stream) {
+  if (microseconds < 0 || microseconds > 1000000) return MX_ERR_ARG;
+  hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+  MX_HIP(hipGetLastError());
   return MX_OK;
 }
 
@@ -609,7 +634,7 @@ extern "C" int mx_jacobi_dev_range(const uint32_t* d_values, int8_t* d_out, cons
   a.count = groups * count; a.group_size = group_size; a.limbs = limbs;
   a.first = first; a.per_group = count; a.skip = d_skip_counts; a.skip_threshold = skip_threshold;
   a.max_batches = (32 * limbs * 9 / 2) / mx::JSTEPS + 8;
-  if (const char* e = getenv("MX_JACOBI_MAX_BATCHES")) a.max_batches = atoi(e);   // developer knob: exercises the safety net
+  if (g_knob_jacobi_max_batches > 0) a.max_batches = g_knob_jacobi_max_batches - 1;   // developer knob: exercises the safety net
   if (limbs <= 3) return launch_jacobi<3>(a, s);
   if (limbs <= 5) return launch_jacobi<5>(a, s);
   if (limbs <= 9) return launch_jacobi<9>(a, s);

@@ -62,10 +62,7 @@ int n2_auto_limbs_per_lane(int n_bits, int64_t batch) {
 // tens of milliseconds is cut so that a burst of such launches drains at a finer grain (measured with
 // bench.py --steps 20: the last round of 4 launches in flight costs ~3 % of the run unsegmented).
 int n2_auto_segments(int n_sqr, int64_t nblocks) {
-  if (const char* e = getenv("MX_N2_SEGMENTS")) {
-    int v = atoi(e);
-    if (v >= 1 && v <= 64) return v;
-  }
+  if (g_knob_n2_segments >= 1) return g_knob_n2_segments;
   return (n_sqr >= 2048 && nblocks >= 256) ? 4 : 1;
 }
 

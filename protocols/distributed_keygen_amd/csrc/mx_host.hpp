@@ -193,14 +193,13 @@ inline std::vector<u32> pack_sliding_ops(const std::vector<SlidingOp>& ops) {
 
 // Limbs per lane (9 narrow / 18 wide) are a per-call argument of the entry points that end in _lpl,
 // _dev or _run.  The older entry points without that argument honour a process-wide override
-// (mx_set_limbs_per_lane, or the environment variable MX_LIMBS_PER_LANE); 0 = automatic.
+// (mx_set_limbs_per_lane); 0 = automatic.  The library reads NO environment variables: developer
+// overrides are explicit calls (mx_debug_knob), so a stray variable cannot change a production launch.
 extern int g_limbs_per_lane;
+extern int g_knob_n2_segments;        // MX_KNOB_N2_SEGMENTS: 0 = automatic
+extern int g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
 inline int override_limbs_per_lane() {
   if (g_limbs_per_lane == LIMBS_PER_LANE || g_limbs_per_lane == LIMBS_PER_LANE_WIDE) return g_limbs_per_lane;
-  if (const char* e = getenv("MX_LIMBS_PER_LANE")) {
-    int v = atoi(e);
-    if (v == LIMBS_PER_LANE || v == LIMBS_PER_LANE_WIDE) return v;
-  }
   return 0;
 }
 

@@ -46,6 +46,8 @@ def _pad_rows(t, rows: int):
     if t.shape[0] == rows:
         return t
     reps = rows - t.shape[0]
+    if t.shape[0] == 0:        # an empty shard (fewer rows than ranks): nothing to repeat
+        return torch.zeros((rows,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     return torch.cat([t, t[-1:].expand(reps, *t.shape[1:])], dim=0).contiguous()
 
 

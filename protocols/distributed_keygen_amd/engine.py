@@ -54,7 +54,8 @@ class Engine:
         self._segments = 0                     # launches per N^2 exponentiation (0 = automatic; include/mxpaillier.h)
         self._n2_plans: "OrderedDict[Tuple[int, int], _Plan]" = OrderedDict()
         self._combine_plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
-        self._side_streams: List[Any] = []     # chunked int-level batches (_pipelined)
+        self._side_streams: List[Any] = []     # chunked int-level batches (_pipelined): streams verified concurrent
+        self._side_streams_capped = False      # the process has fewer concurrent queues than chunks were wanted
         self._pin: Dict[str, Any] = {}         # pinned staging buffers of _pipelined
         self.last_timing: Optional[Dict[str, Any]] = None   # host/GPU time split of the last int-level modexp batch
 
@@ -78,9 +79,15 @@ class Engine:
 
     def _use_plan(self, plan: _Plan) -> None:
         """Order the current stream after the plan's uploads if they were enqueued on another stream."""
+        cur = self.torch.cuda.current_stream(self.device)
+        if plan.stream_ptr != int(cur.cuda_stream):
+            # the block was allocated on the stream that prepared it: tell the caching allocator that this
+            # stream reads it too, so that an evicted plan's memory is not handed out while launches of
+            # this stream that use it are still in flight
+            plan.block.record_stream(cur)
         if plan.ready is not None:
-            if plan.stream_ptr != self._stream_ptr():
-                self.torch.cuda.current_stream(self.device).wait_event(plan.ready)
+            if plan.stream_ptr != int(cur.cuda_stream):
+                cur.wait_event(plan.ready)
             if plan.ready.query():
                 plan.ready = None
 
@@ -120,6 +127,12 @@ class Engine:
         k, l, w, b = (ctypes.c_int() for _ in range(4))
         _lib.check(self.lib.mx_powmod_geometry_for(mod_bits, batch, groups, self._lpl, k, l, w, b), "mx_powmod_geometry_for")
         return k.value, l.value, w.value, b.value
+
+    def debug_knob(self, knob: str, value: int) -> None:
+        """Developer overrides of the library (include/mxpaillier.h: mx_debug_knob; process-wide, 0 restores
+        the default): "n2_segments", "jacobi_max_batches"."""
+        ids = {"n2_segments": 1, "jacobi_max_batches": 2}
+        _lib.check(self.lib.mx_debug_knob(ids[knob], int(value)), "mx_debug_knob")
 
     def profile(self, enable: bool) -> None:
         """Start/stop recording events around every modexp kernel launch (process-wide)."""
@@ -351,6 +364,61 @@ class Engine:
     PIPELINE_MIN = 20000       # elements from which an int-level batch is cut into chunks
     PIPELINE_STREAMS = 8
 
+    def stream_concurrency(self, streams: Sequence[Any], spin_us: int = 400) -> List[Any]:
+        """The largest prefix-greedy subset of `streams` whose kernels demonstrably run side by side.
+        The HIP runtime maps streams onto GPU_MAX_HW_QUEUES hardware queues (4 unless the variable was
+        set before the runtime initialised — it cannot be queried or changed afterwards) and two streams
+        on one queue serialise.  Measured, not assumed: every candidate stream gets one idle one-wavefront
+        kernel (mx_spin) together with the streams accepted so far; if the set takes about one spin it is
+        concurrent, if it takes two the newcomer shares a queue with an accepted stream and is dropped.
+        Waits for the device first (one-time cost when the chunk streams are created)."""
+        import time as _t
+
+        torch = self.torch
+        accepted: List[Any] = []
+        with torch.cuda.device(self.device):
+            torch.cuda.synchronize(self.device)
+            for cand in streams:
+                trial = accepted + [cand]
+                best = None
+                for _ in range(2):                       # the first launch on a fresh stream binds its queue
+                    t0 = _t.perf_counter()
+                    for st in trial:
+                        _lib.check(self.lib.mx_spin(spin_us, int(st.cuda_stream)), "mx_spin")
+                    for st in trial:
+                        st.synchronize()
+                    dt = _t.perf_counter() - t0
+                    best = dt if best is None else min(best, dt)
+                if len(trial) == 1 or best < 1.6e-6 * spin_us:
+                    accepted.append(cand)
+        return accepted
+
+    def _chunk_streams(self, wanted: int) -> List[Any]:
+        """`wanted` streams for the chunks of a long int-level batch — or fewer, if the process does not have
+        that many concurrently running queues (one warning, then larger chunks on the streams that do run
+        side by side)."""
+        torch = self.torch
+        if len(self._side_streams) < wanted and not self._side_streams_capped:
+            with torch.cuda.device(self.device):
+                # high-priority streams are served by their own set of hardware queues: the chunks do not
+                # collide with (and serialise behind) the caller's other streams even when the process runs
+                # with few hardware queues (profiles/r02_hw_queue_collisions.txt)
+                cands = self._side_streams + [torch.cuda.Stream(device=self.device, priority=-1)
+                                              for _ in range(wanted - len(self._side_streams))]
+            ok = self.stream_concurrency(cands)
+            if len(ok) < len(cands):
+                import warnings
+
+                self._side_streams_capped = True
+                warnings.warn(
+                    f"protocols.distributed_keygen_amd: only {len(ok)} of {len(cands)} HIP streams run concurrently in this "
+                    "process (the HIP runtime was initialised with few hardware queues; call "
+                    "protocols.distributed_keygen_amd.configure_hw_queues() before the first GPU call, or set "
+                    f"GPU_MAX_HW_QUEUES=16): long batches are cut into {max(1, len(ok))} chunks instead of {wanted}",
+                    RuntimeWarning, stacklevel=3)
+            self._side_streams = ok
+        return self._side_streams[: max(1, min(wanted, len(self._side_streams)))]
+
     def _pinned(self, which: str, rows: int, limbs: int):
         buf = self._pin.get(which)
         if buf is None or buf.numel() < rows * limbs:
@@ -365,14 +433,9 @@ class Engine:
 
         torch = self.torch
         total = len(vals)
-        nchunks = max(4, min(self.PIPELINE_STREAMS, total // 10000))
+        streams = self._chunk_streams(max(4, min(self.PIPELINE_STREAMS, total // 10000)))
+        nchunks = len(streams)
         per = -(-total // nchunks)
-        while len(self._side_streams) < nchunks:
-            with torch.cuda.device(self.device):
-                # high-priority streams are served by their own set of hardware queues: the chunks do not
-                # collide with (and serialise behind) the caller's other streams even when the process runs
-                # with few hardware queues (profiles/r02_hw_queue_collisions.txt)
-                self._side_streams.append(torch.cuda.Stream(device=self.device, priority=-1))
         in_pin = self._pinned("in", total, limbs_in)
         out_pin = self._pinned("out", total, limbs_out)
         in_np = in_pin.numpy().view(np.uint32)
@@ -388,7 +451,7 @@ class Engine:
             t0 = _t.perf_counter()
             _limbs.pack_into(vals[lo:hi], limbs_in, in_np, lo)
             pack_s += _t.perf_counter() - t0
-            side = self._side_streams[k]
+            side = streams[k]
             side.wait_stream(cur)
             with torch.cuda.stream(side):
                 d_in = in_pin[lo:hi].to(self.device, non_blocking=True)
@@ -408,7 +471,7 @@ class Engine:
             out.extend(_limbs.unpack(out_np[lo:hi]))
             wait_s += t1 - t0
             unpack_s += _t.perf_counter() - t1
-        for side in self._side_streams[: len(events)]:
+        for side in streams[: len(events)]:
             cur.wait_stream(side)
         self.last_timing = {"chunks": len(events), "pack_s": pack_s, "wait_for_gpu_s": wait_s, "unpack_s": unpack_s,
                             "total_s": _t.perf_counter() - t_start}

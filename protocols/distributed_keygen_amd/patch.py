@@ -233,9 +233,12 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
             # survivors' moduli become Python ints
             share_table = [v.get_shares() for v in candidate_n.variables]
             scheme_n = candidate_n.variables[0].shamir_scheme           # degree 2t after the product (UT:248)
-            by_party = {i: [tbl[i] for tbl in share_table] for i in sorted(share_table[0])}
+            by_party = {i: [tbl[i] for tbl in share_table] for i in share_table[0]}
+            # the interpolation points in the order ShamirShares.reconstruct_secret would take them: the first
+            # degree+1 entries of the shares dictionary in insertion order
             has_divisor, surviving = shamir.reconstruct_and_sieve_batch(
-                by_party, scheme_n.modulus, scheme_n.polynomial_degree, prime_list, engine)
+                by_party, scheme_n.modulus, scheme_n.polynomial_degree, prime_list, engine,
+                points=list(share_table[0])[: scheme_n.polynomial_degree + 1])
             survivors = sorted(surviving)
             moduli = surviving                                          # candidate index -> modulus, survivors only
             sieved_out += len(has_divisor) - len(survivors)

@@ -18,7 +18,7 @@ on the device for the sieve that follows (DK:1288-1292).
 
 from __future__ import annotations
 
-from typing import Any, Dict, List, Sequence
+from typing import Any, Dict, List, Optional, Sequence
 
 
 def _engine(engine: Any) -> Any:
@@ -55,13 +55,29 @@ def mul_add_shares_batch(p_shares: Sequence[int], q_shares: Sequence[int], zero_
     return _engine(engine).shamir_fma_batch(list(p_shares), list(q_shares), list(zero_shares), prime)
 
 
-def reconstruct_batch(shares_by_party: Dict[int, Sequence[int]], prime: int, degree: int, engine: Any = None) -> List[int]:
-    """Candidate moduli of a round from every party's shares (DK:1284): per candidate the value at 0 of
-    the degree-`degree` polynomial through the shares of the first degree+1 parties (in index order, as
-    ``ShamirShares.reconstruct_secret`` takes them).  Raises ValueError with fewer shares than that."""
-    points = sorted(shares_by_party)[: degree + 1]
-    if len(points) < degree + 1:
+def _points(shares_by_party: Dict[int, Sequence[int]], degree: int, points: Optional[Sequence[int]]) -> List[int]:
+    """The degree+1 evaluation points the interpolation runs through.  The un-vendored
+    ``ShamirShares.reconstruct_secret`` takes the first degree+1 entries of its shares dictionary in
+    INSERTION order; a caller that has that dictionary passes its key order as `points` (patch.py does).
+    Without it the parties are taken in index order — the same value whenever the shares are consistent
+    (any degree+1 points of a degree-`degree` polynomial interpolate to the same secret)."""
+    if points is None:
+        pts = sorted(shares_by_party)[: degree + 1]
+    else:
+        pts = [int(i) for i in points][: degree + 1]
+        if any(i not in shares_by_party for i in pts):
+            raise KeyError(next(i for i in pts if i not in shares_by_party))
+    if len(pts) < degree + 1:
         raise ValueError("not enough shares to reconstruct")
+    return pts
+
+
+def reconstruct_batch(shares_by_party: Dict[int, Sequence[int]], prime: int, degree: int, engine: Any = None,
+                      points: Optional[Sequence[int]] = None) -> List[int]:
+    """Candidate moduli of a round from every party's shares (DK:1284): per candidate the value at 0 of
+    the degree-`degree` polynomial through the shares of degree+1 parties (`points`, see _points).
+    Raises ValueError with fewer shares than that."""
+    points = _points(shares_by_party, degree, points)
     count = len(shares_by_party[points[0]])
     if any(len(shares_by_party[i]) != count for i in points):
         raise ValueError("every party needs one share per candidate")
@@ -73,12 +89,10 @@ def reconstruct_batch(shares_by_party: Dict[int, Sequence[int]], prime: int, deg
 
 
 def reconstruct_and_sieve_batch(shares_by_party: Dict[int, Sequence[int]], prime: int, degree: int,
-                                prime_list: Sequence[int], engine: Any = None):
+                                prime_list: Sequence[int], engine: Any = None, points: Optional[Sequence[int]] = None):
     """DK:1284 and the filter DK:1288-1292 for a whole round without the moduli leaving the device in
     between: returns (has_small_divisor per candidate, {candidate index: modulus} of the survivors)."""
-    points = sorted(shares_by_party)[: degree + 1]
-    if len(points) < degree + 1:
-        raise ValueError("not enough shares to reconstruct")
+    points = _points(shares_by_party, degree, points)
     count = len(shares_by_party[points[0]])
     if any(len(shares_by_party[i]) != count for i in points):
         raise ValueError("every party needs one share per candidate")

@@ -90,6 +90,12 @@ def _worker(rank: int, world: int, port: int, ret) -> None:
         lo, hi = mxdist.shard_bounds(7, dist.get_rank(), 2)
         local = eng.powmod_shared_t(_rows(bases[lo:hi], L.limbs_for(mod)), mod, exp)
         assert _ints(mxdist.all_gather_rows(local, 7)) == [pow(b, exp, mod) for b in bases]
+        # --- fewer rows than ranks: rank 1's shard is empty (padding an empty shard must not raise
+        # and leave the other ranks hanging in the collective)
+        lo, hi = mxdist.shard_bounds(1, dist.get_rank(), 2)
+        assert (lo, hi) == ((0, 1) if dist.get_rank() == 0 else (1, 1))
+        local = eng.powmod_shared_t(_rows(bases[lo:hi], L.limbs_for(mod)), mod, exp) if hi > lo else _rows([], L.limbs_for(mod))
+        assert _ints(mxdist.all_gather_rows(local, 1)) == [pow(bases[0], exp, mod)]
         # --- biprimality vote
         m0 = (1 << 100) + 277
         v = torch.stack([_rows([5, 6, 7, 9, 2, 4], 4), _rows([5, m0 - 6, 8, 9, 2, 4], 4), _rows([1] * 6, 4)]).reshape(3, 3, 2, 4)

@@ -474,7 +474,7 @@ def test_biprime_v_two_phase_jacobi_selection(eng):
 
 def test_jacobi_unbalanced_operands_and_safety_net(eng, monkeypatch):
     """Tiny numerators against large moduli, numerators just below the modulus, common factors — and
-    the same inputs with the divstep batches cut short (MX_JACOBI_MAX_BATCHES), so that the plain
+    the same inputs with the divstep batches cut short (mx_debug_knob), so that the plain
     binary algorithm that backs them up has to finish every symbol from an intermediate state."""
     rng = random.Random(77)
     rows, mods = [], []
@@ -488,10 +488,12 @@ def test_jacobi_unbalanced_operands_and_safety_net(eng, monkeypatch):
     rows.append([3, 5, 15, 1001, 17, (1 << 400) + 1] + [rng.randrange(mods[-1]) for _ in range(26)])
     want = [[oracle.jacobi_symbol(v, m) for v in r] for r, m in zip(rows, mods)]
     assert eng.jacobi_batch(rows, mods) == want
-    for cut in ("0", "1", "7", "60"):
-        monkeypatch.setenv("MX_JACOBI_MAX_BATCHES", cut)
-        assert eng.jacobi_batch(rows, mods) == want, cut
-    monkeypatch.delenv("MX_JACOBI_MAX_BATCHES")
+    try:
+        for cut in (0, 1, 7, 60):
+            eng.debug_knob("jacobi_max_batches", cut + 1)        # at most `cut` divstep batches
+            assert eng.jacobi_batch(rows, mods) == want, cut
+    finally:
+        eng.debug_knob("jacobi_max_batches", 0)
 
 
 def test_randomize_batch_keeps_the_plaintext(eng):

@@ -335,6 +335,14 @@ def test_rows_from_wire_fast_path_and_reduction():
     assert limbs.unpack(codec.rows_from_wire([-1, m + 5, codec.encode_int(-2), codec.encode_int(1 << 300)], 8, modulus=m)) == [
         m - 1, 5, m - 2, (1 << 300) % m]
     assert limbs.unpack(codec.rows_from_wire(codec.rows_to_wire(rows), 8)) == vals
+    # values that fit the row width but are not canonical residues are reduced too: all-int
+    # fast path, wire-form entries, mixed lists; without a modulus they pass through unchanged
+    assert limbs.unpack(codec.rows_from_wire([m + 5, 3, m, m - 1, 0], 8, modulus=m)) == [5, 3, 0, m - 1, 0]
+    assert limbs.unpack(codec.rows_from_wire([codec.encode_int(m + 5)], 8, modulus=m)) == [5]
+    assert limbs.unpack(codec.rows_from_wire([codec.encode_int(m + 5), 3, codec.encode_int(m), m + 9], 8, modulus=m)) == [5, 3, 0, 9]
+    assert limbs.unpack(codec.rows_from_wire([m + 5], 8)) == [m + 5]
+    assert limbs.unpack(codec.rows_from_wire([(1 << 192) - 1], 6, modulus=m)) == [((1 << 192) - 1) % m]
+    assert limbs.unpack(codec.rows_from_wire([5], 4, modulus=m)) == [5]            # modulus wider than the rows
 
 
 def test_c_codec_matches_int_to_bytes():
@@ -375,6 +383,19 @@ def test_shamir_mirror_matches_reference_vectors(golden_reconstruct):
         assert shamir.reconstruct_batch(some, prime, degree, eng) == want
         with pytest.raises(ValueError):
             shamir.reconstruct_batch(dict(list(some.items())[1:]), prime, degree, eng)
+        # explicit interpolation points (the insertion order of the reference's shares dictionary, as
+        # patch.compute_modulus passes them): same moduli from consistent shares; with one party's shares
+        # corrupted the result depends on whether that party is among the points — as in the reference
+        allp = {i: d["n"] for i, d in shares.items()}
+        order = list(reversed(sorted(allp)))
+        assert shamir.reconstruct_batch(allp, prime, degree, eng, points=order) == want
+        if len(allp) > degree + 1:
+            bad = dict(allp)
+            bad[order[-1]] = [(v + 1) % prime for v in bad[order[-1]]]
+            assert shamir.reconstruct_batch(bad, prime, degree, eng, points=order) == want       # corrupted party not used
+            assert shamir.reconstruct_batch(bad, prime, degree, eng, points=sorted(allp)) != want
+        with pytest.raises(KeyError):
+            shamir.reconstruct_batch(allp, prime, degree, eng, points=[99] + order)
     assert shamir.reconstruct_batch({1: [], 2: [], 3: []}, 101, 2, eng) == []
     assert shamir.lagrange_coefficients_at_zero([1, 2, 3], 101) == [3, 98, 1]
 
