@@ -81,11 +81,11 @@ int main() {
   MX(mx_powmod_nsquare_prepare(&plan, n.data(), exp.data(), limbs_n, exp_limbs, d_plan, pb, s));
   int64_t wr = mx_powmod_nsquare_run_workspace_bytes(&plan, batch);
   if (wr < 0 || wr > ws1) { std::fprintf(stderr, "run workspace query failed\n"); return 3; }
-  MX(mx_powmod_nsquare_run(&plan, d_in, d_b, limbs2, batch, 18, 4, w1, ws1, s));        // wide lanes, 4 segments
+  MX(mx_powmod_nsquare_run(&plan, d_in, d_b, limbs2, batch, 18, 1, 4, w1, ws1, s));     // wide lanes, one wavefront per group, 4 segments
   CHECK(hipStreamSynchronize(s));
   CHECK(hipMemcpy(b.data(), d_b, bytes, hipMemcpyDeviceToHost));
   if (a != b) { std::fprintf(stderr, "plan run (wide, 4 segments) differs from the one-shot form\n"); return 1; }
-  MX(mx_powmod_nsquare_run(&plan, d_in, d_b, limbs2, batch, 9, 1, w1, ws1, s));         // narrow lanes, one launch
+  MX(mx_powmod_nsquare_run(&plan, d_in, d_b, limbs2, batch, 0, 0, 1, w1, ws1, s));      // the library's choice of shape, one launch
   CHECK(hipStreamSynchronize(s));
   CHECK(hipMemcpy(b.data(), d_b, bytes, hipMemcpyDeviceToHost));
   if (a != b) { std::fprintf(stderr, "plan run (narrow) differs from the one-shot form\n"); return 1; }

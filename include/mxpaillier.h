@@ -105,7 +105,16 @@ int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* 
  * arithmetic, no operand upload.  The plan descriptor is a plain struct the caller keeps on the
  * host; the device block must stay valid, and the stream passed to prepare must be complete or
  * ordered before the streams passed to run (prepare's uploads are enqueued on it).
- * limbs_per_lane of run: 9 (narrow geometry), 18 (wide) or 0 = automatic from the batch size.
+ * limbs_per_lane of run: 9 (narrow geometry), 18 (wide), 3 (latency geometry, two wavefronts per group only)
+ * or 0 = the library's choice.
+ * wavefronts_per_group of run: 1 = one wavefront executes both Montgomery passes of every pair product; 2 = the
+ * passes run on two wavefronts of one workgroup, the second one operation behind the first (the chain of first
+ * N-adic digits never reads the second digits) — 0.54-0.58 of the time per operation with twice the wavefronts,
+ * for launches that leave SIMDs idle: a single ciphertext (PSK:92 called from DK:345-349), a keygen-sized batch,
+ * one 10 000-ciphertext sequence; 0 = the library's choice.  With both at 0 the library estimates the duration
+ * of ONE launch of this batch on an idle GPU for every shape and takes the shortest; callers that keep several
+ * launches in flight fill the machine between them and should pass 18 / 1.  mx_nsquare_launch_shape reports the
+ * choice.  Same result bit for bit in every shape.
  * segments of run: the exponentiation is enqueued as this many consecutive launches, each executing a
  * stretch of the tape (the accumulator travels through the workspace); a wavefront then lives
  * 1/segments as long, which is the grain at which a burst of launches on several streams drains.
@@ -120,7 +129,7 @@ typedef struct mx_nsquare_plan {
   int32_t ntape;          /* tape words */
   int32_t n_sqr;          /* pair squarings one exponentiation executes */
   int32_t n_mul;          /* pair multiplications one exponentiation executes */
-  int32_t has_wide;       /* 1 if the wide geometry (limbs_per_lane 18) is available for this modulus */
+  int32_t geometries;     /* bit mask of the limbs_per_lane values with a kernel instance for this modulus: 1 = 9, 2 = 18, 4 = 3 */
   int32_t n_slot_reads;   /* pair slots (2 * limbs_per_lane words per lane) one exponentiation reads from ... */
   int32_t n_slot_writes;  /* ... and writes to the workspace: the kernel's HBM traffic model */
 } mx_nsquare_plan;
@@ -130,8 +139,8 @@ int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const 
 /* workspace of one run (the table of odd powers of every base; one per launch in flight) */
 int64_t mx_powmod_nsquare_run_workspace_bytes(const mx_nsquare_plan* plan, int64_t batch);
 int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t* d_bases, uint32_t* d_out, int limbs2,
-                          int64_t batch, int limbs_per_lane, int segments, void* d_workspace,
-                          int64_t workspace_bytes, void* stream);
+                          int64_t batch, int limbs_per_lane, int wavefronts_per_group, int segments,
+                          void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* ---- small-prime sieve -----------------------------------------------------------------
  * d_out[e] = 1 if some h_primes[k] divides candidate e else 0.  Replaces
@@ -295,6 +304,11 @@ int mx_nsquare_geometry(int n_bits, int64_t batch, int* lanes_per_element, int* 
  * mx_powmod_shared_lpl (groups = 1) / mx_powmod_multi_dev (groups > 1) launch. */
 int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_lane, int* lanes_per_element,
                             int* limbs_per_lane_out, int* limb_bits, int* blocks);
+/* The full launch shape mx_powmod_nsquare_run uses for (limbs_per_lane, wavefronts_per_group), either or both 0 =
+ * the library's choice for this batch: the geometry as above plus the wavefronts per group of elements (1 | 2). */
+int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
+                            int* lanes_per_element, int* limbs_per_lane_out, int* limb_bits, int* blocks,
+                            int* wavefronts_per_group_out);
 int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* lanes_per_element,
                            int* limbs_per_lane_out, int* limb_bits, int* blocks);
 

@@ -19,7 +19,7 @@ class NsquarePlan(ctypes.Structure):
     _fields_ = [
         ("d_plan", c_void_p), ("plan_bytes", c_int64), ("limbs_n", ctypes.c_int32), ("n_bits", ctypes.c_int32),
         ("exp_bits", ctypes.c_int32), ("window", ctypes.c_int32), ("ntape", ctypes.c_int32),
-        ("n_sqr", ctypes.c_int32), ("n_mul", ctypes.c_int32), ("has_wide", ctypes.c_int32),
+        ("n_sqr", ctypes.c_int32), ("n_mul", ctypes.c_int32), ("geometries", ctypes.c_int32),
         ("n_slot_reads", ctypes.c_int32), ("n_slot_writes", ctypes.c_int32),
     ]
 
@@ -50,7 +50,8 @@ SYMBOLS = {
     "mx_nsquare_plan_bytes": (c_int64, [c_int, c_int]),
     "mx_powmod_nsquare_prepare": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_powmod_nsquare_run_workspace_bytes": (c_int64, [POINTER(NsquarePlan), c_int64]),
-    "mx_powmod_nsquare_run": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_nsquare_run": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_nsquare_launch_shape": (c_int, [c_int, c_int64, c_int, c_int, *_P4, POINTER(c_int)]),
     "mx_combine_plan_bytes": (c_int64, [c_int, c_int]),
     "mx_combine_prepare": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_combine_run": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),

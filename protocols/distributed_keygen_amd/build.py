@@ -12,7 +12,8 @@ CSRC = PKG / "csrc"
 LIB = PKG / "libmxpaillier.so"
 CODEC_SRC = CSRC / "mx_pycodec.c"
 CODEC = PKG / "_mxcodec.so"          # CPython helper: bulk Python int <-> limb rows (host side, no arithmetic)
-SOURCES = [CSRC / "mx_capi.hip", CSRC / "mx_capi_n2.hip", CSRC / "mx_capi_n2w.hip"]
+SOURCES = [CSRC / "mx_capi.hip", CSRC / "mx_capi_n2.hip", CSRC / "mx_capi_n2w.hip", CSRC / "mx_capi_n2s.hip",
+           CSRC / "mx_capi_n2sw.hip"]
 HEADERS = sorted(CSRC.glob("*.hpp")) + [PKG.parent.parent / "include" / "mxpaillier.h"]
 
 

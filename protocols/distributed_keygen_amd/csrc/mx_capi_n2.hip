@@ -1,7 +1,7 @@
 // extern "C" entry points of the N^2-modulus modexp (second translation unit of libmxpaillier.so:
 // compiled in parallel with mx_capi.hip, the pair kernels are the most expensive to build).
 #include "mx_upload.hpp"
-#include "mx_powmod_n2.hpp"
+#include "mx_powmod_n2_split.hpp"
 
 // ---- modexp modulo N^2 through pairs modulo N --------------------------------------------------
 namespace {
@@ -13,12 +13,30 @@ struct N2Shape {
   int64_t table_bytes = 0;
 };
 
-bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, N2Shape& p) {
+// limbs_per_lane values of the pair kernel: 9 and 18 in both forms (one or two wavefronts per group of
+// elements), 3 — the latency geometry — only in the two-wavefront form (mx_powmod_n2_split.hpp).  (2 limbs per
+// lane were tried too: fewer instructions per limb step, but the quotient digit then travels through an SGPR
+// (v_readfirstlane for 64-lane groups) and the dependent chain got longer, 18.5 vs 16.8 ms for one ciphertext.)
+constexpr int LIMBS_PER_LANE_LAT = 3;
+constexpr int N2_GEOS = 3;                      // constant sets of a plan, in geo_index order
+constexpr int N2_LPLS[N2_GEOS] = {LIMBS_PER_LANE, LIMBS_PER_LANE_WIDE, LIMBS_PER_LANE_LAT};
+inline int geo_index(int lpl) {
+  for (int g = 0; g < N2_GEOS; ++g) if (N2_LPLS[g] == lpl) return g;
+  return -1;
+}
+inline int max_lanes(int lpl, int wpg) {
+  if (lpl == LIMBS_PER_LANE_WIDE) return 16;
+  if (lpl == LIMBS_PER_LANE) return 32;
+  return wpg == 2 ? 64 : 0;                 // L = 3 exists as a split kernel only
+}
+
+bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg, N2Shape& p) {
+  if (geo_index(limbs_per_lane) < 0 || (wpg != 1 && wpg != 2)) return false;
   if (!choose_geometry(n_bits, p.geo, limbs_per_lane)) return false;
-  if (p.geo.K > (limbs_per_lane == LIMBS_PER_LANE_WIDE ? 16 : 32)) return false;   // instances that exist
-  int gpw = 64 / p.geo.K;
+  if (p.geo.K > max_lanes(limbs_per_lane, wpg)) return false;   // instances that exist
+  int gpw = (64 / p.geo.K) * (wpg == 2 ? mx::N2_SPLIT_PAIRS : 1);      // elements per workgroup
   p.nblocks = (batch + gpw - 1) / gpw;
-  p.nlanes = p.nblocks * 64;
+  p.nlanes = p.nblocks * 64 * (wpg == 2 ? mx::N2_SPLIT_PAIRS : 1);
   p.nslots = mx::N2_SLOT_TABLE + (1 << (window - 1));
   p.table_bytes = align256((int64_t)p.nslots * 2 * p.geo.L * p.nlanes * 4);
   return true;
@@ -33,29 +51,82 @@ int launch_n2_kl(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
 }
 
 }  // namespace
-// wide-geometry instantiations live in mx_capi_n2w.hip (third translation unit, built in parallel)
+// wide-geometry instantiations live in mx_capi_n2w.hip, the two-wavefront kernels in mx_capi_n2s.hip (L = 3, 9) and
+// mx_capi_n2sw.hip (L = 18): translation units of their own, built in parallel
 namespace mxw { int launch_n2_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s); }
+namespace mxs {
+int launch_n2_split(int K, int L, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
+int launch_n2_split_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
+}
 namespace {
-template <int K>
-int launch_n2_k(const mx::PowmodN2Args& a, int64_t nblocks, int lpl, hipStream_t s) {
-  if (lpl == LIMBS_PER_LANE_WIDE) return mxw::launch_n2_wide(K, a, nblocks, s);
-  return launch_n2_kl<K, LIMBS_PER_LANE>(a, nblocks, s);
+int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t s) {
+  const int K = p.geo.K, L = p.geo.L;
+  if (wpg == 2) return L == LIMBS_PER_LANE_WIDE ? mxs::launch_n2_split_wide(K, a, p.nblocks, s) : mxs::launch_n2_split(K, L, a, p.nblocks, s);
+  if (L == LIMBS_PER_LANE_WIDE) return mxw::launch_n2_wide(K, a, p.nblocks, s);
+  switch (K) {
+    case 1: return launch_n2_kl<1, LIMBS_PER_LANE>(a, p.nblocks, s);
+    case 2: return launch_n2_kl<2, LIMBS_PER_LANE>(a, p.nblocks, s);
+    case 4: return launch_n2_kl<4, LIMBS_PER_LANE>(a, p.nblocks, s);
+    case 8: return launch_n2_kl<8, LIMBS_PER_LANE>(a, p.nblocks, s);
+    case 16: return launch_n2_kl<16, LIMBS_PER_LANE>(a, p.nblocks, s);
+    case 32: return launch_n2_kl<32, LIMBS_PER_LANE>(a, p.nblocks, s);
+  }
+  return MX_ERR_SIZE;
 }
 
-// Geometry of the pair kernel when the caller leaves the choice to the library.  Measured on MI355X
-// (tools/ab_geometry.sh, tools/ab_streams.sh, tools/sweep_keys.sh, profiles/): the wide geometry issues
-// 18 % fewer instructions per element, runs 2 wavefronts per SIMD and puts twice the elements into a
-// wavefront.  At key_length 2048 it is faster for a lone 10 000-element launch (164 k vs 144 k
-// modexps/s), with four or more launches in flight (262-272 k vs 241-255 k) and saturated (300 k vs
-// 262 k); for small launches the narrow geometry, which makes twice the wavefronts, fills the
-// machine better (2 000 elements: 80 k vs 55 k).  So: wide from ~480 wavefronts per launch.
-int n2_auto_limbs_per_lane(int n_bits, int64_t batch) {
-  Geometry narrow, wide;
-  if (!choose_geometry(n_bits, narrow, LIMBS_PER_LANE) || !choose_geometry(n_bits, wide, LIMBS_PER_LANE_WIDE))
-    return LIMBS_PER_LANE;
-  if (narrow.K < 8 || wide.K > 16) return LIMBS_PER_LANE;
-  const int64_t waves = (batch * wide.K + 63) / 64;
-  return waves >= 480 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+// Launch shape of the pair kernel when the caller leaves the choice (limbs per lane and/or wavefronts per
+// group) to the library: the candidate with the lowest estimated duration for ONE launch of this batch on an
+// otherwise idle GPU.  The estimate is a cycle count per pair operation for the wavefront that bounds the launch,
+// fitted to tools/sweep_shapes.py (profiles/r03_sweep_shapes.txt; within ~8 % of every measured point at
+// key_length 2048 and 4096):
+//   a limb step is m multiply-accumulates plus o other instructions (quotient digit, carry hand-over, shifts);
+//   a wavefront that has its SIMD to itself issues one instruction every ~5.3 cycles whatever it is, and waits
+//   ~80 / L cycles per step for the multiplier limbs it fetches from LDS once per L steps;
+//   every further wavefront resident on the same SIMD adds what its instructions cost when the SIMD is shared:
+//   4.2 cycles per multiply-accumulate, 2.3 per other instruction (tools/ubench/valu_peak.hip);
+//   wavefronts beyond what the register file holds per SIMD (2 at L = 18, 3 at L = 9, 8 at L = 3) run in rounds.
+// Two-wavefront groups: the second pass (m = 2L, o = 11) bounds an operation, its wavefronts sit on SIMDs 1 and 3 of
+// a CU, one per workgroup.  One-wavefront groups: both passes (m = L/2 + 1 + 3L, o = 20), a wavefront per workgroup.
+// What comes out (key_length 2048): up to ~1000 ciphertexts the latency geometry (3 limbs per lane, two
+// wavefronts), to ~4000 L = 9 split, to ~8000 L = 18 split, and the one-wavefront wide kernel once a launch
+// fills the machine on its own (from ~24 000).  Callers that keep several launches in flight fill the machine
+// between them and should say so by passing limbs_per_lane = 18, wavefronts_per_group = 1 (bench.py's
+// steady-state leg does).
+struct N2Choice { int lpl, wpg; };
+int device_cus() {
+  static const int cus = [] {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    return n;
+  }();
+  return cus;
+}
+double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg) {
+  N2Shape p;
+  if (!shape_n2(n_bits, 1, batch, lpl, wpg, p)) return -1.0;
+  const double L = p.geo.L, steps = (double)p.geo.nblk * p.geo.L;
+  const double m = wpg == 2 ? 2 * L : (p.geo.L / 2 + 1) + 3 * L, o = wpg == 2 ? 11.0 : 20.0;
+  const double alone = steps * (5.3 * (m + o) + 80.0 / L) * (wpg == 2 ? 1.0 : 0.92);
+  const double shared = steps * (4.2 * m + 2.3 * o);
+  const int cus = device_cus();
+  const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
+  const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;
+  auto round = [&](int64_t r) { return r <= 0 ? 0.0 : alone + (double)(r - 1) * shared; };
+  return (double)(per_simd / fit) * round(fit) + round(per_simd % fit);
+}
+N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
+  N2Choice best{LIMBS_PER_LANE, 1};
+  double best_t = -1.0;
+  for (int l : N2_LPLS) {
+    if (limbs_per_lane && l != limbs_per_lane) continue;
+    for (int w : {1, 2}) {
+      if (wpg && w != wpg) continue;
+      const double t = n2_estimate(n_bits, batch, l, w);
+      if (t > 0 && (best_t < 0 || t < best_t)) { best_t = t; best = N2Choice{l, w}; }
+    }
+  }
+  if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1};   // reported as MX_ERR_SIZE by the caller
+  return best;
 }
 
 // Segments when the caller leaves the choice to the library: a launch whose wavefronts would live for
@@ -99,15 +170,22 @@ void n2_constants(u32* c, const u32* h_n, int limbs_n, int m, int k) {
 }
 }  // namespace
 
+extern "C" int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group, int* k,
+                                       int* l, int* w, int* blocks, int* wavefronts) {
+  if (!k || !l || !w || !blocks || !wavefronts || batch <= 0) return MX_ERR_ARG;
+  if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
+  const N2Choice ch = n2_auto_shape(n_bits, batch, limbs_per_lane, wavefronts_per_group);
+  N2Shape p;
+  if (!shape_n2(n_bits, 1, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
+  *k = p.geo.K; *l = p.geo.L; *w = p.geo.W; *blocks = p.geo.nblk; *wavefronts = ch.wpg;
+  return MX_OK;
+}
+
 extern "C" int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_lane, int* k, int* l, int* w,
                                        int* blocks) {
-  if (!k || !l || !w || !blocks || batch <= 0) return MX_ERR_ARG;
-  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
-  N2Shape p;
-  const int lpl = limbs_per_lane ? limbs_per_lane : n2_auto_limbs_per_lane(n_bits, batch);
-  if (!shape_n2(n_bits, 1, batch, lpl, p)) return MX_ERR_SIZE;
-  *k = p.geo.K; *l = p.geo.L; *w = p.geo.W; *blocks = p.geo.nblk;
-  return MX_OK;
+  int waves = 0;
+  return mx_nsquare_launch_shape(n_bits, batch, limbs_per_lane, 0, k, l, w, blocks, &waves);
 }
 
 extern "C" int mx_nsquare_geometry(int n_bits, int64_t batch, int* k, int* l, int* w, int* blocks) {
@@ -116,7 +194,7 @@ extern "C" int mx_nsquare_geometry(int n_bits, int64_t batch, int* k, int* l, in
 
 extern "C" int64_t mx_nsquare_plan_bytes(int limbs_n, int exp_limbs) {
   if (limbs_n <= 0 || exp_limbs <= 0) return MX_ERR_ARG;
-  return 2 * n2_consts_bytes(limbs_n) + align256((int64_t)MAX_SLIDING_OPS * 4);
+  return N2_GEOS * n2_consts_bytes(limbs_n) + align256((int64_t)MAX_SLIDING_OPS * 4);
 }
 
 extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp,
@@ -126,9 +204,13 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
   if (!(h_n[0] & 1u)) return MX_ERR_MODULUS;
   const int bits = bit_length(h_n, limbs_n);
   if (bits < 2) return MX_ERR_MODULUS;
-  Geometry narrow, wide;
-  if (!choose_geometry(bits, narrow, LIMBS_PER_LANE) || narrow.K > 32) return MX_ERR_SIZE;
-  const bool has_wide = choose_geometry(bits, wide, LIMBS_PER_LANE_WIDE) && wide.K <= 16;
+  // constants of every geometry that has an instance for this modulus (they differ in R = 2^(W*L*blocks))
+  const int* lpls = N2_LPLS;
+  Geometry geos[N2_GEOS];
+  int geometries = 0;
+  for (int g = 0; g < N2_GEOS; ++g)
+    if (choose_geometry(bits, geos[g], lpls[g]) && geos[g].K <= max_lanes(lpls[g], 2)) geometries |= 1 << g;
+  if (!(geometries & 1)) return MX_ERR_SIZE;
   if (mx_nsquare_plan_bytes(limbs_n, exp_limbs) > plan_bytes) return MX_ERR_WORKSPACE;
   const int ebits = bit_length(h_exp, exp_limbs);
   const int k = bits - 1;                                      // x = x_lo + 2^k x_hi
@@ -167,16 +249,25 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
   if ((int)tape.size() > MAX_SLIDING_OPS) return MX_ERR_SIZE;
 
   const int64_t cb = n2_consts_bytes(limbs_n);
-  std::vector<u32> c((size_t)8 * limbs_n);
   hipStream_t s = (hipStream_t)stream;
   char* dp = (char*)d_plan;
-  n2_constants(c.data(), h_n, limbs_n, narrow.W * narrow.L * narrow.nblk, k);
-  MX_TRY(upload_words(dp, c.data(), c.size(), s));
-  if (has_wide) {
-    n2_constants(c.data(), h_n, limbs_n, wide.W * wide.L * wide.nblk, k);
-    MX_TRY(upload_words(dp + cb, c.data(), c.size(), s));
+  int done_m[N2_GEOS] = {};
+  std::vector<u32> rows[N2_GEOS];
+  for (int g = 0; g < N2_GEOS; ++g) {
+    if (!(geometries & (1 << g))) continue;
+    const int m = geos[g].W * geos[g].L * geos[g].nblk;
+    done_m[g] = m;
+    int same = -1;
+    for (int h = 0; h < g; ++h) if (done_m[h] == m) same = h;       // geometries often share R (2048: all three)
+    if (same >= 0) {
+      rows[g] = rows[same];
+    } else {
+      rows[g].resize((size_t)8 * limbs_n);
+      n2_constants(rows[g].data(), h_n, limbs_n, m, k);
+    }
+    MX_TRY(upload_words(dp + g * cb, rows[g].data(), rows[g].size(), s));
   }
-  MX_TRY(upload_words(dp + 2 * cb, tape.data(), tape.size(), s));
+  MX_TRY(upload_words(dp + N2_GEOS * cb, tape.data(), tape.size(), s));
   plan->d_plan = d_plan;
   plan->plan_bytes = plan_bytes;
   plan->limbs_n = limbs_n;
@@ -186,7 +277,7 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
   plan->ntape = (int)tape.size();
   plan->n_sqr = n_sqr;
   plan->n_mul = n_mul;
-  plan->has_wide = has_wide ? 1 : 0;
+  plan->geometries = geometries;
   plan->n_slot_reads = n_reads;
   plan->n_slot_writes = n_writes;
   return MX_OK;
@@ -194,41 +285,45 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
 
 extern "C" int64_t mx_powmod_nsquare_run_workspace_bytes(const mx_nsquare_plan* plan, int64_t batch) {
   if (!plan || batch <= 0 || plan->window < 1) return MX_ERR_ARG;
-  N2Shape p, q;
-  if (!shape_n2(plan->n_bits, plan->window, batch, LIMBS_PER_LANE, p)) return MX_ERR_SIZE;
-  if (shape_n2(plan->n_bits, plan->window, batch, LIMBS_PER_LANE_WIDE, q) && q.table_bytes > p.table_bytes)
-    return q.table_bytes;
-  return p.table_bytes;
+  // the largest table any launch shape of this batch needs (the caller may leave the choice to the library)
+  int64_t most = -1;
+  for (int l : N2_LPLS) {
+    N2Shape p;
+    if (shape_n2(plan->n_bits, plan->window, batch, l, 2, p) && p.table_bytes > most) most = p.table_bytes;
+  }
+  return most < 0 ? MX_ERR_SIZE : most;
 }
 
 extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t* d_bases, uint32_t* d_out,
-                                     int limbs2, int64_t batch, int limbs_per_lane, int segments, void* d_ws,
-                                     int64_t ws_bytes, void* stream) {
+                                     int limbs2, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
+                                     int segments, void* d_ws, int64_t ws_bytes, void* stream) {
   if (!plan || !plan->d_plan || !d_bases || !d_out || !d_ws) return MX_ERR_ARG;
   if (limbs2 <= 0 || batch <= 0 || plan->limbs_n <= 0 || plan->ntape <= 0) return MX_ERR_ARG;
-  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
   if (segments < 0 || segments > 64) return MX_ERR_ARG;
   const int bits = plan->n_bits;
   if (2 * bits - 1 > 32 * limbs2) return MX_ERR_ARG;          // rows too narrow for N^2
-  const int lpl = limbs_per_lane ? limbs_per_lane : n2_auto_limbs_per_lane(bits, batch);
+  const N2Choice ch = n2_auto_shape(bits, batch, limbs_per_lane, wavefronts_per_group);
   N2Shape p;
-  if (!shape_n2(bits, plan->window, batch, lpl, p)) return MX_ERR_SIZE;
-  if (lpl == LIMBS_PER_LANE_WIDE && !plan->has_wide) return MX_ERR_SIZE;
+  if (!shape_n2(bits, plan->window, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
+  const int gi = geo_index(ch.lpl);
+  if (!(plan->geometries & (1 << gi))) return MX_ERR_SIZE;
   if (p.table_bytes > ws_bytes) return MX_ERR_WORKSPACE;
   if (2 * p.geo.K * p.geo.L + 8 < limbs2 + 2) return MX_ERR_ARG;   // row wider than the staging area
   const int64_t cb = n2_consts_bytes(plan->limbs_n);
   const char* dp = (const char*)plan->d_plan;
   mx::PowmodN2Args a;
   a.bases = d_bases; a.out = d_out;
-  a.consts = (const u32*)(dp + (lpl == LIMBS_PER_LANE_WIDE ? cb : 0));
-  a.tape = (const u32*)(dp + 2 * cb);
+  a.consts = (const u32*)(dp + gi * cb);
+  a.tape = (const u32*)(dp + N2_GEOS * cb);
   a.ntape = plan->ntape;
   a.slots = (u32*)d_ws;
   a.batch = batch; a.limbsn = plan->limbs_n; a.limbs2 = limbs2; a.nblk = p.geo.nblk; a.ksplit = bits - 1;
   hipStream_t s = (hipStream_t)stream;
   // segments: consecutive launches that each execute a stretch of the tape (mx_powmod_n2.hpp); positions
   // are counted in squarings, the accumulator travels through a scratch slot of the workspace
-  int nseg = segments > 0 ? segments : n2_auto_segments(plan->n_sqr, p.nblocks);
+  int nseg = segments > 0 ? segments : n2_auto_segments(plan->n_sqr, p.nlanes / 64 * ch.wpg);
   if (nseg > plan->n_sqr / 16) nseg = plan->n_sqr / 16;
   if (nseg < 1) nseg = 1;
   MxKernelTimer timer(s);                        // one timed interval per exponentiation (all its segments)
@@ -237,16 +332,7 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
     a.last = sg == nseg - 1;
     a.pos_begin = (int)((int64_t)plan->n_sqr * sg / nseg);
     a.pos_end = a.last ? 0x7FFFFFFF : (int)((int64_t)plan->n_sqr * (sg + 1) / nseg);
-    int rc = MX_ERR_SIZE;
-    switch (p.geo.K) {
-      case 1: rc = launch_n2_k<1>(a, p.nblocks, p.geo.L, s); break;
-      case 2: rc = launch_n2_k<2>(a, p.nblocks, p.geo.L, s); break;
-      case 4: rc = launch_n2_k<4>(a, p.nblocks, p.geo.L, s); break;
-      case 8: rc = launch_n2_k<8>(a, p.nblocks, p.geo.L, s); break;
-      case 16: rc = launch_n2_k<16>(a, p.nblocks, p.geo.L, s); break;
-      case 32: rc = launch_n2_k<32>(a, p.nblocks, p.geo.L, s); break;
-    }
-    if (rc != MX_OK) return rc;
+    MX_TRY(launch_n2(a, p, ch.wpg, s));
   }
   return MX_OK;
 }
@@ -274,6 +360,6 @@ extern "C" int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const
   }
   mx_nsquare_plan plan;
   MX_TRY(mx_powmod_nsquare_prepare(&plan, h_n, h_exp, limbs_n, exp_limbs, d_ws, pb, stream));
-  return mx_powmod_nsquare_run(&plan, d_bases, d_out, limbs2, batch, override_limbs_per_lane(), 0,
+  return mx_powmod_nsquare_run(&plan, d_bases, d_out, limbs2, batch, override_limbs_per_lane(), 0, 0,
                                (char*)d_ws + pb, ws_bytes - pb, stream);
 }

@@ -1,0 +1,38 @@
+// Two-wavefront instantiations of the N^2-modulus pair kernel (mx_powmod_n2_split.hpp) for 3 and 9 limbs per
+// lane (translation unit of its own, built in parallel with the others).
+#include "mx_upload.hpp"
+#include "mx_powmod_n2_split.hpp"
+
+namespace mxs {
+template <int K, int L>
+static int launch(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  size_t lds = mx::powmod_n2_split_lds_bytes<K, L>();
+  if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, L, LIMB_BITS>),
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    MX_HIP(attr);
+  }
+  hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+template <int L>
+static int launch_l(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  switch (K) {
+    case 1: return launch<1, L>(a, nblocks, s);
+    case 2: return launch<2, L>(a, nblocks, s);
+    case 4: return launch<4, L>(a, nblocks, s);
+    case 8: return launch<8, L>(a, nblocks, s);
+    case 16: return launch<16, L>(a, nblocks, s);
+    case 32: return launch<32, L>(a, nblocks, s);
+  }
+  return MX_ERR_SIZE;
+}
+
+int launch_n2_split(int K, int L, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  if (L == 3) return K == 64 ? launch<64, 3>(a, nblocks, s) : launch_l<3>(K, a, nblocks, s);
+  if (L == LIMBS_PER_LANE) return launch_l<LIMBS_PER_LANE>(K, a, nblocks, s);
+  return MX_ERR_SIZE;
+}
+}  // namespace mxs

@@ -32,12 +32,19 @@ namespace mx {
 
 typedef long long i64;
 
-template <int K, int L, int W, bool USE_DPP = true>
+// WG_SYNC: how the group's LDS scratch is ordered between its writers and readers.  true (default): a
+// workgroup barrier — the kernels whose workgroup is ONE wavefront (for them the barrier costs nothing
+// and the scratch of every group belongs to that wavefront).  false: a wavefront-level fence only — for
+// kernels whose workgroup holds several wavefronts that run DIFFERENT code and own disjoint scratch
+// (mx_powmod_n2_split.hpp): the LDS operations of one wavefront execute in order, so a fence that stops
+// the compiler from reordering them is all a wavefront needs to read what its own lanes wrote.
+template <int K, int L, int W, bool USE_DPP = true, bool WG_SYNC = true>
 struct Mont {
   static_assert(L >= 2, "L >= 2");
   static_assert(W >= 16 && W <= 30, "radix");
   using LN = Lanes<K, USE_DPP>;
   static constexpr u32 MASK = (1u << W) - 1u;
+  static constexpr int LIMBS = L;
   static constexpr int S = K * L;              // capacity in limbs
   static constexpr int LDS_WORDS = 2 * S + 8;  // per-group scratch (32-bit words): multiplier b, second multiplier d
   static constexpr int LDS_D = S + 4;          // offset of the second multiplier
@@ -51,6 +58,16 @@ struct Mont {
   int p;         // lane position in the group
   int nblk;      // R = 2^(W*L*nblk)
   u32* lds;      // this group's LDS scratch, LDS_WORDS words
+
+  static __device__ __forceinline__ void sync() {
+    if constexpr (WG_SYNC) {
+      __syncthreads();
+    } else {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  }
 
   // ------------------------------------------------------------------ setup / conversion
   __device__ __forceinline__ void init(u32* lds_group, int nblk_) {
@@ -69,9 +86,9 @@ struct Mont {
   // Cooperative copy of `nwords` 32-bit words (global memory, contiguous per element: the
   // group reads one contiguous span, lane-consecutive) into the group's LDS scratch, zero padded.
   __device__ __forceinline__ void stage_words(const u32* __restrict__ src, int nwords) {
-    __syncthreads();
+    sync();
     for (int k = p; k < LDS_WORDS; k += K) lds[k] = (k < nwords) ? src[k] : 0u;
-    __syncthreads();
+    sync();
   }
 
   // radix-2^32 words in LDS -> this lane's L radix-2^W limbs
@@ -92,11 +109,11 @@ struct Mont {
 
   // exact W-bit limbs (this lane's slice) -> radix-2^32 words in global memory
   __device__ __forceinline__ void store(u32* __restrict__ dst, int nwords, const u32 (&x)[L], bool valid) {
-    __syncthreads();
+    sync();
 #pragma unroll
     for (int j = 0; j < L; ++j) lds[p * L + j] = x[j];
     if (p == 0) { lds[S] = 0; lds[S + 1] = 0; lds[S + 2] = 0; lds[S + 3] = 0; }
-    __syncthreads();
+    sync();
     for (int k = p; k < nwords; k += K) {
       int bit = 32 * k;
       int g = bit / W, off = bit - g * W;
@@ -109,7 +126,7 @@ struct Mont {
       }
       if (valid) dst[k] = out;
     }
-    __syncthreads();
+    sync();
   }
 
   // n[] must be loaded; computes n0inv = -N^-1 mod 2^W from the group's limb 0
@@ -241,10 +258,10 @@ struct Mont {
 
   // b (and d) where every lane of the group can read any limb; they stay valid until the next staging
   __device__ __forceinline__ void stage_multipliers(const u32 (&b)[L], const u32 (&d)[L]) {
-    __syncthreads();
+    sync();
 #pragma unroll
     for (int j = 0; j < L; ++j) { lds[p * L + j] = b[j]; lds[LDS_D + p * L + j] = d[j]; }
-    __syncthreads();
+    sync();
   }
 
   template <int F, int I, int J>
@@ -320,14 +337,14 @@ struct Mont {
                                        const u32 (&d)[L], const u32 (&init)[L], u32* qrec, u32* emit, int nsteps_blk) {
     // stage the multiplier(s) where every lane of the group can read any limb
     if constexpr (!(F & F_STAGED)) {
-      __syncthreads();
+      sync();
 #pragma unroll
       for (int j = 0; j < L; ++j) lds[p * L + j] = (F & F_BDOUBLE) ? (b[j] << 1) : b[j];
       if constexpr (F & F_TWO) {
 #pragma unroll
         for (int j = 0; j < L; ++j) lds[LDS_D + p * L + j] = d[j];
       }
-      __syncthreads();
+      sync();
     }
     u64 t[L];
 #pragma unroll

@@ -65,14 +65,14 @@ struct PowmodN2Args {
   int first, last;    // first segment: input conversion prologue; last segment: output epilogue
 };
 
-template <int K, int L, int W>
-struct PairArith {
-  using M_t = Mont<K, L, W, true>;
+template <class M_t>
+struct PairArithT {
+  static constexpr int L = M_t::LIMBS;
   static constexpr u32 MASK = M_t::MASK;
   M_t& M;
   const u32* cp;      // LDS: limbs of C' = C - R + 1 (one copy per workgroup, slice of lane p at cp[p*L ..])
 
-  __device__ __forceinline__ PairArith(M_t& m, const u32* cprime_lds) : M(m), cp(cprime_lds) {}
+  __device__ __forceinline__ PairArithT(M_t& m, const u32* cprime_lds) : M(m), cp(cprime_lds) {}
 
   // accumulator start of the second pass: C' + (R - 1 - Q), limb-wise (in place in q)
   __device__ __forceinline__ void second_pass_init(u32 (&q)[L]) const {
@@ -81,15 +81,38 @@ struct PairArith {
     for (int j = 0; j < L; ++j) q[j] = cp[M.p * L + j] + (has_q ? (MASK - q[j]) : 0u);
   }
 
+  // The two passes of a pair product, separately: the first (Z0 and the quotient Q) involves only the
+  // first digits of the operands, the second only reads Q.  One wavefront runs both in turn (mul / sqr
+  // below); the split kernel gives each pass its own wavefront (mx_powmod_n2_split.hpp).
+  //   multiplication, multipliers staged in LDS by M.stage_multipliers(y0, y1) (pass 1 reads y0 only)
+  __device__ __forceinline__ void mul_pass1(u32 (&t0)[L], u32 (&q)[L], u32 (&x0)[L]) {
+    M.template mulx<M_t::F_RECORD_Q | M_t::F_STAGED>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
+  }
+  //   pass 1 on its own (stages y0 itself; the split kernel's first wavefront has no use for y1)
+  __device__ __forceinline__ void mul_pass1_unstaged(u32 (&t0)[L], u32 (&q)[L], u32 (&x0)[L], const u32 (&y0)[L]) {
+    M.template mulx<M_t::F_RECORD_Q>(t0, x0, y0, x0, y0, y0, q, nullptr, M.nblk);
+  }
+  __device__ __forceinline__ void mul_pass2(u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L], u32 (&q)[L]) {
+    second_pass_init(q);
+    M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_STAGED>(z1, x1, x1, x0, x1, q, nullptr, nullptr, M.nblk);
+  }
+  //   squaring
+  __device__ __forceinline__ void sqr_pass1(u32 (&t0)[L], u32 (&q)[L], u32 (&x0)[L]) {
+    M.template mulx<M_t::F_RECORD_Q | M_t::F_SQUARE>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
+  }
+  __device__ __forceinline__ void sqr_pass2(u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L], u32 (&q)[L]) {
+    second_pass_init(q);
+    M.template mulx<M_t::F_INIT | M_t::F_BDOUBLE>(z1, x0, x1, x0, x1, q, nullptr, nullptr, M.nblk);   // 2 * X0 * X1
+  }
+
   // (z0, z1) = (x0, x1) * (y0, y1); outputs may alias inputs
   __device__ __forceinline__ void mul(u32 (&z0)[L], u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L],
                                       const u32 (&y0)[L], const u32 (&y1)[L]) {
     // both multipliers go to LDS once: pass 1 reads y0, pass 2 reads y0 (row X1*Y0) and y1 (row X0*Y1)
     M.stage_multipliers(y0, y1);
     u32 t0[L], q[L];
-    M.template mulx<M_t::F_RECORD_Q | M_t::F_STAGED>(t0, x0, y0, x0, y0, y0, q, nullptr, M.nblk);
-    second_pass_init(q);
-    M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_STAGED>(z1, x1, y0, x0, y1, q, nullptr, nullptr, M.nblk);
+    mul_pass1(t0, q, x0);
+    mul_pass2(z1, x0, x1, q);
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
@@ -97,13 +120,14 @@ struct PairArith {
   // (z0, z1) = (x0, x1)^2
   __device__ __forceinline__ void sqr(u32 (&z0)[L], u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L]) {
     u32 t0[L], q[L];
-    M.template mulx<M_t::F_RECORD_Q | M_t::F_SQUARE>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
-    second_pass_init(q);
-    M.template mulx<M_t::F_INIT | M_t::F_BDOUBLE>(z1, x0, x1, x0, x1, q, nullptr, nullptr, M.nblk);   // 2 * X0 * X1
+    sqr_pass1(t0, q, x0);
+    sqr_pass2(z1, x0, x1, q);
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
 };
+template <int K, int L, int W>
+using PairArith = PairArithT<Mont<K, L, W, true>>;
 
 // W-bit field of a little-endian word array starting at bit `bitpos` (words zero padded by the caller)
 __device__ __forceinline__ u32 extract_field(const u32* words, int bitpos, int nbits) {

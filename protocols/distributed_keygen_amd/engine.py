@@ -51,6 +51,7 @@ class Engine:
         self.device = torch.device("cuda", idx)
         self._ws: Dict[int, Any] = {}          # stream -> workspace tensor
         self._lpl = 0                          # lane geometry of this engine's modexp launches (0 = automatic)
+        self._wpg = 0                          # wavefronts per group of the N^2 pair kernel (0 = automatic, 1, 2)
         self._segments = 0                     # launches per N^2 exponentiation (0 = automatic; include/mxpaillier.h)
         self._n2_plans: "OrderedDict[Tuple[int, int], _Plan]" = OrderedDict()
         self._combine_plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
@@ -105,10 +106,22 @@ class Engine:
 
     def set_limbs_per_lane(self, limbs_per_lane: int) -> None:
         """Lane geometry of this engine's modexp launches: 0 = automatic (from the batch size), 9 =
-        narrow, 18 = wide.  Passed with every call (no process-wide state)."""
-        if limbs_per_lane not in (0, 9, 18):
-            raise ValueError("limbs_per_lane must be 0, 9 or 18")
+        narrow, 18 = wide, 3 = the latency geometry of the N^2 pair kernel (two wavefronts per group; the
+        generic-modulus kernels treat it as automatic).  Passed with every call (no process-wide state)."""
+        if limbs_per_lane not in (0, 3, 9, 18):
+            raise ValueError("limbs_per_lane must be 0, 3, 9 or 18")
         self._lpl = int(limbs_per_lane)
+
+    def set_wavefronts_per_group(self, wavefronts: int) -> None:
+        """N^2 pair kernel (powmod_nsquare_t): 1 = one wavefront runs both Montgomery passes of a pair product,
+        2 = two wavefronts, one pass each (for launches that leave SIMDs idle), 0 = the library's choice
+        (include/mxpaillier.h: mx_powmod_nsquare_run)."""
+        if wavefronts not in (0, 1, 2):
+            raise ValueError("wavefronts per group must be 0, 1 or 2")
+        self._wpg = int(wavefronts)
+
+    def _lpl_generic(self) -> int:
+        return self._lpl if self._lpl in (9, 18) else 0
 
     def set_segments(self, segments: int) -> None:
         """Launches one mx_powmod_nsquare_run exponentiation is cut into (0 = automatic, 1..64)."""
@@ -125,7 +138,7 @@ class Engine:
         import ctypes
 
         k, l, w, b = (ctypes.c_int() for _ in range(4))
-        _lib.check(self.lib.mx_powmod_geometry_for(mod_bits, batch, groups, self._lpl, k, l, w, b), "mx_powmod_geometry_for")
+        _lib.check(self.lib.mx_powmod_geometry_for(mod_bits, batch, groups, self._lpl_generic(), k, l, w, b), "mx_powmod_geometry_for")
         return k.value, l.value, w.value, b.value
 
     def debug_knob(self, knob: str, value: int) -> None:
@@ -150,9 +163,16 @@ class Engine:
         """(lanes per element, limbs per lane, limb bits, blocks) of a powmod_nsquare launch."""
         import ctypes
 
-        k, l, w, b = (ctypes.c_int() for _ in range(4))
-        _lib.check(self.lib.mx_nsquare_geometry_for(n_bits, batch, self._lpl, k, l, w, b), "mx_nsquare_geometry_for")
-        return k.value, l.value, w.value, b.value
+        return self.nsquare_launch_shape(n_bits, batch)[:4]
+
+    def nsquare_launch_shape(self, n_bits: int, batch: int) -> Tuple[int, int, int, int, int]:
+        """(lanes per element, limbs per lane, limb bits, blocks, wavefronts per group) of a
+        powmod_nsquare launch of `batch` elements with this engine's settings."""
+        import ctypes
+
+        k, l, w, b, wv = (ctypes.c_int() for _ in range(5))
+        _lib.check(self.lib.mx_nsquare_launch_shape(n_bits, batch, self._lpl, self._wpg, k, l, w, b, wv), "mx_nsquare_launch_shape")
+        return k.value, l.value, w.value, b.value, wv.value
 
     def _mods_operand(self, mods, limbs: int, odd_only: bool = True):
         """Moduli of a per-group launch as (device rows [groups, limbs], max bits).  `mods` is a sequence
@@ -187,7 +207,7 @@ class Engine:
             ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, 1))
             rc = self.lib.mx_powmod_shared_lpl(
                 bases_t.data_ptr(), out_t.data_ptr(), h_mod.ctypes.data, h_exp.ctypes.data,
-                limbs, elimbs, batch, self._lpl, ws.data_ptr(), ws.numel(), self._stream_ptr(),
+                limbs, elimbs, batch, self._lpl_generic(), ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_shared_lpl")
         return out_t
@@ -219,7 +239,7 @@ class Engine:
             ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, groups))
             rc = self.lib.mx_powmod_multi_dev(
                 bases_t.data_ptr(), out_t.data_ptr(), mods_t.data_ptr(), exps_t.data_ptr(),
-                limbs, elimbs, mod_bits, exp_bits, groups, group_size, self._lpl, ws.data_ptr(), ws.numel(),
+                limbs, elimbs, mod_bits, exp_bits, groups, group_size, self._lpl_generic(), ws.data_ptr(), ws.numel(),
                 self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_multi_dev")
@@ -307,7 +327,7 @@ class Engine:
             self._use_plan(plan)
             ws = self._workspace(self.lib.mx_powmod_nsquare_run_workspace_bytes(plan.desc, batch))
             rc = self.lib.mx_powmod_nsquare_run(
-                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl,
+                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl, self._wpg,
                 self._segments if segments is None else int(segments), ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_nsquare_run")

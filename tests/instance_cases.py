@@ -7,21 +7,33 @@ mx_powmod_multi_dev: per-group exponents, fixed window).  ``tests/test_instances
 library's own geometry queries over the whole supported range and fails if an instance it can
 return has no case below; ``tests/test_gpu_instances.py`` runs the cases bit-exactly against pow().
 
-Each case: (kind, modulus-root bits, limbs_per_lane argument, batch, exponent bits).
+Each case: (kind, modulus-root bits, limbs_per_lane argument, batch, exponent bits[, wavefronts per group]).
 kind "n2": modulus is N^2 for an N of that many bits; "shared" / "multi": modulus of that many bits.
+The pair kernel exists in two forms — ``powmod_n2_kernel`` (one wavefront per group of elements) and
+``powmod_n2_split_kernel`` (two: mx_powmod_n2_split.hpp) — selected by the sixth field (1 | 2; 0 = the
+library's choice for this batch).
 """
 
 from __future__ import annotations
 
 N2_CASES = [
-    # narrow geometry (L = 9): K = 1, 2, 4, 8, 16, 16, 32, 32
-    ("n2", 200, 9, 19, 130), ("n2", 400, 9, 11, 130), ("n2", 900, 9, 9, 130), ("n2", 2051, 9, 9, 200),
-    ("n2", 3075, 9, 5, 96), ("n2", 4099, 9, 5, 96), ("n2", 6000, 9, 3, 64), ("n2", 8200, 9, 3, 64),
-    # wide geometry (L = 18): K = 1, 2, 4, 8, 8, 16, 16
-    ("n2", 400, 18, 70, 130), ("n2", 900, 18, 40, 130), ("n2", 2051, 18, 20, 200),
-    ("n2", 3075, 18, 12, 96), ("n2", 4099, 18, 12, 96), ("n2", 6000, 18, 6, 64), ("n2", 8200, 18, 6, 64),
-    # automatic choice: small batch -> narrow
-    ("n2", 2051, 0, 7, 64),
+    # one wavefront per group, narrow geometry (L = 9): K = 1, 2, 4, 8, 16, 16, 32, 32
+    ("n2", 200, 9, 19, 130, 1), ("n2", 400, 9, 11, 130, 1), ("n2", 900, 9, 9, 130, 1), ("n2", 2051, 9, 9, 200, 1),
+    ("n2", 3075, 9, 5, 96, 1), ("n2", 4099, 9, 5, 96, 1), ("n2", 6000, 9, 3, 64, 1), ("n2", 8200, 9, 3, 64, 1),
+    # one wavefront per group, wide geometry (L = 18): K = 1, 2, 4, 8, 8, 16, 16
+    ("n2", 400, 18, 70, 130, 1), ("n2", 900, 18, 40, 130, 1), ("n2", 2051, 18, 20, 200, 1),
+    ("n2", 3075, 18, 12, 96, 1), ("n2", 4099, 18, 12, 96, 1), ("n2", 6000, 18, 6, 64, 1), ("n2", 8200, 18, 6, 64, 1),
+    # two wavefronts per group, L = 9: K = 1, 2, 4, 8, 16, 16, 32, 32 (batches that leave the last workgroup ragged)
+    ("n2", 200, 9, 130, 130, 2), ("n2", 400, 9, 67, 130, 2), ("n2", 900, 9, 35, 130, 2), ("n2", 2051, 9, 19, 200, 2),
+    ("n2", 3075, 9, 9, 96, 2), ("n2", 4099, 9, 9, 96, 2), ("n2", 6000, 9, 5, 64, 2), ("n2", 8200, 9, 3, 64, 2),
+    # two wavefronts per group, L = 18: K = 1, 2, 4, 8, 8, 16, 16
+    ("n2", 400, 18, 70, 130, 2), ("n2", 900, 18, 40, 130, 2), ("n2", 2051, 18, 37, 200, 2),
+    ("n2", 3075, 18, 12, 96, 2), ("n2", 4099, 18, 12, 96, 2), ("n2", 6000, 18, 6, 64, 2), ("n2", 8200, 18, 6, 64, 2),
+    # two wavefronts per group, latency geometry L = 3: K = 1, 2, 4, 8, 16, 32, 64, 64
+    ("n2", 60, 3, 130, 100, 2), ("n2", 150, 3, 67, 130, 2), ("n2", 300, 3, 35, 130, 2), ("n2", 600, 3, 19, 130, 2),
+    ("n2", 1027, 3, 9, 130, 2), ("n2", 2051, 3, 5, 200, 2), ("n2", 3075, 3, 3, 96, 2), ("n2", 4099, 3, 3, 96, 2),
+    # the library's choice: a handful of elements -> the latency geometry on two wavefronts
+    ("n2", 2051, 0, 7, 64, 0),
 ]
 
 GENERIC_CASES = [
@@ -49,11 +61,20 @@ def _geom(fn, *args):
     return (k.value, l.value) if rc == 0 else None
 
 
+def _shape(lib, bits, batch, lpl, wpg):
+    import ctypes
+
+    k, l, w, b, wv = (ctypes.c_int() for _ in range(5))
+    rc = lib.mx_nsquare_launch_shape(bits, batch, lpl, wpg, k, l, w, b, wv)
+    return (k.value, l.value, wv.value) if rc == 0 else None
+
+
 def case_instance(lib, case):
-    """The template instance ("n2" | "generic-sliding" | "generic-fixed", K, L) a case runs."""
-    kind, bits, lpl, batch, _ = case
+    """The template instance a case runs: ("n2", K, L, wavefronts per group) or
+    ("generic-sliding" | "generic-fixed", K, L)."""
+    kind, bits, lpl, batch = case[:4]
     if kind == "n2":
-        g = _geom(lib.mx_nsquare_geometry_for, bits, batch, lpl)
+        g = _shape(lib, bits, batch, lpl, case[5])
         return None if g is None else ("n2",) + g
     groups = 1 if kind == "shared" else 3
     g = _geom(lib.mx_powmod_geometry_for, bits, batch * groups, groups, lpl)
@@ -62,15 +83,17 @@ def case_instance(lib, case):
 
 def reachable_instances(lib):
     """Every instance the launchers can return, probed through the library's geometry queries over the
-    supported modulus range, a spread of batch sizes and all three limbs_per_lane arguments."""
+    supported modulus range, a spread of batch sizes and all limbs_per_lane / wavefronts_per_group arguments."""
     out = set()
     bit_points = sorted(set(list(range(2, 600)) + list(range(600, 17000, 7)) + [16700, 16701, 8348, 8349, 4172, 4173]))
-    for lpl in (0, 9, 18):
-        for batch in (1, 64, 5000, 20000, 200000, 2000000):
-            for bits in bit_points:
-                g = _geom(lib.mx_nsquare_geometry_for, bits, batch, lpl)
-                if g is not None:
-                    out.add(("n2",) + g)
+    for batch in (1, 64, 5000, 20000, 200000, 2000000):
+        for bits in bit_points:
+            for lpl in (0, 3, 9, 18):
+                for wpg in (0, 1, 2):
+                    g = _shape(lib, bits, batch, lpl, wpg)
+                    if g is not None:
+                        out.add(("n2",) + g)
+            for lpl in (0, 9, 18):
                 for groups, name in ((1, "generic-sliding"), (max(2, batch // 40), "generic-fixed")):
                     g = _geom(lib.mx_powmod_geometry_for, bits, max(batch, groups), groups, lpl)
                     if g is not None:

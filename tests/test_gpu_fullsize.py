@@ -135,3 +135,89 @@ def test_c2_c4_biprimality_batches(eng, key_length, n_parties, n_cands):
         else:
             assert verdict == oracle.biprime_test_with_v_i(vd, m, 40)
     assert sum(verdicts) == sum(1 for c in cands if c[3])
+
+
+def _steer_to_primes(args):
+    """(p_parts, q_parts, seed) -> the same shares with the last one of each moved so that both sums are prime."""
+    from protocols.distributed_keygen_amd import synthetic
+
+    p_parts, q_parts, seed = args
+    rng = random.Random(seed)
+    for parts in (p_parts, q_parts):
+        base = t = sum(parts)
+        while not synthetic.is_probable_prime(t, rng, 8):
+            t += 4
+        parts[-1] += t - base
+    return p_parts, q_parts
+
+
+def _host_v_row(args):
+    """One candidate's reference v-calculation (DK:1084-1099) with CPython pow: (g list, N, exponent) -> v list."""
+    gs, m, e = args
+    kept = [g for g in gs if oracle.jacobi_symbol(g, m) == 1][:40]
+    return [pow(g, e, m) for g in kept]
+
+
+def test_c4_full_size_4096_candidates_key2048(eng):
+    """configs[3] at its full size: 5 parties, key_length 2048, 4096 candidate moduli x 160 generators.  All five
+    parties' v values through the fused Jacobi -> selection -> modexp path, the verdict of every candidate: exactly
+    the planted biprimes pass all 40 slots.  72 candidates (the planted ones and a spread of composites) are
+    recomputed on the host cores — Jacobi selection with the oracle, v values with pow() — and compared bit for
+    bit, for party 1 (long exponent) and party 3 (short exponent).  The 512-candidate shard that one of 8 GPUs
+    gets (another launch shape) reproduces its slice of the full run."""
+    import multiprocessing as mp
+
+    import torch
+
+    from protocols.distributed_keygen_amd import limbs as L, synthetic
+
+    n_parties, cands, gens, keep = 5, 4096, 160, 40
+    rng = random.Random(0xC4)
+    primes = oracle.small_prime_list(2000)
+    shares = []                                       # survivors of the sieve DK:1288-1292, as the v-calculation sees them
+    while len(shares) < cands:
+        chunk = [synthetic.candidate_shares(rng, n_parties, 1024) for _ in range(16384)]
+        bad = eng.sieve_batch([sum(p) * sum(q) for p, q in chunk], primes)
+        shares += [sh for sh, b in zip(chunk, bad) if not b]
+    shares = shares[:cands]
+    planted = sorted(rng.sample(range(1, cands - 1), 8) + [0, cands - 1])
+    with mp.Pool() as pool:
+        fixed = pool.map(_steer_to_primes, [(shares[k][0], shares[k][1], 1000 + k) for k in planted], chunksize=1)
+        for k, sh in zip(planted, fixed):
+            shares[k] = sh
+        mods = [sum(p) * sum(q) for p, q in shares]
+        bits = max(m.bit_length() for m in mods)
+        limbs = L.limbs_for_bits(bits)
+        nb = (bits + 7) // 8 + 8
+        g_all = [int.from_bytes(rng.randbytes(nb), "little") % m for m in mods for _ in range(gens)]
+        g_t = eng.to_device(L.pack(g_all, limbs))
+        mods_op = (eng.to_device(L.pack(mods, limbs)), bits)
+        exps = {i: [((m - p[0] - q[0] + 1) // 4) if i == 1 else ((p[i - 1] + q[i - 1]) // 4) for m, (p, q) in zip(mods, shares)]
+                for i in range(1, n_parties + 1)}
+        v_all = torch.zeros((n_parties, cands, keep, limbs), dtype=torch.int32, device=eng.device)
+        counts = {}
+        for i in range(1, n_parties + 1):
+            eb = max(e.bit_length() for e in exps[i])
+            ex_op = (eng.to_device(L.pack(exps[i], L.limbs_for_bits(eb))), eb)
+            v_t, cnt_t = eng.biprime_v_t(g_t, mods_op, ex_op, gens, keep)
+            v_all[i - 1] = v_t.view(cands, keep, limbs)
+            counts[i] = cnt_t.cpu().tolist()
+            if i == 1:      # the shard one of 8 GPUs would get: its own launch (512 candidates), same rows
+                sl = slice(3 * 512, 4 * 512)
+                sh_mods = (mods_op[0][sl].contiguous(), bits)
+                sh_exps = (ex_op[0][sl].contiguous(), eb)
+                sv_t, scnt_t = eng.biprime_v_t(g_t[sl.start * gens : sl.stop * gens].contiguous(), sh_mods, sh_exps, gens, keep)
+                assert torch.equal(sv_t.view(512, keep, limbs), v_all[0][sl]) and scnt_t.cpu().tolist() == counts[1][sl]
+        assert all(counts[i] == counts[1] for i in counts)               # the selection does not depend on the party
+        assert min(counts[1]) == keep                                    # 160 generators of a sieved candidate hold 40 with symbol 1
+        passes = eng.biprime_verdict_t(v_all, mods_op).cpu().numpy()
+        all_pass = [k for k in range(cands) if passes[k].all()]
+        assert all_pass == planted                                       # the vote: planted biprimes, nothing else
+        # a non-biprime fails a slot with probability >= 1/2 and in practice almost surely: none gets through 8 slots
+        assert all(not passes[k][:8].all() for k in range(cands) if k not in planted)
+        sample = sorted(set(planted + [(k * 577) % cands for k in range(62)]))
+        assert len(sample) >= 64
+        for party in (1, 3):
+            want = pool.map(_host_v_row, [(g_all[k * gens : (k + 1) * gens], mods[k], exps[party][k]) for k in sample], chunksize=1)
+            got = L.unpack(eng.to_host(v_all[party - 1][sample].reshape(-1, limbs)))
+            assert [got[j * keep : (j + 1) * keep] for j in range(len(sample))] == want, party

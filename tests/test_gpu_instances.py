@@ -23,25 +23,28 @@ def eng():
     e = Engine()
     yield e
     e.set_limbs_per_lane(0)
+    e.set_wavefronts_per_group(0)
 
 
 def _modulus(rng, bits):
     return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
 
 
-@pytest.mark.parametrize("case", ic.ALL_CASES, ids=lambda c: f"{c[0]}-{c[1]}b-L{c[2]}-x{c[3]}")
+@pytest.mark.parametrize("case", ic.ALL_CASES, ids=lambda c: f"{c[0]}-{c[1]}b-L{c[2]}-x{c[3]}" + (f"-w{c[5]}" if len(c) > 5 else ""))
 def test_instance_parity(eng, case):
     from protocols.distributed_keygen_amd import _lib
 
-    kind, bits, lpl, batch, ebits = case
+    kind, bits, lpl, batch, ebits = case[:5]
     rng = random.Random(hash(case) & 0xFFFFFF)
     eng.set_limbs_per_lane(lpl)
+    eng.set_wavefronts_per_group(case[5] if kind == "n2" else 0)
     inst = ic.case_instance(_lib.lib(), case)
     assert inst is not None
     if kind == "n2":
         n = _modulus(rng, bits)
         n2 = n * n
-        assert eng.nsquare_geometry(bits, batch)[:2] == inst[1:]
+        shape = eng.nsquare_launch_shape(bits, batch)
+        assert (shape[0], shape[1], shape[4]) == inst[1:]
         bases = [0, 1, n2 - 1, n, n + 1, n2 - n][: max(1, batch - 1)] + [rng.randrange(n2) for _ in range(batch)]
         bases = bases[:batch]
         for e in (rng.getrandbits(ebits) | (1 << (ebits - 1)) | 1, 2):
@@ -60,6 +63,7 @@ def test_instance_parity(eng, case):
         rows = [([0, 1, m - 1] + [rng.randrange(m) for _ in range(batch)])[:batch] for m in mods]
         assert eng.powmod_batch_multi(rows, exps, mods) == [[pow(b, e, m) for b in r] for r, e, m in zip(rows, exps, mods)]
     eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
 
 
 def _special_moduli(bits):
@@ -73,6 +77,7 @@ def test_wide_pair_kernel_k8_k16_special_operands(eng, bits):
     with the operands that stress the lazy-carry machinery: all-ones and sparse moduli, bases that
     are multiples of N, all-ones limb patterns in radix 2^29 and 2^32."""
     eng.set_limbs_per_lane(18)
+    eng.set_wavefronts_per_group(1)
     rng = random.Random(bits)
     assert eng.nsquare_geometry(bits, 16)[:2] == ((8, 18) if bits <= 4172 else (16, 18))
     for n in _special_moduli(bits)[: 4 if bits < 5000 else 2]:
@@ -84,29 +89,35 @@ def test_wide_pair_kernel_k8_k16_special_operands(eng, bits):
                  (n2 - pat29) % n2, (n2 - pat32) % n2] + [rng.randrange(n2) for _ in range(4)]
         for e in (0, 1, 2, 3, (1 << 130) - 1, rng.getrandbits(150) | 1):
             assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (bits, e.bit_length())
+            eng.set_wavefronts_per_group(2)        # and the two-wavefront form of the same instance
+            assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (bits, e.bit_length(), "split")
+            eng.set_wavefronts_per_group(1)
     eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
 
 
-@pytest.mark.parametrize("lpl", [9, 18])
-def test_golden_key4096_partial_decryptions_both_geometries(eng, golden_decrypt_synth, lpl):
-    """The reference-generated partial decryptions of the key_length-4096 key through the narrow
-    <16,9> AND the wide <8,18> pair kernel."""
+@pytest.mark.parametrize("lpl,wpg", [(9, 1), (18, 1), (3, 2), (9, 2), (18, 2)])
+def test_golden_key4096_partial_decryptions_every_launch_shape(eng, golden_decrypt_synth, lpl, wpg):
+    """The reference-generated partial decryptions of the key_length-4096 key through every launch shape of the
+    pair kernel: narrow <16,9> and wide <8,18> on one wavefront per group, and <64,3>, <16,9>, <8,18> on two."""
     grp = golden_decrypt_synth["k4096_n3_t1"]
     n = unhex(grp["n"])
     n2 = n * n
     eng.set_limbs_per_lane(lpl)
-    assert eng.nsquare_geometry(n.bit_length(), 3)[:2] == ((16, 9) if lpl == 9 else (8, 18))
+    eng.set_wavefronts_per_group(wpg)
+    assert eng.nsquare_geometry(n.bit_length(), 3)[:2] == {9: (16, 9), 18: (8, 18), 3: (64, 3)}[lpl]
     cs = [unhex(c["c"]) for c in grp["cases"]]
     for i, share in grp["shares"].items():
         exp = oracle.partial_decrypt_exponent(int(i), grp["degree"], unhex(grp["n_fac"]), unhex(share))
         bases = cs if exp >= 0 else [oracle.mod_inv(c, n2) for c in cs]
         assert eng.powmod_nsquare_batch(bases, abs(exp), n) == [unhex(c["partials"][i]) for c in grp["cases"]], i
     eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
 
 
 def test_c5_sweep_point_batch4096_auto_geometry(eng):
     """configs[4] at a batch size of its sweep: 4096 ciphertexts at key_length 4096 through the
-    product path with the library's own geometry choice — which must be the wide <8,18> instance —
+    product path with the library's own choice of launch shape — the wide <8,18> instance on two wavefronts per group —
     96 samples bit-exact against pow() on the host cores, and the full threshold decryption
     round trip decrypt(encrypt(m)) == m on all 4096."""
     from protocols.distributed_keygen_amd import synthetic
@@ -115,7 +126,8 @@ def test_c5_sweep_point_batch4096_auto_geometry(eng):
     n, n2 = key.n, key.n_square
     batch = 4096
     eng.set_limbs_per_lane(0)
-    assert eng.nsquare_geometry(n.bit_length(), batch)[:2] == (8, 18)
+    eng.set_wavefronts_per_group(0)
+    assert eng.nsquare_launch_shape(n.bit_length(), batch)[:2] + eng.nsquare_launch_shape(n.bit_length(), batch)[4:] == (8, 18, 2)
     rng = random.Random(40960)
     msgs = [rng.randrange(n) for _ in range(batch)]
     msgs[:3] = [0, 1, n - 1]
@@ -134,8 +146,11 @@ def test_c5_sweep_point_batch4096_auto_geometry(eng):
     with mp.Pool() as pool:
         want = pool.starmap(pow, [(cts[k], key.exponent(i_pos), n2) for k in idx], chunksize=1)
     assert [partials[i_pos - 1][k] for k in idx] == want
-    # the narrow instance on the same inputs agrees on every ciphertext
-    eng.set_limbs_per_lane(9)
-    assert eng.nsquare_geometry(n.bit_length(), batch)[:2] == (16, 9)
-    assert eng.powmod_nsquare_batch(cts, key.exponent(i_pos), n) == partials[i_pos - 1]
+    # the one-wavefront narrow and wide instances on the same inputs agree on every ciphertext
+    for lpl, want in ((9, (16, 9)), (18, (8, 18))):
+        eng.set_limbs_per_lane(lpl)
+        eng.set_wavefronts_per_group(1)
+        assert eng.nsquare_geometry(n.bit_length(), batch)[:2] == want
+        assert eng.powmod_nsquare_batch(cts, key.exponent(i_pos), n) == partials[i_pos - 1]
     eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)

@@ -45,10 +45,8 @@ def test_geometry_query():
         assert (k.value, l.value, w.value) == (want_k, 9, 29)
         assert w.value * l.value * b.value >= bits + 4 and b.value <= k.value
     assert lib.mx_geometry(16701, k, l, w, b) == -2
-    # the pair kernel picks its geometry per launch: narrow for small launches, wide (half the lanes,
-    # twice the limbs per lane) from ~480 wavefronts, and only when the narrow one needs >= 8 lanes
-    for bits, batch, want in ((2051, 100, (8, 9)), (2051, 10000, (4, 18)), (2051, 7000, (8, 9)), (1028, 100000, (4, 9)),
-                              (4100, 4000, (8, 18)), (4100, 1000, (16, 9))):
+    # the pair kernel picks its launch shape per launch (tests/test_instances.py pins the crossovers)
+    for bits, batch, want in ((2051, 100, (32, 3)), (2051, 3000, (8, 9)), (2051, 7000, (4, 18)), (4100, 100, (64, 3))):
         assert lib.mx_nsquare_geometry(bits, batch, k, l, w, b) == 0
         assert (k.value, l.value) == want, (bits, batch)
         assert w.value * l.value * b.value >= bits + 4

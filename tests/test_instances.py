@@ -22,23 +22,34 @@ def test_every_reachable_instance_has_a_parity_case():
     missing = reachable - covered
     assert not missing, f"kernel instances without a parity case: {sorted(missing)}"
     # the enumeration itself must see the instances VERDICT r01 named, and the full template grid
-    assert ("n2", 8, 18) in reachable and ("n2", 16, 18) in reachable
-    assert {k for kind, k, l in reachable if kind == "n2" and l == 9} == {1, 2, 4, 8, 16, 32}
-    assert {k for kind, k, l in reachable if kind == "n2" and l == 18} == {1, 2, 4, 8, 16}
+    assert ("n2", 8, 18, 1) in reachable and ("n2", 16, 18, 1) in reachable
+    for wpg in (1, 2):
+        assert {k for kind, k, l, *w in reachable if kind == "n2" and l == 9 and w == [wpg]} == {1, 2, 4, 8, 16, 32}
+        assert {k for kind, k, l, *w in reachable if kind == "n2" and l == 18 and w == [wpg]} == {1, 2, 4, 8, 16}
+    for lat in (3,):
+        assert {k for kind, k, l, *w in reachable if kind == "n2" and l == lat and w == [2]} == {1, 2, 4, 8, 16, 32, 64}
+        assert not {k for kind, k, l, *w in reachable if kind == "n2" and l == lat and w == [1]}     # latency geometries are split only
     for kind in ("generic-sliding", "generic-fixed"):
-        assert {k for kd, k, l in reachable if kd == kind and l == 9} == {1, 2, 4, 8, 16, 32, 64}
-        assert {k for kd, k, l in reachable if kd == kind and l == 18} == {1, 2, 4, 8, 16, 32}
+        assert {k for kd, k, l, *w in reachable if kd == kind and l == 9} == {1, 2, 4, 8, 16, 32, 64}
+        assert {k for kd, k, l, *w in reachable if kd == kind and l == 18} == {1, 2, 4, 8, 16, 32}
 
 
-def test_auto_geometry_choices_match_the_documented_thresholds():
-    """key_length 4096 at the C5 sweep's batch sizes: narrow <16,9> below ~3840 ciphertexts, wide <8,18>
-    from there (the instance the round-1 C5 numbers were produced with)."""
+def test_auto_launch_shapes_match_the_measured_crossovers():
+    """The library's choice for ONE launch on an idle GPU follows the crossovers tools/sweep_shapes.py measured
+    (profiles/r03_sweep_shapes.txt): latency geometry on two wavefronts for a handful of ciphertexts, then 9 and 18
+    limbs per lane still on two wavefronts while that buys occupancy, the one-wavefront wide kernel once a launch
+    fills the machine on its own."""
     from protocols.distributed_keygen_amd import _lib
 
     lib = _lib.lib()
-    assert ic.case_instance(lib, ("n2", 4099, 0, 1000, 0)) == ("n2", 16, 9)
-    assert ic.case_instance(lib, ("n2", 4099, 0, 4096, 0)) == ("n2", 8, 18)
-    assert ic.case_instance(lib, ("n2", 4099, 0, 16000, 0)) == ("n2", 8, 18)
-    assert ic.case_instance(lib, ("n2", 2051, 0, 10000, 0)) == ("n2", 4, 18)
-    assert ic.case_instance(lib, ("n2", 2051, 0, 2000, 0)) == ("n2", 8, 9)
-    assert ic.case_instance(lib, ("n2", 3075, 0, 4000, 0)) == ("n2", 8, 18)
+    shape = lambda bits, batch: ic.case_instance(lib, ("n2", bits, 0, batch, 0, 0))
+    for batch, want in ((1, (32, 3, 2)), (64, (32, 3, 2)), (1000, (32, 3, 2)), (2000, (8, 9, 2)), (4096, (8, 9, 2)),
+                        (6144, (4, 18, 2)), (8192, (4, 18, 2)), (10000, (8, 9, 2)), (16384, (4, 18, 1)), (30000, (4, 18, 1))):
+        assert shape(2051, batch) == ("n2",) + want, batch
+    for batch, want in ((1, (64, 3, 2)), (512, (64, 3, 2)), (1024, (16, 9, 2)), (4096, (8, 18, 2)), (16000, (8, 18, 1))):
+        assert shape(4099, batch) == ("n2",) + want, batch
+    assert shape(1027, 256) == ("n2", 16, 3, 2) and shape(1027, 100000)[3] == 1
+    # an explicit argument pins that half of the choice
+    assert ic.case_instance(lib, ("n2", 2051, 18, 10, 0, 0)) == ("n2", 4, 18, 2)
+    assert ic.case_instance(lib, ("n2", 2051, 0, 10, 0, 1)) == ("n2", 8, 9, 1)
+    assert ic.case_instance(lib, ("n2", 2051, 3, 10, 0, 1)) is None          # the latency geometry has no one-wavefront form
