@@ -70,7 +70,11 @@ def check_limits(engine: Any = None, prime_list: Optional[Iterable[int]] = None,
 def _gpu_key(key: Any, engine: Any) -> GpuPaillierSharedKey:
     cached = getattr(key, "_mx_gpu_key", None)
     if cached is None or cached.n != key.n or cached.share is not key.share:
-        cached = GpuPaillierSharedKey.from_reference(key, engine)
+        # the ciphertext class the key's own module binds (paillier_shared_key.py:16-19 imports it by name)
+        import sys
+
+        ct_type = getattr(sys.modules.get(type(key).__module__), "PaillierCiphertext", None)
+        cached = GpuPaillierSharedKey.from_reference(key, engine, ciphertext_type=ct_type)
         key._mx_gpu_key = cached
     return cached
 

@@ -52,7 +52,11 @@ def _mult_list(values: Iterable[int]) -> int:
 class GpuPaillierSharedKey:
     """Drop-in for ``PaillierSharedKey`` (PSK:25-127) with batched GPU arithmetic."""
 
-    def __init__(self, n: int, t: int, player_id: int, share: Any, theta: int, engine: Any = None) -> None:
+    def __init__(self, n: int, t: int, player_id: int, share: Any, theta: int, engine: Any = None,
+                 ciphertext_type: Any = None) -> None:
+        # the class PSK:62-65 tests ciphertexts against; None = the reference's PaillierCiphertext when its
+        # package has been imported (patch.install passes the one its target package binds)
+        self.ciphertext_type = ciphertext_type
         self.share = share
         self.n = n
         self.n_square = n * n
@@ -63,9 +67,10 @@ class GpuPaillierSharedKey:
         self.theta_inv = self.engine.modinv_batch([theta], n)[0]  # mod_inv(self.theta, self.n), PSK:50 (ValueError if not invertible)
 
     @classmethod
-    def from_reference(cls, key: Any, engine: Any = None) -> "GpuPaillierSharedKey":
+    def from_reference(cls, key: Any, engine: Any = None, ciphertext_type: Any = None) -> "GpuPaillierSharedKey":
         """Wrap an existing reference ``PaillierSharedKey`` (same n, t, player_id, share, theta)."""
-        return cls(n=key.n, t=key.t, player_id=key.player_id, share=key.share, theta=key.theta, engine=engine)
+        return cls(n=key.n, t=key.t, player_id=key.player_id, share=key.share, theta=key.theta, engine=engine,
+                   ciphertext_type=ciphertext_type)
 
     @property
     def engine(self) -> Any:
@@ -85,7 +90,7 @@ class GpuPaillierSharedKey:
 
     def _check_ciphertext(self, ciphertext: Any, ref_type: Any = None) -> None:
         if ref_type is None:
-            ref_type = _ref_ciphertext_type()
+            ref_type = self.ciphertext_type or _ref_ciphertext_type()
         is_ct = isinstance(ciphertext, PlainCiphertext) or (
             isinstance(ciphertext, ref_type) if ref_type is not None
             else (hasattr(ciphertext, "get_value") and hasattr(ciphertext, "scheme"))
@@ -100,7 +105,7 @@ class GpuPaillierSharedKey:
         ``keep_rows`` returns ``(ints, column)``: the column is the engine's device-resident copy of
         the results for ``decrypt_columns`` (the party's own share of the recombination)."""
         values: List[int] = []
-        ref_type = _ref_ciphertext_type()
+        ref_type = self.ciphertext_type or _ref_ciphertext_type()
         ok_type = ok_scheme = None
         for ciphertext in ciphertexts:
             # PSK:62-68 per ciphertext, in order; a type / scheme object that already passed is not re-examined
