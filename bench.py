@@ -21,8 +21,9 @@ Workloads:
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0) whose `roofline`
 is the VALU instruction-issue roof (the path is integer-only: no MFMA, HBM three orders of
 magnitude away) with the HBM figures as a sub-block, plus `cpu_baseline` (the
-reference's gmpy2 engine on the host cores) and, on one GPU, the legs `single_batch`,
-`end_to_end`, `extra.biprime_k2048` and `extra.c5_k4096`.  DESIGN.md §6 defines every field.
+reference's gmpy2 engine on the host cores) and, on one GPU, the legs `single_batch`, `latency`,
+`end_to_end`, `end_to_end_keygen`, `extra.biprime_k2048`, `extra.biprime_k1024_c256/_c8192` and
+`extra.c5_k4096[_b1024/_b16384]`.  DESIGN.md §6 defines every field.
 """
 
 from __future__ import annotations
@@ -49,15 +50,20 @@ from protocols.distributed_keygen_amd import configure_hw_queues  # noqa: E402  
 configure_hw_queues(16)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
-# VALU issue: 1024 SIMDs, one wave64 VALU instruction per 4 cycles per SIMD (16 lanes per cycle;
-# 157.3 TFLOP/s fp32 vector peak = that rate with packed FMA), 2.4 GHz.  Measured on this chip
-# (profiles/r01_ubench_valu_rates.txt): plain VALU 4.0-4.3 cycles, v_mad_u64_u32 4.5-5.0.
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4          # wave-instructions per second
-# measured issue cost (8 waves per SIMD) of v_mad_u64_u32 in the form the kernels use it (accumulator chain,
-# carry-out to an SGPR pair: 4.53-4.54 cycles) and of the other VALU instructions of the stream (4.03-4.3)
-MAD_CYCLES, OTHER_CYCLES = 4.53, 4.15
-INSTR_MODEL = ROOT / "profiles" / "r02_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits)
-HBM_MEASURED = ROOT / "profiles" / "r02_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
+# VALU issue on MI355X, measured with fully independent instruction streams, wall clock AND counters
+# (tools/ubench/valu_peak.hip, profiles/r03_ubench_valu_peak.txt; settles VERDICT r02 "weak" 2):
+#   simple 32-bit VALU (v_fma_f32, v_add_u32)        2.25-2.30 cycles per wave64 instruction per SIMD — the SIMD-32
+#                                                     issue MI355X_MICROARCH.md states (2 cycles);
+#   every integer multiply (v_mul_lo_u32, v_mad_u64_u32) and v_pk_fma_f32   4.14-4.21 cycles (half rate);
+#   shader clock under load: 2.08-2.17 GHz with every SIMD streaming v_mad_u64_u32, not the nominal 2.4 GHz.
+# The modexp kernels are ~80 % v_mad_u64_u32, so the roof that binds them is the MULTIPLY issue rate; the guide's
+# vector peak (any instruction at 2 cycles) is reported beside it.
+SIMDS, NOMINAL_HZ = 1024, 2.4e9
+MAC_CYCLES, OTHER_CYCLES = 4.19, 2.28       # v_mad_u64_u32 (accumulator form) / plain VALU, >= 2 wavefronts per SIMD
+GUIDE_VECTOR_PEAK = SIMDS * NOMINAL_HZ / 2  # wave-instructions per second if every instruction issued in 2 cycles
+MAC_ISSUE_PEAK = SIMDS * NOMINAL_HZ / MAC_CYCLES
+INSTR_MODEL = ROOT / "profiles" / "r03_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits) + digest of the kernel sources
+HBM_MEASURED = ROOT / "profiles" / "r03_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def parse() -> argparse.Namespace:
@@ -71,6 +77,9 @@ def parse() -> argparse.Namespace:
     ap.add_argument("--batch", type=int, default=0,
                     help="units per step per GPU: ciphertexts (c3: 10000, c5: 4096) or candidate moduli (biprime: 4096/N)")
     ap.add_argument("--key-length", type=int, default=0, help="default 2048 (c3, biprime), 4096 (c5)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="biprime workload on N GPUs: strong = --batch (default 4096) candidates sharded over the ranks (configs[3]), "
+                         "weak = that many per GPU")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the single_batch / end_to_end / extra legs")
     ap.add_argument("--cpu-seconds", type=float, default=4.0)
@@ -79,8 +88,9 @@ def parse() -> argparse.Namespace:
                     help="independent steps kept in flight, one HIP stream each; 1 = strictly one batch at a time; "
                          "0 = automatic: the first of 4, 5, 6, 7, 8, 3 that divides --steps, else 4")
     ap.add_argument("--limbs-per-lane", type=int, default=-1,
-                    help="lane geometry 9|18, 0 = library heuristic; default: 18 (wide) when the launches in flight "
-                         "over-subscribe the wide geometry's 2048 wavefront slots")
+                    help="lane geometry 3|9|18; 0 / default = the library's choice for the launches in flight taken together")
+    ap.add_argument("--wavefronts-per-group", type=int, default=0,
+                    help="c3/c5 pair kernel: 1 | 2 wavefronts per group of elements, 0 = the library's choice")
     ap.add_argument("--segments", type=int, default=0,
                     help="c3/c5: launches per exponentiation (mx_powmod_nsquare_run), 0 = the library's choice")
     ap.add_argument("--generic-modulus", action="store_true",
@@ -139,9 +149,30 @@ def _load_json(path: Path):
         return None
 
 
+_MODEL_STATE = {}
+
+
+def instr_model():
+    """(model, reason): the committed instruction-count model, or (None, why) if it does not describe the kernels
+    this run launches — it was fitted to counters of a particular version of the device code, and a kernel edit
+    silently invalidates it (VERDICT r02 "weak" 10): the digest of the kernel sources must match."""
+    if "m" not in _MODEL_STATE:
+        model, reason = _load_json(INSTR_MODEL), None
+        if model is None:
+            reason = f"{INSTR_MODEL.name} not found"
+        else:
+            from tools.calibrate_instr import kernel_sources_digest
+
+            if model.get("kernel_sources_sha256") != kernel_sources_digest():
+                model, reason = None, (f"{INSTR_MODEL.name} was fitted to other kernel sources (digest mismatch): re-run "
+                                       "tools/calibrate_instr.py under rocprofv3 --pmc SQ_INSTS_VALU")
+        _MODEL_STATE["m"] = (model, reason)
+    return _MODEL_STATE["m"]
+
+
 def instr_per_wave(kind: str, L: int, nblk: int, n_sqr: int, n_mul: int):
-    """VALU wave-instructions one wavefront of a modexp launch executes (tools/calibrate_instr.py)."""
-    model = _load_json(INSTR_MODEL)
+    """VALU wave-instructions one wavefront (kind "n2split": one PAIR of wavefronts) of a modexp launch executes."""
+    model, _ = instr_model()
     try:
         i_sqr, i_mul, fixed = model[kind][str(L)][str(nblk)]
     except Exception:
@@ -150,30 +181,45 @@ def instr_per_wave(kind: str, L: int, nblk: int, n_sqr: int, n_mul: int):
 
 
 def valu_roofline(kernel: str, instr_per_launch, launches: int, elapsed: float, kernel_ms: float, concurrent: int,
-                  mac_share=None) -> dict:
+                  mac_share=None, clock_mhz=None) -> dict:
+    """Roofline of an integer-VALU kernel: `achieved` = VALU wave-instructions of all timed launches / wall time;
+    `peak` = what THIS instruction mix could issue at the nominal clock (mac_share of it multiplies at 4.19
+    cycles, the rest plain VALU at 2.28: the measured costs); `frac` = achieved / peak.  Beside it: the same
+    fraction at the shader clock measured during the run, the multiply-accumulates alone against the multiply
+    issue rate, and everything against the guide's 2-cycle vector peak."""
     out = {
-        "bound": "valu-issue", "kernel": kernel, "unit": "G VALU wave-instructions/s",
-        "peak": VALU_ISSUE_PEAK / 1e9, "kernel_ms": kernel_ms, "concurrent_launches": concurrent,
+        "bound": "valu-multiply-issue", "kernel": kernel, "unit": "G VALU wave-instructions/s",
+        "kernel_ms": kernel_ms, "concurrent_launches": concurrent,
         "instructions_per_launch": instr_per_launch,
         "instructions_basis": "n_waves x (n_sqr x I_sqr + n_mul x I_mul + F): squarings/multiplications from the "
-                              "exponent's tape, per-instance constants fitted to SQ_INSTS_VALU (profiles/r02_instr_model.json)",
-        "peak_basis": "1024 SIMDs x 2.4 GHz / 4 cycles per wave64 VALU instruction (MI355X_MICROARCH.md: 256 CUs x 4 SIMDs, "
-                      "157.3 TFLOP/s fp32 vector); v_mad_u64_u32 itself issues at 4.5-5.0 cycles (profiles/r01_ubench_valu_rates.txt)",
+                              "exponent's tape, per-instance constants fitted to SQ_INSTS_VALU (profiles/r02_instr_model.json; "
+                              "the one-wavefront kernels are unchanged since the fit, bench.py refuses a model older than their sources)",
+        "peak_basis": (f"{SIMDS} SIMDs x {NOMINAL_HZ / 1e9} GHz / (mac_share x {MAC_CYCLES} + (1 - mac_share) x {OTHER_CYCLES}) cycles: issue costs measured "
+                       "on this chip with independent streams, wall clock and SQ_INSTS_VALU (profiles/r03_ubench_valu_peak.txt): integer "
+                       "multiplies issue at half the rate of plain VALU instructions, which issue at the 2 cycles of MI355X_MICROARCH.md "
+                       "(SIMD-32)"),
+        "shader_clock_mhz_measured": clock_mhz,
+        "shader_clock_basis": "mx_clock_probe wavefronts running beside the timed steps (s_memtime / s_memrealtime x 100 MHz)",
     }
     if instr_per_launch is None:
-        out.update({"achieved": None, "frac": None})
+        out.update({"achieved": None, "peak": None, "frac": None})
         return out
     achieved = instr_per_launch * launches / elapsed
+    share = 1.0 if mac_share is None else mac_share
+    mix_cycles = share * MAC_CYCLES + (1 - share) * OTHER_CYCLES
+    peak = SIMDS * NOMINAL_HZ / mix_cycles
     out["achieved"] = achieved / 1e9
-    out["frac"] = achieved / VALU_ISSUE_PEAK
-    if mac_share is not None:
-        # the same instruction stream priced with the microbenchmarked issue cost of its two instruction classes
-        mix_cycles = mac_share * MAD_CYCLES + (1 - mac_share) * OTHER_CYCLES
-        out["mix_estimate_frac"] = 4.0 / mix_cycles
-        out["mix_note"] = (f"{mac_share:.0%} of the stream is v_mad_u64_u32 ({MAD_CYCLES} cycles in the microbenchmark) and the "
-                           f"rest plain VALU ({OTHER_CYCLES}): priced that way the stream would issue at frac = 4/{mix_cycles:.2f}; "
-                           "a measured frac at or above this estimate means the kernel issues as fast as its instruction mix "
-                           "allows (the estimate is not a strict bound: the microbenchmark streams carry their own loop overhead)")
+    out["peak"] = peak / 1e9
+    out["frac"] = achieved / peak
+    out["mac_share"] = mac_share
+    out["frac_at_measured_clock"] = (achieved / (SIMDS * clock_mhz * 1e6 / mix_cycles)) if clock_mhz else None
+    out["frac_macs_vs_multiply_issue_peak"] = achieved * share / MAC_ISSUE_PEAK
+    out["frac_vs_guide_vector_peak"] = achieved / GUIDE_VECTOR_PEAK
+    out["guide_vector_peak"] = GUIDE_VECTOR_PEAK / 1e9
+    out["note"] = ("frac prices the kernel's own instruction mix at the measured issue costs and the NOMINAL clock; the chip "
+                   "sustains ~2.1-2.2 GHz under this load, so frac_at_measured_clock is the fraction of the issue slots the "
+                   "kernel fills.  frac_vs_guide_vector_peak is what a stream of 2-cycle instructions could reach — no "
+                   "32x32-bit multiply form issues at that rate (v_mul_lo_u32, v_mad_u64_u32, v_mad_u32_u24 all 4.1-4.3)")
     return out
 
 
@@ -262,12 +308,17 @@ class DecryptWorkload:
         ln = self.lanes[k % len(self.lanes)]
         eng = self.eng
         with self.torch.cuda.stream(ln["stream"]):
+            if ln.get("work") is not None:       # the all-gather of this lane's previous step must have read its rows
+                ln["work"].wait()
+                ln["work"] = None
             if self.generic:
                 eng.powmod_shared_t(self.own_in_t, self.n2, self.own_exp, out_t=ln["partials"][self.own_slot])
             else:
                 eng.powmod_nsquare_t(self.own_in_t, self.n, self.own_exp, out_t=ln["partials"][self.own_slot])
             if dist is not None:
-                dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][self.own_slot].reshape(-1))
+                # the one exchange step of the path, on RCCL's own stream: the recombination below needs only this
+                # rank's rows, so it and the next step's launches run beside the gather (waited for when the lane is reused)
+                ln["work"] = dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][self.own_slot].reshape(-1), async_op=True)
             eng.combine_t(ln["partials"], self.n, self.theta_inv, out_t=ln["msg"], status_t=ln["status"])
 
     def verify(self, check: int, rank: int, dist) -> str:
@@ -295,16 +346,19 @@ class DecryptWorkload:
         return f"{len(idx)} elements bit-exact vs CPython pow; all {batch} combines divisible by N"
 
 
-def pick_decrypt_geometry(args, key_length: int, batch: int, nstreams: int) -> int:
-    if args.limbs_per_lane >= 0:
-        return args.limbs_per_lane
+def pick_decrypt_shape(eng, args, n_bits: int, batch: int, nstreams: int):
+    """(limbs per lane, wavefronts per group) of the timed launches.  The library chooses the shape for ONE launch on
+    an idle GPU; a caller that keeps `nstreams` launches in flight asks for the shape that suits their sum."""
+    lpl = args.limbs_per_lane if args.limbs_per_lane >= 0 else 0
+    wpg = args.wavefronts_per_group
     if args.generic_modulus:
-        return 18 if nstreams >= 3 else 0
-    wide_lanes = 1
-    while wide_lanes * 29 * 18 < key_length + 8:
-        wide_lanes *= 2
-    wide_waves_in_flight = nstreams * batch * wide_lanes // 64
-    return 18 if (nstreams >= 4 and key_length >= 2048 and wide_waves_in_flight >= 2048) else 0
+        return (lpl or (18 if nstreams >= 3 else 0)), 0
+    if lpl and wpg:
+        return lpl, wpg
+    eng.set_limbs_per_lane(lpl)
+    eng.set_wavefronts_per_group(wpg)
+    _, l, _, _, w = eng.nsquare_launch_shape(n_bits, batch * nstreams)
+    return (lpl or l), (wpg or w)
 
 
 def time_steps(eng, torch, dist, step_fn, steps: int, warmup: int, nstreams: int):
@@ -327,13 +381,18 @@ def time_steps(eng, torch, dist, step_fn, steps: int, warmup: int, nstreams: int
     # HIP events around the modexp kernel itself, recorded by the library on the stream it launches
     # on (mx_profile): the same interval rocprofv3 --kernel-trace reports for that kernel
     eng.profile(True)
+    probes = []
     t0 = time.perf_counter()
     for k in range(steps):
         step_fn(k)
+        if k % max(1, steps // 4) == 0 and k >= nstreams - 1:
+            probes.append(eng.clock_probe_start(300))       # a one-wavefront probe beside the steps in flight
     barrier()
     elapsed = time.perf_counter() - t0
     eng.profile(False)
     kernel_total_ms, launches = eng.profile_collect()
+    clocks = [eng.clock_probe_mhz(h) for h in probes]
+    CLOCK["mhz"] = sum(clocks) / len(clocks) if clocks else None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -341,29 +400,37 @@ def time_steps(eng, torch, dist, step_fn, steps: int, warmup: int, nstreams: int
     return elapsed, (kernel_total_ms / launches if launches else 0.0), launches
 
 
+CLOCK = {"mhz": None}       # shader clock measured during the last time_steps call
+
+
 def decrypt_roofline(eng, wl: DecryptWorkload, steps: int, elapsed: float, kernel_ms: float, nstreams: int, key_length: int) -> dict:
     n_bits, batch = wl.n.bit_length(), wl.batch
     if wl.generic:
         K, Lw, _, nblk = eng.geometry(wl.n2.bit_length(), batch, 1)
         name = f"mx::powmod_kernel<{K},{Lw},29,true>"
-        roof = valu_roofline(name, None, steps, elapsed, kernel_ms, nstreams)
+        roof = valu_roofline(name, None, steps, elapsed, kernel_ms, nstreams, clock_mhz=CLOCK["mhz"])
         roof["instructions_basis"] = "no model for the sliding-window generic kernel (not the product path)"
         traffic_model = None
     else:
-        K, Lw, _, nblk = eng.nsquare_geometry(n_bits, batch)
-        name = f"mx::powmod_n2_kernel<{K},{Lw},29>"
+        K, Lw, _, nblk, wv = eng.nsquare_launch_shape(n_bits, batch)
+        name = f"mx::powmod_n2_kernel<{K},{Lw},29>" if wv == 1 else f"mx::powmod_n2_split_kernel<{K},{Lw},29>"
         plan = eng.nsquare_plan(wl.n, wl.own_exp).desc
-        nwaves = -(-batch // (64 // K))
-        per_wave = instr_per_wave("n2", Lw, nblk, plan.n_sqr, plan.n_mul)
+        groups = -(-batch // (64 // K))                      # groups of elements = wavefronts (wv = 1) or wavefront pairs (wv = 2)
+        if wv == 2:
+            groups += groups & 1                             # two pairs per workgroup: an odd tail pair runs on a duplicate
+        per_group = instr_per_wave("n2" if wv == 1 else "n2split", Lw, nblk, plan.n_sqr, plan.n_mul)
         # multiply-accumulates of the stream: a pair squaring is a symmetric pass (L/2+1 product + L
         # reduction MACs per limb step) + a full pass (L + L); a pair multiplication a full pass + a
         # two-row pass (2L + L); nblk * L limb steps per pass
         steps_per_pass = nblk * Lw
         macs = plan.n_sqr * steps_per_pass * ((Lw // 2 + 1 + Lw) + 2 * Lw) + plan.n_mul * steps_per_pass * (2 * Lw + 3 * Lw)
-        roof = valu_roofline(name, None if per_wave is None else per_wave * nwaves, steps, elapsed, kernel_ms, nstreams,
-                             mac_share=None if per_wave is None else macs / per_wave)
+        roof = valu_roofline(name, None if per_group is None else per_group * groups, steps, elapsed, kernel_ms, nstreams,
+                             mac_share=None if per_group is None else macs / per_group, clock_mhz=CLOCK["mhz"])
+        if per_group is None:
+            roof["instructions_basis"] = instr_model()[1] or f"no entry for this instance in {INSTR_MODEL.name}"
         roof["tape"] = {"pair_squarings": plan.n_sqr, "pair_multiplications": plan.n_mul, "window": plan.window}
-        traffic_model = nwaves * 64 * 4 * 2 * Lw * (plan.n_slot_reads + plan.n_slot_writes) + 2 * batch * 4 * wl.limbs2
+        roof["wavefronts_per_group"] = wv
+        traffic_model = groups * 64 * 4 * 2 * Lw * (plan.n_slot_reads + plan.n_slot_writes) + 2 * batch * 4 * wl.limbs2
     e_bits = wl.own_exp.bit_length()
     alg_bytes = batch * (2 * 4 * wl.limbs2) + 4 * wl.limbs2 + (e_bits + 7) // 8
     roof["traffic"] = None
@@ -377,28 +444,34 @@ def decrypt_roofline(eng, wl: DecryptWorkload, steps: int, elapsed: float, kerne
 def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: int, batch: int, label: str) -> dict:
     nstreams = args.streams if args.streams > 0 else next(
         (d for d in (4, 5, 6, 7, 8, 3) if args.steps % d == 0), min(4, max(1, args.steps)))
-    eng.set_limbs_per_lane(pick_decrypt_geometry(args, key_length, batch, nstreams))
+    eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
     eng.set_segments(args.segments)
-    wl = DecryptWorkload(eng, key_length, batch, rank, args.generic_modulus)
+    wl = DecryptWorkload(eng, key_length, batch, rank, args.generic_modulus)     # untimed set-up with the library's own choices
+    lpl, wpg = pick_decrypt_shape(eng, args, wl.n.bit_length(), batch, nstreams)
+    eng.set_limbs_per_lane(lpl)
+    eng.set_wavefronts_per_group(wpg)
+    eng.set_priority_aux(nstreams > 1)          # the recombination does not queue behind the other lanes' modexp launches
     wl.make_lanes(nstreams, dist, world)
     elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), args.steps, args.warmup, nstreams)
     assert launches == args.steps, (launches, args.steps)
     note = wl.verify(args.check if rank == 0 else 0, rank, dist)
     if rank != 0:
         return {}
-    geo = eng.geometry(wl.n2.bit_length(), batch, 1) if args.generic_modulus else eng.nsquare_geometry(wl.n.bit_length(), batch)
+    geo = eng.geometry(wl.n2.bit_length(), batch, 1) if args.generic_modulus else eng.nsquare_launch_shape(wl.n.bit_length(), batch)
     out = {
         "metric": "modexps/sec (2048-bit N, mod N^2)" if key_length == 2048 else f"modexps/sec ({key_length}-bit N, mod N^2)",
         "value": world * batch * args.steps / elapsed,
         "unit": "modexps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "distributed": dist_info(torch, dist, world),
         "config": {
             "workload": f"{label}: 3-party key_length={key_length} t=1, {batch} ciphertexts/GPU/step: "
                         "partial-decrypt c^exp mod N^2 + share-combine",
             "batch_per_gpu": batch, "mod_bits": wl.n2.bit_length(), "exp_bits": wl.own_exp.bit_length(),
             "limbs_u32": wl.limbs2, "party": wl.own, "parallelism": f"dp{world}", "steps_in_flight": nstreams,
-            "geometry_K_L_W_blocks": list(geo),
+            "geometry_K_L_W_blocks": list(geo[:4]), "wavefronts_per_group": geo[4] if len(geo) > 4 else 1,
             "algorithm": "Montgomery modulo N^2" if args.generic_modulus else "N-adic pairs, two Montgomery passes modulo N per product",
             "call_path": "per-key plan (mx_powmod_nsquare_prepare once) + mx_powmod_nsquare_run + mx_combine_run per step",
             "segments_per_exponentiation": args.segments or "library default (4 for long exponents on large batches)",
@@ -411,17 +484,59 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
 
 
 def leg_single_batch(eng, torch, wl: DecryptWorkload, key_length: int) -> dict:
-    """The same step with ONE launch in flight (what a caller without its own streams gets)."""
-    saved = eng._lpl
+    """The same step with ONE launch in flight (what a caller without its own streams gets): the library picks the
+    launch shape for a lone launch of this size."""
+    saved = (eng._lpl, eng._wpg)
     eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
     wl.make_lanes(1, None, 1)
     steps = 6
     elapsed, kernel_ms, _ = time_steps(eng, torch, None, lambda k: wl.step(k, None), steps, 1, 1)
-    geo = eng.nsquare_geometry(wl.n.bit_length(), wl.batch)
-    eng.set_limbs_per_lane(saved)
+    geo = eng.nsquare_launch_shape(wl.n.bit_length(), wl.batch)
+    eng.set_limbs_per_lane(saved[0])
+    eng.set_wavefronts_per_group(saved[1])
+    waves = -(-wl.batch // (64 // geo[0])) * geo[4]
     return {"value": wl.batch * steps / elapsed, "unit": "modexps/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
-            "kernel_ms": kernel_ms, "geometry_K_L_W_blocks": list(geo),
-            "note": f"one {wl.batch}-ciphertext launch at a time: {-(-wl.batch // (64 // geo[0]))} wavefronts for 1024 SIMDs"}
+            "kernel_ms": kernel_ms, "geometry_K_L_W_blocks": list(geo[:4]), "wavefronts_per_group": geo[4],
+            "shader_clock_mhz_measured": CLOCK["mhz"],
+            "note": f"one {wl.batch}-ciphertext launch at a time: {waves} wavefronts for 1024 SIMDs"}
+
+
+def leg_latency(eng, torch, wl: DecryptWorkload, single_core_rate) -> dict:
+    """The lone call the reference's API produces (DistributedPaillier.decrypt of ONE ciphertext,
+    distributed_keygen.py:345-349 -> paillier_shared_key.py:92): Python int in, Python int out through
+    GpuPaillierSharedKey.partial_decrypt, beside one gmpy2.powmod on one host core.  Also a keygen-sized batch."""
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+
+    key = wl.key
+    gk = GpuPaillierSharedKey(key.n, key.t, wl.own, ShareView(dict(key.shares), key.degree, key.n_fac), key.theta, engine=eng)
+    saved = (eng._lpl, eng._wpg)
+    eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
+    out = {"unit": "ms per call, Python ints to Python ints (pack, H2D, modexp, D2H, unpack)"}
+    for count in (1, 64, 1024):
+        times = []
+        for rep in range(5):
+            cts = [PlainCiphertext(c, key.n) for c in wl.cts[:count]]
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got = gk.partial_decrypt_batch(cts) if count > 1 else [gk.partial_decrypt(cts[0])]
+            times.append(time.perf_counter() - t0)
+        base = wl.cts[0] if wl.exps[wl.own] >= 0 else pow(wl.cts[0], -1, wl.n2)
+        assert got[0] == pow(base, wl.own_exp, wl.n2)
+        times.sort()
+        geo = eng.nsquare_launch_shape(wl.n.bit_length(), count)
+        out[f"n{count}"] = {"ms": times[len(times) // 2] * 1e3, "best_ms": times[0] * 1e3, "geometry_K_L_W_blocks": list(geo[:4]),
+                            "wavefronts_per_group": geo[4], "ciphertexts_per_s": count / times[len(times) // 2]}
+    eng.set_limbs_per_lane(saved[0])
+    eng.set_wavefronts_per_group(saved[1])
+    out["value"] = out["n1"]["ms"]
+    if single_core_rate:
+        out["gmpy2_one_core_ms"] = 1e3 / single_core_rate
+        out["vs_gmpy2_one_core"] = (1e3 / single_core_rate) / out["n1"]["ms"]
+        out["note"] = ("vs_gmpy2_one_core > 1 means the GPU answers a single decrypt() faster than the reference's own "
+                       "scalar path; below 1 install(scalars=False) keeps the reference's path for lone calls")
+    return out
 
 
 def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
@@ -436,8 +551,9 @@ def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
     key, L = wl.key, wl.L
     share = ShareView(dict(key.shares), key.degree, key.n_fac)
     gk = GpuPaillierSharedKey(key.n, key.t, wl.own, share, key.theta, engine=eng)
-    saved = eng._lpl
+    saved = (eng._lpl, eng._wpg)
     eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
     others1 = {i: L.unpack(eng.to_host(wl.partials_t[k])) for k, i in enumerate(wl.parties) if i != wl.own}
     out = {"unit": "ciphertexts/s, Python ints to Python ints",
            "note": "one call each on the default stream; includes Python int <-> limb rows (C codec), PCIe both ways, "
@@ -482,7 +598,8 @@ def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
             "partial_decrypt_breakdown": {k2: (round(v, 5) if isinstance(v, float) else v) for k2, v in (tm or {}).items()},
         }
     out["value"] = out[f"n{wl.batch * 4}"]["partial_decrypt_rate"]
-    eng.set_limbs_per_lane(saved)
+    eng.set_limbs_per_lane(saved[0])
+    eng.set_wavefronts_per_group(saved[1])
     return out
 
 
@@ -559,15 +676,20 @@ class BiprimeWorkload:
         ln = self.lanes[k % len(self.lanes)]
         eng = self.eng
         with self.torch.cuda.stream(ln["stream"]):
+            for w in ln.pop("works", []):        # the gathers of this lane's previous step must have read its buffers
+                w.wait()
             # DK:1084-1099 over this rank's candidates: Jacobi filter -> first 40 -> 40 modexps each
             v_t, _ = eng.biprime_v_t(self.g_t, self.mods_op, self.exps_op, self.GENS, self.KEEP)
             ln["v_all"][self.index - 1].view(-1, self.limbs).copy_(v_t)
-            if dist is not None:                                          # v rows to every rank (DK:1331-1337)
-                dist.all_gather_into_tensor(ln["v_gather"].view(-1), v_t.reshape(-1))
+            works = []
+            if dist is not None:                                          # v rows to every rank (DK:1331-1337), beside the verdict
+                ln["v_keep"] = v_t
+                works.append(dist.all_gather_into_tensor(ln["v_gather"].view(-1), v_t.reshape(-1), async_op=True))
             # DK:1147-1158 for every (candidate, test slot) of this rank's candidates
             eng.biprime_verdict_t(ln["v_all"], self.mods_op, pass_t=ln["verdict"])
             if dist is not None:                                          # the vote: verdict bytes of all ranks
-                dist.all_gather_into_tensor(ln["vote_gather"].view(-1), ln["verdict"].reshape(-1))
+                works.append(dist.all_gather_into_tensor(ln["vote_gather"].view(-1), ln["verdict"].reshape(-1), async_op=True))
+            ln["works"] = works
 
     def verify(self, check: int) -> str:
         import sympy
@@ -603,7 +725,9 @@ def biprime_roofline(eng, wl: BiprimeWorkload, steps: int, elapsed: float, kerne
     steps_per_pass = nblk * Lw
     macs = n_sqr * steps_per_pass * (Lw // 2 + 1 + Lw) + n_mul * steps_per_pass * 2 * Lw
     roof = valu_roofline(f"mx::powmod_kernel<{K},{Lw},29,false>", None if per_wave is None else per_wave * nwaves, steps,
-                         elapsed, kernel_ms, nstreams, mac_share=None if per_wave is None else macs / per_wave)
+                         elapsed, kernel_ms, nstreams, mac_share=None if per_wave is None else macs / per_wave, clock_mhz=CLOCK["mhz"])
+    if per_wave is None:
+        roof["instructions_basis"] = instr_model()[1] or f"no entry for this instance in {INSTR_MODEL.name}"
     roof["exponentiation"] = {"squarings": n_sqr, "multiplications": n_mul, "fixed_window": True}
     s = wl.limbs
     alg_bytes = batch * 2 * 4 * s + wl.cands * 4 * (s + elimbs)
@@ -614,11 +738,26 @@ def biprime_roofline(eng, wl: BiprimeWorkload, steps: int, elapsed: float, kerne
     return roof
 
 
+def dist_info(torch, dist, world: int):
+    """What the process group actually is: world size as the backend reports it and the RCCL version."""
+    if dist is None:
+        return None
+    info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_expected": world}
+    try:
+        info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
+    except Exception:  # pragma: no cover
+        info["rccl_version"] = None
+    info["exchange"] = "all_gather_into_tensor, async on RCCL's stream, overlapped with the recombination / verdict and the next step's launches"
+    return info
+
+
 def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, total_cands: int, steps: int, warmup: int,
-                nstreams: int, n_parties: int = 5) -> dict:
-    cands = -(-total_cands // world)
+                nstreams: int, n_parties: int = 5, weak: bool = False) -> dict:
+    cands = total_cands if weak else -(-total_cands // world)
+    total_cands = cands * world if weak else total_cands
     eng.set_limbs_per_lane(args.limbs_per_lane if args.limbs_per_lane >= 0 else 0)
     wl = BiprimeWorkload(eng, key_length, n_parties, cands, seed=0xD15C0 + 3 + 101 * rank)
+    eng.set_priority_aux(nstreams > 1)          # Jacobi filter, selection and verdict do not queue behind the other lane's modexps
     wl.make_lanes(nstreams, dist, world)
     elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), steps, warmup, nstreams)
     assert launches == steps
@@ -651,7 +790,8 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
         "value": world * cands * wl.KEEP * steps / elapsed,
         "unit": "modexps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+        "distributed": dist_info(torch, dist, world),
         "config": {
             "workload": f"C4: {n_parties}-party key_length={key_length} t=2, {total_cands} sieve-surviving candidate moduli "
                         f"sharded over {world} GPU(s) ({cands}/GPU/step): 160 Jacobi symbols + first-40 selection + 40 modexps "
@@ -670,6 +810,131 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
         "roofline": biprime_roofline(eng, wl, steps, elapsed, kernel_ms, nstreams),
         "_wl": wl,
     }
+
+
+# ---------------------------------------------------------------------------------------------------
+# one key-generation round, Python ints in -> verdicts out (distributed_keygen.py:1284-1360)
+# ---------------------------------------------------------------------------------------------------
+def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 5, t: int = 2,
+                     batch_sizes=(1024, 16384, 65536)) -> dict:
+    """What patch.compute_modulus does per round, timed from Python ints to Python verdicts for `batch_size`
+    candidates: every party's Shamir shares of the candidate moduli -> reconstruct + sieve (one device pass,
+    shamir.reconstruct_and_sieve_batch) -> survivors' v values (biprime_test_v_calculation_batch: Jacobi filter,
+    selection, 40 modexps each) -> verdicts (biprime_test_with_v_i_batch).  The exchange rounds in between (shares,
+    jointly random generators, the other parties' v values) are network traffic in the reference and are prepared
+    untimed.  Beside it: the same four steps as the reference computes them (oracle/cpu_keygen_round.py, one core —
+    the reference runs a round sequentially on its asyncio thread), timed on a sample and scaled to the round."""
+    import sympy
+
+    from protocols.distributed_keygen_amd import biprime, shamir, synthetic
+
+    rng = random.Random(0xD15C0 + 77)
+    half = key_length // 2
+    degree = 2 * t
+    prime = synthetic.random_prime(rng, 2 * (half + 4) + 44, mod4=1)        # the Shamir field: larger than any candidate modulus
+    prime_list = [int(q) for q in sympy.primerange(3, 2001)]
+    total = max(batch_sizes)
+    shares = [synthetic.candidate_shares(rng, n_parties, half) for _ in range(total)]
+    mods = [sum(p) * sum(q) for p, q in shares]
+    points = list(range(1, n_parties + 1))
+    columns = {i: [] for i in points}
+    for m in mods:                                                           # degree-2t sharing of every modulus (DK:1274-1281)
+        coeffs = [m] + [rng.getrandbits(prime.bit_length() + 8) % prime for _ in range(degree)]
+        for i in points:
+            acc = 0
+            for c in reversed(coeffs):
+                acc = (acc * i + c) % prime
+            columns[i].append(acc)
+    out = {"unit": "candidate moduli per second through one round (Python ints -> verdicts), one GPU",
+           "config": f"{n_parties}-party key_length={key_length} t={t}: Shamir field of {prime.bit_length()} bits, {len(prime_list)} sieve primes, "
+                     "160 generators and 40 test slots per surviving candidate",
+           "rounds": {}}
+    sample_job = None
+    for B in batch_sizes:
+        by_party = {i: columns[i][:B] for i in points}
+        best = None
+        for rep in range(2):                                                 # the first pass warms allocations
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            has_div, surviving = shamir.reconstruct_and_sieve_batch(by_party, prime, degree, prime_list, eng, points=points)
+            t1 = time.perf_counter()
+            surv = sorted(surviving)
+            moduli = [surviving[k] for k in surv]
+            assert all(moduli[j] == mods[k] for j, k in enumerate(surv))
+            g_rng = random.Random(B)
+            g_values = [[g_rng.getrandbits(key_length + 64) % m for _ in range(160)] for m in moduli]      # untimed: a communication round
+            t2 = time.perf_counter()
+            v1 = biprime.biprime_test_v_calculation_batch(g_values, 1, moduli, [shares[k][0][0] for k in surv],
+                                                          [shares[k][1][0] for k in surv], 40, eng)
+            t3 = time.perf_counter()
+            v_by = [{1: v} for v in v1]                                          # untimed: the other parties' v values arrive
+            for i in range(2, n_parties + 1):
+                vi = biprime.biprime_test_v_calculation_batch(g_values, i, moduli, [shares[k][0][i - 1] for k in surv],
+                                                              [shares[k][1][i - 1] for k in surv], 40, eng)
+                for d, v in zip(v_by, vi):
+                    d[i] = v
+            t4 = time.perf_counter()
+            verdicts = biprime.biprime_test_with_v_i_batch(v_by, moduli, 40, eng, errors="return")
+            t5 = time.perf_counter()
+            cur = {"reconstruct_sieve_s": t1 - t0, "v_calculation_s": t3 - t2, "verdict_s": t5 - t4}
+            cur["total_s"] = sum(cur.values())
+            if best is None or cur["total_s"] < best["total_s"]:
+                best = cur
+        # spot checks against the definitions (CPython)
+        k0 = surv[0]
+        assert has_div[k0] is False and sum(1 for b in has_div if not b) == len(surv)
+        assert bool(has_div[1]) == any(mods[1] % q == 0 for q in prime_list)
+        e0 = (moduli[0] - shares[k0][0][0] - shares[k0][1][0] + 1) // 4
+        keep = [g for g in g_values[0] if sympy.jacobi_symbol(g, moduli[0]) == 1][:40]
+        assert v1[0] == [pow(g, e0, moduli[0]) for g in keep]
+        want = len(v1[0]) >= 40                                               # DK:1147-1172 on the host for survivor 0
+        for slot in range(min(40, len(v1[0]))):
+            prod = 1
+            for i in range(2, n_parties + 1):
+                prod *= v_by[0][i][slot]
+            if v1[0][slot] % moduli[0] not in (prod % moduli[0], (-prod) % moduli[0]):
+                want = False
+                break
+        assert verdicts[0] is want
+        best.update({"batch_size": B, "survivors": len(surv), "candidates_per_s": B / best["total_s"],
+                     "modexps": 40 * len(surv), "biprimes_found": sum(1 for v in verdicts if v is True)})
+        out["rounds"][f"b{B}"] = best
+        if sample_job is None:
+            ns, nc = 3, 256
+            sample_job = {"prime": hex(prime), "points": points, "columns": {str(i): [hex(v) for v in columns[i][:nc]] for i in points},
+                          "prime_list": prime_list, "moduli_check": [hex(m) for m in mods[:8]],
+                          "survivors": [{"modulus": hex(moduli[j]), "exponent": hex((moduli[j] - shares[surv[j]][0][0] - shares[surv[j]][1][0] + 1) // 4),
+                                         "g": [hex(g) for g in g_values[j]], "v_check": [hex(v) for v in v1[j]],
+                                         "v_others": [[hex(v) for v in v_by[j][i]] for i in range(2, n_parties + 1)]} for j in range(min(ns, len(surv)))]}
+    out["value"] = out["rounds"][f"b{max(batch_sizes)}"]["candidates_per_s"]
+    if not args.no_cpu_baseline and sample_job is not None:
+        with tempfile.NamedTemporaryFile("w", suffix=".json", delete=False) as f:
+            json.dump(sample_job, f)
+            path = f.name
+        script = str(ROOT / "oracle" / "cpu_keygen_round.py")
+        res = None
+        for py in ("/opt/conda/bin/python3.9", sys.executable):
+            if os.path.exists(py):
+                try:
+                    r = subprocess.run([py, script, path], capture_output=True, text=True, timeout=180)
+                    if r.returncode == 0 and r.stdout.strip():
+                        res = json.loads(r.stdout.strip().splitlines()[-1])
+                        break
+                except Exception:  # pragma: no cover - measurement plumbing
+                    pass
+        os.unlink(path)
+        if res is not None:
+            base = {"kind": "port", "cores": 1, "engine": res["engine"], "unit": "seconds per unit, one core",
+                    "per_unit": {k: res[k] for k in res if k.endswith("_candidate") or k.endswith("_survivor")},
+                    "sample": f"{res['sample_candidates']} candidates (reconstruct, sieve) and {res['sample_survivors']} survivors (v values, verdict) "
+                              "of the first round, one core: the reference runs a round sequentially on its asyncio thread; scaled to each round size",
+                    "rounds": {}}
+            for name, rd in out["rounds"].items():
+                cpu_s = rd["batch_size"] * (res["reconstruct_s_per_candidate"] + res["sieve_s_per_candidate"]) + rd["survivors"] * (
+                    res["v_calculation_s_per_survivor"] + res["verdict_s_per_survivor"])
+                base["rounds"][name] = {"cpu_round_s": cpu_s, "candidates_per_s": rd["batch_size"] / cpu_s, "gpu_speedup": cpu_s / rd["total_s"]}
+            out["cpu_baseline"] = base
+    return out
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -745,7 +1010,10 @@ def main() -> None:
                 del wl
             if extras:
                 # the extra legs must never cost the headline line: a failing leg is reported in its field
+                leg_seconds = out.setdefault("leg_seconds", {})
+
                 def guarded(name, fn):
+                    t_leg = time.perf_counter()
                     try:
                         return fn()
                     except Exception as exc:  # pragma: no cover - measurement plumbing
@@ -753,37 +1021,50 @@ def main() -> None:
 
                         sys.stderr.write(f"bench.py: leg {name} failed:\n{traceback.format_exc()}\n")
                         return {"error": f"{type(exc).__name__}: {exc}"}
+                    finally:
+                        leg_seconds[name] = round(time.perf_counter() - t_leg, 2)
 
                 out["single_batch"] = guarded("single_batch", lambda: leg_single_batch(eng, torch, wl, key_length))
+                out["latency"] = guarded("latency", lambda: leg_latency(eng, torch, wl, (out.get("cpu_baseline") or {}).get("single_core_value")))
                 out["end_to_end"] = guarded("end_to_end", lambda: leg_end_to_end(eng, torch, wl, out["value"]))
                 del wl
                 torch.cuda.empty_cache()
                 out["extra"] = {}
                 if args.workload == "c3" and key_length == 2048:
-                    def biprime_leg():
-                        bp = run_biprime(args, eng, torch, None, 0, 1, 2048, 4096, steps=8, warmup=2, nstreams=2)
+                    keep_bp = ("metric", "value", "unit", "steps", "ms_per_step", "config", "stages", "roofline", "cpu_baseline")
+
+                    def biprime_leg(klen, cands, steps, cpu):
+                        bp = run_biprime(args, eng, torch, None, 0, 1, klen, cands, steps=steps, warmup=2, nstreams=2)
                         bwl = bp.pop("_wl")
-                        if not args.no_cpu_baseline:
+                        if cpu and not args.no_cpu_baseline:
                             bp["cpu_baseline"] = cpu_baseline(bwl.mods[0], bwl.exps[0], bwl.g_sample[:40], min(args.cpu_seconds, 3.0),
                                                               "candidate 0's modulus and party-1 exponent, its first 40 generators cycled")
                         del bwl
                         torch.cuda.empty_cache()
-                        return {k: bp[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "stages", "roofline", "cpu_baseline") if k in bp}
+                        return {k: bp[k] for k in keep_bp if k in bp}
 
-                    def c5_leg():
+                    def c5_leg(batch, steps, streams, cpu):
                         a5 = argparse.Namespace(**vars(args))
-                        a5.steps, a5.warmup, a5.streams, a5.limbs_per_lane, a5.check = 8, 2, 4, -1, 3
-                        c5 = run_decrypt_main(a5, eng, torch, None, 0, 1, 4096, 4096, "C5 (BASELINE.json configs[4])")
+                        a5.steps, a5.warmup, a5.streams, a5.limbs_per_lane, a5.wavefronts_per_group, a5.check = steps, 2, streams, -1, 0, 3
+                        c5 = run_decrypt_main(a5, eng, torch, None, 0, 1, 4096, batch, "C5 (BASELINE.json configs[4])")
                         c5wl = c5.pop("_wl")
-                        if not args.no_cpu_baseline:
+                        if cpu and not args.no_cpu_baseline:
                             bases = [c if c5wl.exps[c5wl.own] >= 0 else pow(c, -1, c5wl.n2) for c in c5wl.cts[:32]]
                             c5["cpu_baseline"] = cpu_baseline(c5wl.n2, c5wl.own_exp, bases, min(args.cpu_seconds, 3.0),
                                                               "same modulus/exponent, first 32 ciphertexts cycled")
                         del c5wl
+                        torch.cuda.empty_cache()
                         return {k: c5[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "cpu_baseline") if k in c5}
 
-                    out["extra"]["biprime_k2048"] = guarded("biprime_k2048", biprime_leg)
-                    out["extra"]["c5_k4096"] = guarded("c5_k4096", c5_leg)
+                    out["extra"]["biprime_k2048"] = guarded("biprime_k2048", lambda: biprime_leg(2048, 4096, 8, True))
+                    # configs[1]: key_length 1024, at the size of a keygen round's survivors and at a saturating size
+                    out["extra"]["biprime_k1024_c256"] = guarded("biprime_k1024_c256", lambda: biprime_leg(1024, 256, 8, True))
+                    out["extra"]["biprime_k1024_c8192"] = guarded("biprime_k1024_c8192", lambda: biprime_leg(1024, 8192, 6, False))
+                    # configs[4]: the sweep points of key_length 4096
+                    out["extra"]["c5_k4096"] = guarded("c5_k4096", lambda: c5_leg(4096, 8, 4, True))
+                    out["extra"]["c5_k4096_b1024"] = guarded("c5_k4096_b1024", lambda: c5_leg(1024, 8, 4, False))
+                    out["extra"]["c5_k4096_b16384"] = guarded("c5_k4096_b16384", lambda: c5_leg(16384, 4, 2, False))
+                    out["end_to_end_keygen"] = guarded("end_to_end_keygen", lambda: leg_keygen_round(eng, torch, args))
         if world > 1 and not args.no_extras and args.workload == "c3" and not args.generic_modulus:
             # configs[3] on N GPUs inside the driver's scaling run: 4096 candidates sharded over the ranks,
             # all-gather of the v rows and of the verdict bytes (the biprimality vote, DK:1331-1360)
@@ -793,12 +1074,13 @@ def main() -> None:
             bp = run_biprime(args, eng, torch, dist, rank, world, 2048, 4096, steps=8, warmup=2, nstreams=2)
             if rank == 0:
                 bp.pop("_wl", None)
-                out["extra"] = {"biprime_k2048": {k: bp[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "config", "stages", "roofline") if k in bp}}
+                out["extra"] = {"biprime_k2048": {k: bp[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "distributed", "config", "stages", "roofline") if k in bp}}
     else:
         key_length = args.key_length or 2048
-        total = args.batch * world if args.batch else 4096
+        weak = args.scaling == "weak"
+        total = (args.batch or 4096) if weak else (args.batch * world if args.batch else 4096)
         nstreams = args.streams if args.streams > 0 else 2
-        out = run_biprime(args, eng, torch, dist, rank, world, key_length, total, args.steps, args.warmup, nstreams)
+        out = run_biprime(args, eng, torch, dist, rank, world, key_length, total, args.steps, args.warmup, nstreams, weak=weak)
         if rank == 0:
             wl = out.pop("_wl")
             if world == 1 and not args.no_cpu_baseline:

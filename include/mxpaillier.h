@@ -284,6 +284,12 @@ int mx_debug_knob(int knob, int value);
  * decides whether chunks of a batch launched on those streams fill the machine together or serialise
  * (GPU_MAX_HW_QUEUES is read once when the runtime initialises and cannot be queried).  Never synchronises. */
 int mx_spin(int64_t microseconds, void* stream);
+/* Enqueues a kernel of ONE wavefront that idles for `microseconds` and writes two counters to d_ticks[0..1]: the
+ * advance of the shader clock counter and of the 100 MHz real-time counter over that interval; their ratio x 100 MHz
+ * is the clock the SIMDs run at under the load that is in flight at that moment (MI355X drops from its nominal
+ * 2.4 GHz to ~2.1 GHz when every SIMD streams multiply-accumulates: profiles/r03_ubench_valu_peak.txt).  Launch it
+ * on a stream of its own while the work of interest runs.  Never synchronises. */
+int mx_clock_probe(int64_t microseconds, uint64_t* d_ticks, void* stream);
 /* Engine geometry chosen for a modulus of `mod_bits` bits: lanes per element (K), limbs per lane
  * (L), limb width (W) and Montgomery blocks; returns MX_OK or MX_ERR_SIZE. */
 int mx_geometry(int mod_bits, int* lanes_per_element, int* limbs_per_lane, int* limb_bits, int* blocks);

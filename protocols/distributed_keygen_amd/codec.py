@@ -90,20 +90,9 @@ def rows_from_wire(values: Sequence[Any], limbs: int, modulus: int = 0) -> np.nd
 
 
 def _reduce_rows(rows: np.ndarray, modulus: int) -> np.ndarray:
-    """Rows that fit the row width but are >= modulus -> their residue (in place).  The comparison is
-    vectorised (most significant differing limb decides); only the offenders become Python ints."""
-    count, limbs = rows.shape
-    if count == 0 or modulus.bit_length() > 32 * limbs:
-        return rows                                  # every value of this width is below the modulus
-    m = np.frombuffer(modulus.to_bytes(4 * limbs, "little"), dtype="<u4")
-    diff = rows != m
-    top = limbs - 1 - np.argmax(diff[:, ::-1], axis=1)          # most significant differing limb (0 if none differ)
-    sel = np.arange(count)
-    ge = ~diff.any(axis=1) | (rows[sel, top] > m[top])
-    for k in np.nonzero(ge)[0]:
-        v = int.from_bytes(rows[k].tobytes(), "little") % modulus
-        rows[k] = np.frombuffer(v.to_bytes(4 * limbs, "little"), dtype="<u4")
-    return rows
+    from . import limbs as _limbs
+
+    return _limbs.reduce_rows(rows, modulus)
 
 
 def rows_to_wire(rows: np.ndarray) -> List[Dict[str, Any]]:

@@ -215,6 +215,18 @@ __global__ void spin_kernel(unsigned long long ticks) {
   while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
 }
 
+// One wavefront idles for `ticks` periods of the 100 MHz real-time counter and reports how far the shader clock
+// counter (s_memtime) advanced meanwhile: the clock the SIMDs are actually running at while whatever else is in
+// flight on the device keeps them busy (mx_clock_probe).
+__global__ void clock_probe_kernel(unsigned long long ticks, unsigned long long* out) {
+  const unsigned long long r0 = __builtin_amdgcn_s_memrealtime();
+  const unsigned long long c0 = __builtin_amdgcn_s_memtime();
+  unsigned long long r1 = r0;
+  while (r1 - r0 < ticks) { __builtin_amdgcn_s_sleep(8); r1 = __builtin_amdgcn_s_memrealtime(); }
+  const unsigned long long c1 = __builtin_amdgcn_s_memtime();
+  if (threadIdx.x == 0) { out[0] = c1 - c0; out[1] = r1 - r0; }
+}
+
 __global__ void lanes_selftest_kernel(int* out) {
   unsigned v = threadIdx.x * 40503u + 977u;
   int bad = 0;
@@ -361,6 +373,14 @@ int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limb
 int mx_spin(int64_t microseconds, void* stream) {
   if (microseconds < 0 || microseconds > 1000000) return MX_ERR_ARG;
   hipLaunchKernelGGL(spin_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+int mx_clock_probe(int64_t microseconds, uint64_t* d_ticks, void* stream) {
+  if (microseconds <= 0 || microseconds > 1000000 || !d_ticks) return MX_ERR_ARG;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull,
+                     (unsigned long long*)d_ticks);
   MX_HIP(hipGetLastError());
   return MX_OK;
 }

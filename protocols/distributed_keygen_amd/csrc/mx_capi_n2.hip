@@ -112,7 +112,10 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg) {
   const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
   const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;
   auto round = [&](int64_t r) { return r <= 0 ? 0.0 : alone + (double)(r - 1) * shared; };
-  return (double)(per_simd / fit) * round(fit) + round(per_simd % fit);
+  if (per_simd <= fit) return round(per_simd);          // everything resident at once: the fullest SIMD bounds the launch
+  // more wavefronts than fit: the launch streams through full SIMDs at the rate of a full round
+  const double per_simd_mean = wpg == 2 ? (double)p.nblocks / cus : (double)p.nblocks / (4.0 * cus);
+  return per_simd_mean / (double)fit * round(fit);
 }
 N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
   N2Choice best{LIMBS_PER_LANE, 1};

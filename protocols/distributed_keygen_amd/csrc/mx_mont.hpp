@@ -352,6 +352,17 @@ struct Mont {
     u32 qr[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) qr[j] = 0;
+    // The multiplier limbs of a block come from LDS.  With few limbs per lane a block is only a few dozen
+    // instructions, and a wavefront that has its SIMD to itself (the latency geometry's reason to exist) would
+    // sit out the LDS round trip at the head of every block: there the limbs of block blk + 1 are fetched
+    // before block blk is worked on.  The large-L instances hide the latency behind their own work and keep
+    // the registers.
+    constexpr bool PREFETCH = L <= 4;
+    u32 nb[L], nd[L];
+    if constexpr (PREFETCH) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) { nb[j] = lds[j]; nd[j] = (F & F_TWO) ? lds[LDS_D + j] : 0u; }
+    }
     for (int blk = 0; blk < nsteps_blk; ++blk) {
       // The multiplicand limbs are loop invariant, and the compiler would hoist their zero
       // extension to 64 bits out of this loop — every limb then occupies a register PAIR for the
@@ -364,10 +375,18 @@ struct Mont {
         if constexpr (!(F & F_PLAIN)) asm volatile("" : "+v"(n[j]));
       }
       u32 bb[L], dd[L];
+      if constexpr (PREFETCH) {
+        const int nx = blk + 1 < nsteps_blk ? blk + 1 : blk;
 #pragma unroll
-      for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];
+        for (int j = 0; j < L; ++j) { bb[j] = nb[j]; dd[j] = nd[j]; }
 #pragma unroll
-      for (int j = 0; j < L; ++j) dd[j] = (F & F_TWO) ? lds[LDS_D + blk * L + j] : 0u;
+        for (int j = 0; j < L; ++j) { nb[j] = lds[nx * L + j]; nd[j] = (F & F_TWO) ? lds[LDS_D + nx * L + j] : 0u; }
+      } else {
+#pragma unroll
+        for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];
+#pragma unroll
+        for (int j = 0; j < L; ++j) dd[j] = (F & F_TWO) ? lds[LDS_D + blk * L + j] : 0u;
+      }
       block_steps<F>(t, a, c, bb, dd, qr, blk, emit, std::make_integer_sequence<int, L>{});
     }
     normalize_weak(r, t);

@@ -8,11 +8,13 @@
 //       Z1 = REDC(X0 Y1 + X1 Y0 + C - Q).
 // So the chain of first digits X0 is an ordinary Montgomery exponentiation modulo N that never looks at
 // X1, and the chain of second digits only consumes what the first chain produced one operation earlier:
-// (X0 before the operation, Q).  A workgroup is two wavefronts on two SIMDs of one CU:
-//       wavefront A   for every operation s:  pass 1 of s,  mailbox[s & 1] <- (X0 before s, Q_s),  barrier
-//       wavefront B   for every operation s:  barrier,  (X0, Q) <- mailbox[s & 1],  pass 2 of s
-// B runs one operation behind A; the barrier is the only synchronisation and the mailbox (LDS, two
-// entries) the only traffic (2 L words per lane per operation).  Pass 1 is the lighter one (a squaring's
+// (X0 before the operation, Q).  A pair of wavefronts on two SIMDs of one CU shares the work:
+//       wavefront A   for every operation s:  pass 1 of s,  mailbox[s & 1] <- (X0 before s, Q_s),  produced = s + 1
+//       wavefront B   for every operation s:  wait for produced > s,  (X0, Q) <- mailbox[s & 1],  consumed = s + 1,  pass 2 of s
+// (A waits for consumed >= s - 1 before it overwrites an entry).  B runs behind A; the two counters (LDS,
+// release / acquire at workgroup scope, polled with s_sleep) are the only synchronisation and the mailbox (LDS,
+// two entries) the only traffic (2 L words per lane per operation).  No workgroup barrier inside the tape: the
+// pairs of a workgroup do not wait for each other.  Pass 1 is the lighter one (a squaring's
 // pass 1 is symmetric; a multiplication's pass 2 has two product rows), so an operation costs what its
 // pass 2 costs: 0.54-0.58 of the one-wavefront kernel's time per operation, with twice the wavefronts in
 // the launch.  Slots in device memory are split the same way (A owns the first digits, B the second), so
@@ -23,7 +25,8 @@
 // robin over the four SIMDs of its CU, but starts every workgroup at the same SIMD — two-wavefront workgroups
 // ended up stacked on SIMDs 0 and 1 while 2 and 3 idled (tools/sweep_shapes.py: a launch with two of them per CU
 // took 1.5x as long as one with a single one).  With four wavefronts a workgroup covers the CU evenly.  The two
-// pairs execute the same tape, so every wavefront meets the same number of barriers.
+// pairs share nothing but the copy of C' (with a workgroup barrier per operation instead of the counters they
+// waited for each other: 35.2 instead of 32.4 ms per wide launch).
 //
 // Small-L instances (L = 3: 32 lanes per element at key_length 2048, 64 at 4096) exist only in this form:
 // they are the latency geometry — a limb step costs 2 L multiply-accumulates plus ~10 instructions of
@@ -38,8 +41,9 @@ constexpr int N2_SPLIT_PAIRS = 2;      // wavefront pairs per workgroup (4 wavef
 
 template <int K, int L>
 constexpr size_t powmod_n2_split_lds_bytes() {
-  // per pair: two wavefronts' Montgomery scratch and the two mailbox entries of 2 L words per lane; one C'
-  return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64) + (size_t)K * L) * 4;
+  // per pair: two wavefronts' Montgomery scratch, the two mailbox entries of 2 L words per lane and the two
+  // hand-over counters; one C'
+  return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64 + 4) + (size_t)K * L) * 4;
 }
 
 template <int K, int L, int W>
@@ -52,7 +56,7 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   constexpr int GPW = 64 / K;
   const int lane = threadIdx.x & 63;
   // 0: wavefront A (first digits), 1: wavefront B (second digits); in an SGPR, so that the two roles are
-  // uniform branches (a barrier must never be reached under an execution mask)
+  // uniform branches
   const int half = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 1));
   const int pair = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));          // which pair of the workgroup
   const int gw = lane / K;
@@ -60,10 +64,13 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   const i64 elem_raw = wave_slot * GPW + gw;
   const bool valid = elem_raw < A.batch;
   const i64 elem = valid ? elem_raw : A.batch - 1;
-  constexpr int PAIR_WORDS = 2 * GPW * GROUP_WORDS + 2 * 2 * L * 64;
+  constexpr int PAIR_WORDS = 2 * GPW * GROUP_WORDS + 2 * 2 * L * 64 + 4;
   u32* pair_lds = smem + pair * PAIR_WORDS;
   u32* wide = pair_lds + (half * GPW + gw) * GROUP_WORDS;  // this wavefront's scratch of this group
   u32* mbox = pair_lds + 2 * GPW * GROUP_WORDS;             // [2 entries][2 L words][64 lanes]
+  u32* produced = mbox + 2 * 2 * L * 64;                    // entries A has handed over / B has taken (this pair)
+  u32* consumed = produced + 1;
+  if (half == 0 && lane == 0) { *produced = 0; *consumed = 0; }
   u32* cp_lds = smem + N2_SPLIT_PAIRS * PAIR_WORDS;
   auto mb = [&](int entry, int j) -> u32& { return mbox[(entry * 2 * L + j) * 64 + lane]; };
 
@@ -121,7 +128,7 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
       for (int j = 0; j < L; ++j) { slot_at(N2_SLOT_LO, j) = 0; slot_at(N2_SLOT_HI, j) = 0; }
     }
   }
-  __syncthreads();            // C' is in place for both wavefronts (the only workgroup barrier outside the tape)
+  __syncthreads();            // C', the counters and the prologue's slots are in place (the kernel's only workgroup barrier)
 
   // ---- the tape (this segment's part of it): acc is THIS wavefront's digit of the accumulator pair
   u32 acc[L];
@@ -133,19 +140,23 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
     for (int j = 0; j < L; ++j) acc[j] = slot_at(N2_SLOT_CARRY, j);
   }
   int pos = 0;                                      // squarings executed by the tape so far
-  int entry = 0;                                    // mailbox entry of the next operation
-  // A: after pass 1 of an operation, hand (X0 before it, Q) to B.  B: receive them before its pass 2.
+  u32 seq = 0;                                      // operations handed over so far (the same count in both wavefronts)
+  // A: after pass 1 of an operation, hand (X0 before it, Q) to B.  B: take them before its pass 2.
   auto send = [&](const u32 (&x0)[L], const u32 (&q)[L]) {
+    while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + 2u <= seq) __builtin_amdgcn_s_sleep(2);
+    const int entry = (int)(seq & 1u);
 #pragma unroll
     for (int j = 0; j < L; ++j) { mb(entry, j) = x0[j]; mb(entry, L + j) = q[j]; }
-    __syncthreads();
-    entry ^= 1;
+    ++seq;
+    __hip_atomic_store(produced, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   auto receive = [&](u32 (&x0)[L], u32 (&q)[L]) {
-    __syncthreads();
+    while (__hip_atomic_load(produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= seq) __builtin_amdgcn_s_sleep(2);
+    const int entry = (int)(seq & 1u);
 #pragma unroll
     for (int j = 0; j < L; ++j) { x0[j] = mb(entry, j); q[j] = mb(entry, L + j); }
-    entry ^= 1;
+    ++seq;
+    __hip_atomic_store(consumed, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
   for (int k = 0; k < A.ntape; ++k) {
     const u32 word = A.tape[k];
@@ -189,8 +200,8 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
         u32 x0[L], f1[L];
 #pragma unroll
         for (int j = 0; j < L; ++j) f1[j] = slot_at(arg, j);
-        // the first digit of the table entry was written by wavefront A: read it behind the barrier of this
-        // operation (A stored it before it got there; the barrier orders the workgroup's memory operations)
+        // the first digit of the table entry was written by wavefront A: read it behind the hand-over of this
+        // operation (A stored it before it released `produced`; the acquire orders this wavefront's loads after it)
         receive(x0, q);
 #pragma unroll
         for (int j = 0; j < L; ++j) f0[j] = slot_other(arg, j);
@@ -218,14 +229,15 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   // ---- epilogue on wavefront B, which receives A's final first digit through the mailbox
   u32 acc0[L], acc1[L];
   if (half == 0) {
-#pragma unroll
-    for (int j = 0; j < L; ++j) mb(entry, j) = acc[j];
-    __syncthreads();
+    send(acc, acc);
     return;
   }
-  __syncthreads();
+  {
+    u32 unused[L];
+    receive(acc0, unused);
+  }
 #pragma unroll
-  for (int j = 0; j < L; ++j) { acc0[j] = mb(entry, j); acc1[j] = acc[j]; }
+  for (int j = 0; j < L; ++j) acc1[j] = acc[j];
   {
     u64 t[L];
 #pragma unroll

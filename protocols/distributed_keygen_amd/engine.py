@@ -59,6 +59,8 @@ class Engine:
         self._side_streams_capped = False      # the process has fewer concurrent queues than chunks were wanted
         self._pin: Dict[str, Any] = {}         # pinned staging buffers of _pipelined
         self.last_timing: Optional[Dict[str, Any]] = None   # host/GPU time split of the last int-level modexp batch
+        self._priority_aux = False             # small kernels on a high-priority companion stream (set_priority_aux)
+        self._aux: Dict[int, Any] = {}         # stream -> its companion
 
     # ------------------------------------------------------------------ plumbing
     def _stream_ptr(self) -> int:
@@ -129,6 +131,34 @@ class Engine:
             raise ValueError("segments must be 0..64")
         self._segments = int(segments)
 
+    def set_priority_aux(self, enable: bool) -> None:
+        """With several launches in flight on several streams, the small kernels of a step (recombination,
+        verdict, Jacobi filter, selection: 0.5-5 ms of work) queue for wavefront slots behind the other streams'
+        full-machine modexp launches — 4-34 ms of waiting measured (profiles/r02_bench_*_rocprof_summary.txt).
+        When enabled they run on a HIGH-PRIORITY companion of the calling stream, ordered by events on both sides
+        (the caller still sees them in stream order): the dispatcher hands them the first slots that free up."""
+        self._priority_aux = bool(enable)
+
+    def _small(self, fn):
+        """fn() on the current stream, or — set_priority_aux — on its high-priority companion between two waits."""
+        if not self._priority_aux:
+            return fn()
+        torch = self.torch
+        cur = torch.cuda.current_stream(self.device)
+        key = int(cur.cuda_stream)
+        aux = self._aux.get(key)
+        if aux is None:
+            with torch.cuda.device(self.device):
+                aux = self._aux[key] = torch.cuda.Stream(device=self.device, priority=-1)
+        aux.wait_stream(cur)
+        with torch.cuda.stream(aux):
+            out = fn()
+        cur.wait_stream(aux)
+        for t in (out if isinstance(out, tuple) else (out,)):
+            if hasattr(t, "record_stream"):
+                t.record_stream(cur)         # allocated on the companion, used by the caller's stream from here on
+        return out
+
     def selftest_lanes(self) -> int:
         with self.torch.cuda.device(self.device):
             return _lib.check(self.lib.mx_selftest_lanes(self._stream_ptr()), "mx_selftest_lanes")
@@ -146,6 +176,26 @@ class Engine:
         the default): "n2_segments", "jacobi_max_batches"."""
         ids = {"n2_segments": 1, "jacobi_max_batches": 2}
         _lib.check(self.lib.mx_debug_knob(ids[knob], int(value)), "mx_debug_knob")
+
+    def clock_probe_start(self, microseconds: int = 300):
+        """Enqueue a shader-clock probe (mx_clock_probe) on a high-priority stream of its own, so that it runs
+        beside whatever the other streams have in flight; returns a handle for clock_probe_mhz."""
+        torch = self.torch
+        if getattr(self, "_probe_stream", None) is None:
+            with torch.cuda.device(self.device):
+                self._probe_stream = torch.cuda.Stream(device=self.device, priority=-1)
+        with torch.cuda.device(self.device), torch.cuda.stream(self._probe_stream):
+            # allocated and cleared ON the probe stream: a fill enqueued on the caller's (busy) stream would run
+            # after the probe and wipe its result
+            out = torch.zeros(2, dtype=torch.int64, device=self.device)
+            _lib.check(self.lib.mx_clock_probe(int(microseconds), out.data_ptr(), int(self._probe_stream.cuda_stream)), "mx_clock_probe")
+        return out
+
+    def clock_probe_mhz(self, handle) -> float:
+        """Shader clock in MHz measured by a finished probe (waits for it)."""
+        self._probe_stream.synchronize()
+        ticks = handle.cpu().tolist()
+        return ticks[0] / ticks[1] * 100.0 if ticks[1] else 0.0
 
     def profile(self, enable: bool) -> None:
         """Start/stop recording events around every modexp kernel launch (process-wide)."""
@@ -309,11 +359,13 @@ class Engine:
             self._combine_plans.popitem(last=False)
         return plan
 
-    def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None, segments: Optional[int] = None):
+    def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None, segments: Optional[int] = None,
+                         shape: Optional[Tuple[int, int]] = None):
         """out[e] = bases[e]^exp mod n^2 (rows of the width of n^2), computed through pairs modulo n
         (include/mxpaillier.h: mx_powmod_nsquare_prepare / _run) — the fast path of the partial
         decryption PSK:92.  The per-key plan is prepared on first use; afterwards a call is launches only
-        (`segments` of them, default: the engine's setting, 0 = the library's choice)."""
+        (`segments` of them, default: the engine's setting, 0 = the library's choice).  `shape` =
+        (limbs per lane, wavefronts per group) overrides the engine's settings for this call."""
         if exp < 0:
             raise ValueError("negative exponent: invert the base first (paillier_shared_key.py:89-91)")
         batch, limbs2 = bases_t.shape
@@ -327,7 +379,8 @@ class Engine:
             self._use_plan(plan)
             ws = self._workspace(self.lib.mx_powmod_nsquare_run_workspace_bytes(plan.desc, batch))
             rc = self.lib.mx_powmod_nsquare_run(
-                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch, self._lpl, self._wpg,
+                plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch,
+                self._lpl if shape is None else int(shape[0]), self._wpg if shape is None else int(shape[1]),
                 self._segments if segments is None else int(segments), ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_nsquare_run")
@@ -346,12 +399,12 @@ class Engine:
         _check_modulus(n)
         n2 = n * n
         limbs2 = _limbs.limbs_for(n2)
-        vals = [_reduce(b, n2) for b in bases]
+        vals = bases if isinstance(bases, list) else list(bases)
         if len(vals) < self.PIPELINE_MIN:
             import time as _t
 
             t0 = _t.perf_counter()
-            rows = _limbs.pack(vals, limbs2)
+            rows = _limbs.pack_reduced(vals, limbs2, n2)
             t1 = _t.perf_counter()
             # a lone launch that is waited for right away: nothing else is in flight whose drain segments
             # could shorten, and the three extra segment boundaries would cost ~1 %
@@ -363,14 +416,18 @@ class Engine:
             return (res, out_t) if keep_rows else res
         self.nsquare_plan(n, exp)          # prepared once, before the chunks fan out over streams
         kept: List[Any] = []
+        # the chunks run side by side: the launch shape is the one that suits the WHOLE sequence (the library's
+        # choice for a single launch of that size), not the one a lone chunk would get
+        k_, l_, _, _, w_ = self.nsquare_launch_shape(n.bit_length(), len(vals))
+        chunk_shape = (self._lpl or l_, self._wpg or w_)
 
         def launch(t):
-            out_t = self.powmod_nsquare_t(t, n, exp)
+            out_t = self.powmod_nsquare_t(t, n, exp, shape=chunk_shape)
             if keep_rows:
                 kept.append(out_t)
             return out_t
 
-        res = self._pipelined(vals, limbs2, limbs2, launch)
+        res = self._pipelined(vals, limbs2, limbs2, launch, modulus=n2)
         if not keep_rows:
             return res
         # the chunk results were allocated on the side streams; the concatenation reads them on the
@@ -446,9 +503,10 @@ class Engine:
             self._pin[which] = buf
         return buf[: rows * limbs].view(rows, limbs)
 
-    def _pipelined(self, vals: List[int], limbs_in: int, limbs_out: int, launch) -> List[int]:
+    def _pipelined(self, vals: List[int], limbs_in: int, limbs_out: int, launch, modulus: int = 0) -> List[int]:
         """ints -> ints through `launch(device rows) -> device rows`, chunked over side streams with
-        pinned staging buffers: pack chunk k+1 on the host while chunk k is copied and computed."""
+        pinned staging buffers: pack chunk k+1 on the host while chunk k is copied and computed.  With
+        `modulus` the packed rows are reduced modulo it (bulk: limbs.reduce_rows)."""
         import time as _t
 
         torch = self.torch
@@ -469,7 +527,14 @@ class Engine:
             if lo >= hi:
                 break
             t0 = _t.perf_counter()
-            _limbs.pack_into(vals[lo:hi], limbs_in, in_np, lo)
+            try:
+                _limbs.pack_into(vals[lo:hi], limbs_in, in_np, lo)
+            except ValueError:
+                if not modulus:
+                    raise
+                _limbs.pack_into([int(v) % modulus for v in vals[lo:hi]], limbs_in, in_np, lo)
+            if modulus:
+                _limbs.reduce_rows(in_np[lo:hi], modulus)
             pack_s += _t.perf_counter() - t0
             side = streams[k]
             side.wait_stream(cur)
@@ -504,7 +569,7 @@ class Engine:
             return []
         _check_modulus(mod)
         limbs = _limbs.limbs_for(mod)
-        rows = _limbs.pack([_reduce(b, mod) for b in bases], limbs)
+        rows = _limbs.pack_reduced(bases, limbs, mod)
         out = self.powmod_shared_t(self.to_device(rows), mod, exp)
         return _limbs.unpack(self.to_host(out))
 
@@ -524,10 +589,10 @@ class Engine:
             return [[] for _ in bases]
         limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
         flat = []
-        for b, m in zip(bases, mods):
-            flat.extend(_reduce(x, m) for x in b)
+        for b in bases:
+            flat.extend(b)
             flat.extend([0] * (gsize - len(b)))
-        rows = _limbs.pack(flat, limbs)
+        rows = _limbs.pack_reduced(flat, limbs, list(mods))
         out = self.powmod_multi_t(self.to_device(rows), list(mods), list(exps), gsize)
         vals = _limbs.unpack(self.to_host(out))
         return [vals[g * gsize : g * gsize + len(bases[g])] for g in range(groups)]
@@ -558,8 +623,8 @@ class Engine:
             return []
         _check_modulus(mod)
         limbs = _limbs.limbs_for(mod)
-        at = self.to_device(_limbs.pack([_reduce(x, mod) for x in a], limbs))
-        bt = self.to_device(_limbs.pack([_reduce(x, mod) for x in b], limbs))
+        at = self.to_device(_limbs.pack_reduced(a, limbs, mod))
+        bt = self.to_device(_limbs.pack_reduced(b, limbs, mod))
         return _limbs.unpack(self.to_host(self.mulmod_t(at, bt, mod)))
 
     DIRECT_MODINV_MAX = 4      # elements inverted directly (one wavefront each); longer batches use the product tree
@@ -617,7 +682,7 @@ class Engine:
             return []
         _check_modulus(mod)
         limbs = _limbs.limbs_for(mod)
-        x_t = self.to_device(_limbs.pack([_reduce(v, mod) for v in values], limbs))
+        x_t = self.to_device(_limbs.pack_reduced(values, limbs, mod))
         return _limbs.unpack(self.to_host(self.modinv_t(x_t, mod)))
 
     def encrypt_batch(self, messages: Sequence[int], randomness: Sequence[int], n: int) -> List[int]:
@@ -629,7 +694,7 @@ class Engine:
         _check_modulus(n)
         n2 = n * n
         limbs = _limbs.limbs_for(n2)
-        rn_t = self.powmod_nsquare_t(self.to_device(_limbs.pack([_reduce(r, n2) for r in randomness], limbs)), n, n)
+        rn_t = self.powmod_nsquare_t(self.to_device(_limbs.pack_reduced(randomness, limbs, n2)), n, n)
         g_t = self.to_device(_limbs.pack([(1 + (m % n) * n) % n2 for m in messages], limbs))
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, g_t, n2, out_t=rn_t)))
 
@@ -644,8 +709,8 @@ class Engine:
         _check_modulus(n)
         n2 = n * n
         limbs = _limbs.limbs_for(n2)
-        rn_t = self.powmod_nsquare_t(self.to_device(_limbs.pack([_reduce(r, n2) for r in randomness], limbs)), n, n)
-        c_t = self.to_device(_limbs.pack([_reduce(c, n2) for c in ciphertexts], limbs))
+        rn_t = self.powmod_nsquare_t(self.to_device(_limbs.pack_reduced(randomness, limbs, n2)), n, n)
+        c_t = self.to_device(_limbs.pack_reduced(ciphertexts, limbs, n2))
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, c_t, n2, out_t=rn_t)))
 
     # ------------------------------------------------------------------ Shamir field of the key generation
@@ -695,7 +760,7 @@ class Engine:
         if len(a) == 0:
             return []
         limbs = _limbs.limbs_for(prime)
-        ts = [self.to_device(_limbs.pack([_reduce(v, prime) for v in col], limbs)) for col in (a, b, c)]
+        ts = [self.to_device(_limbs.pack_reduced(col, limbs, prime)) for col in (a, b, c)]
         return _limbs.unpack(self.to_host(self.shamir_fma_t(ts[0], ts[1], ts[2], prime)))
 
     def shamir_lincomb_batch(self, columns: Sequence[Sequence[int]], coeffs: Sequence[int], prime: int) -> List[int]:
@@ -705,7 +770,7 @@ class Engine:
         if any(len(c) != len(columns[0]) for c in columns):
             raise ValueError("columns must have the same length")
         limbs = _limbs.limbs_for(prime)
-        x = np.stack([_limbs.pack([_reduce(v, prime) for v in col], limbs) for col in columns])
+        x = np.stack([_limbs.pack_reduced(col, limbs, prime) for col in columns])
         return _limbs.unpack(self.to_host(self.shamir_lincomb_t(self.to_device(x), coeffs, prime)))
 
     def shamir_reconstruct_sieve_batch(self, columns: Sequence[Sequence[int]], coeffs: Sequence[int], prime: int,
@@ -717,7 +782,7 @@ class Engine:
         if len(columns) == 0 or len(columns[0]) == 0:
             return [], {}
         limbs = _limbs.limbs_for(prime)
-        x = np.stack([_limbs.pack([_reduce(v, prime) for v in col], limbs) for col in columns])
+        x = np.stack([_limbs.pack_reduced(col, limbs, prime) for col in columns])
         mods_t = self.shamir_lincomb_t(self.to_device(x), coeffs, prime)
         primes = [int(q) for q in primes]
         if len(primes) == 0:
@@ -774,10 +839,10 @@ class Engine:
             return [[] for _ in values]
         limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
         flat = []
-        for vs, m in zip(values, mods):
-            flat.extend(_reduce(x, m) for x in vs)
+        for vs in values:
+            flat.extend(vs)
             flat.extend([0] * (gsize - len(vs)))
-        out = self.jacobi_t(self.to_device(_limbs.pack(flat, limbs)), list(mods), gsize)
+        out = self.jacobi_t(self.to_device(_limbs.pack_reduced(flat, limbs, list(mods))), list(mods), gsize)
         arr = out.cpu().numpy()
         return [[int(x) for x in arr[g * gsize : g * gsize + len(values[g])]] for g in range(groups)]
 
@@ -808,12 +873,17 @@ class Engine:
         # half of them: the first 2.6 * keep generators yield `keep` ones for > 99 % of the candidates,
         # and the tail of the list is evaluated only for the candidates where they did not.
         head = min(group_size, (13 * keep + 4) // 5)
-        j_t = self.jacobi_t(g_t, mods_op, group_size, first=0, count=head)
-        sel_t, cnt_t = self.select_first_t(g_t, j_t, group_size, keep)
-        if head < group_size:
-            self.jacobi_t(g_t, mods_op, group_size, out_t=j_t, first=head, count=group_size - head,
-                          skip_counts_t=cnt_t, skip_threshold=keep)
+
+        def filter_and_select():
+            j_t = self.jacobi_t(g_t, mods_op, group_size, first=0, count=head)
             sel_t, cnt_t = self.select_first_t(g_t, j_t, group_size, keep)
+            if head < group_size:
+                self.jacobi_t(g_t, mods_op, group_size, out_t=j_t, first=head, count=group_size - head,
+                              skip_counts_t=cnt_t, skip_threshold=keep)
+                sel_t, cnt_t = self.select_first_t(g_t, j_t, group_size, keep)
+            return sel_t, cnt_t
+
+        sel_t, cnt_t = self._small(filter_and_select)
         v_t = self.powmod_multi_t(sel_t, mods_op, exps, keep)
         return v_t, cnt_t
 
@@ -833,10 +903,10 @@ class Engine:
             return [[] for _ in mods]
         limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
         flat = []
-        for gs, m in zip(g_values, mods):
-            flat.extend(_reduce(x, m) for x in gs)
+        for gs in g_values:
+            flat.extend(gs)
             flat.extend([0] * (gsize - len(gs)))          # padding: symbol (0/N) = 0, never selected
-        g_t = self.to_device(_limbs.pack(flat, limbs))
+        g_t = self.to_device(_limbs.pack_reduced(flat, limbs, list(mods)))
         v_t, cnt_t = self.biprime_v_t(g_t, list(mods), list(exps), gsize, keep)
         counts = cnt_t.cpu().numpy()
         vals = _limbs.unpack(self.to_host(v_t))
@@ -887,13 +957,16 @@ class Engine:
             raise ValueError("output rows of the wrong shape")
         if status_t is None and not packed:
             status_t = self.torch.empty(batch, dtype=self.torch.uint8, device=self.device)
-        with self.torch.cuda.device(self.device):
-            self._use_plan(plan)
-            rc = self.lib.mx_combine_run(
-                plan.desc, partials_t.data_ptr(), out_t.data_ptr(), stride,
-                status_t.data_ptr() if status_t is not None else None, n_partials, batch, self._stream_ptr(),
-            )
-        _lib.check(rc, "mx_combine_run")
+        def run():
+            with self.torch.cuda.device(self.device):
+                self._use_plan(plan)
+                rc = self.lib.mx_combine_run(
+                    plan.desc, partials_t.data_ptr(), out_t.data_ptr(), stride,
+                    status_t.data_ptr() if status_t is not None else None, n_partials, batch, self._stream_ptr(),
+                )
+            _lib.check(rc, "mx_combine_run")
+
+        self._small(run)
         return out_t if packed else (out_t, status_t)
 
     def combine_batch(
@@ -908,7 +981,7 @@ class Engine:
             raise ValueError("every ciphertext needs the same number of partial decryptions")
         n2 = n * n
         limbs2 = _limbs.limbs_for(n2)
-        rows = np.stack([_limbs.pack([_reduce(p[i], n2) for p in partials], limbs2) for i in range(n_partials)])
+        rows = np.stack([_limbs.pack_reduced([p[i] for p in partials], limbs2, n2) for i in range(n_partials)])
         out_t, status_t = self.combine_t(self.to_device(rows), n, theta_inv)
         ok = [not bool(x) for x in status_t.cpu().numpy()]
         return _limbs.unpack(self.to_host(out_t)), ok
@@ -955,13 +1028,16 @@ class Engine:
             raise ValueError("one modulus per group expected")
         if pass_t is None:
             pass_t = self.torch.empty((groups, n_slots), dtype=self.torch.uint8, device=self.device)
-        with self.torch.cuda.device(self.device):
-            ws = self._workspace(self.lib.mx_verdict_workspace_bytes(limbs, n_parties, groups, n_slots))
-            rc = self.lib.mx_biprime_verdict_dev(
-                v_t.data_ptr(), pass_t.data_ptr(), mods_t.data_ptr(), limbs, mod_bits, n_parties, groups, n_slots,
-                ws.data_ptr(), ws.numel(), self._stream_ptr(),
-            )
-        _lib.check(rc, "mx_biprime_verdict_dev")
+        def run():
+            with self.torch.cuda.device(self.device):
+                ws = self._workspace(self.lib.mx_verdict_workspace_bytes(limbs, n_parties, groups, n_slots))
+                rc = self.lib.mx_biprime_verdict_dev(
+                    v_t.data_ptr(), pass_t.data_ptr(), mods_t.data_ptr(), limbs, mod_bits, n_parties, groups, n_slots,
+                    ws.data_ptr(), ws.numel(), self._stream_ptr(),
+                )
+            _lib.check(rc, "mx_biprime_verdict_dev")
+
+        self._small(run)
         return pass_t
 
     def biprime_verdict_batch(self, v: Sequence[Sequence[Sequence[int]]], mods: Sequence[int]) -> List[List[bool]]:
@@ -979,7 +1055,7 @@ class Engine:
         limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
         rows = np.stack(
             [
-                _limbs.pack([_reduce(v[g][i][k], mods[g]) for g in range(groups) for k in range(n_slots)], limbs)
+                _limbs.pack_reduced([x for g in range(groups) for x in v[g][i][:n_slots]], limbs, list(mods))
                 for i in range(n_parties)
             ]
         ).reshape(n_parties, groups, n_slots, limbs)

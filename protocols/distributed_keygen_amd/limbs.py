@@ -65,6 +65,51 @@ def pack(values: Sequence[int], limbs: int) -> np.ndarray:
     return out
 
 
+def reduce_rows(rows: np.ndarray, moduli) -> np.ndarray:
+    """Rows (uint32 [count, limbs]) that are >= their modulus -> their residue, in place.  `moduli`: one int for
+    all rows, or a sequence of ints with count = len(moduli) * group (consecutive rows share a modulus).
+    Vectorised: the word that holds a modulus' top bit decides for all but a handful of rows (a value is below
+    the modulus when that word is smaller and nothing lies above it); only rows that may be >= it become Python
+    ints.  This replaces a Python-level ``v % m`` per element on the int-level paths, where received values are
+    canonical residues already."""
+    count, limbs = rows.shape
+    if count == 0:
+        return rows
+    mods = [int(moduli)] if isinstance(moduli, int) else [int(m) for m in moduli]
+    group = count // len(mods)
+    view = rows.reshape(len(mods), group, limbs)
+    for g, m in enumerate(mods):
+        top = (m.bit_length() - 1) // 32
+        if top >= limbs:
+            continue                                  # every value of this width is below the modulus
+        blk = view[g]
+        suspect = blk[:, top] >= np.uint32((m >> (32 * top)) & 0xFFFFFFFF)
+        if top + 1 < limbs:
+            suspect |= blk[:, top + 1 :].any(axis=1)
+        for k in np.nonzero(suspect)[0]:
+            v = int.from_bytes(blk[k].tobytes(), "little")
+            if v >= m:
+                blk[k] = np.frombuffer((v % m).to_bytes(4 * limbs, "little"), dtype="<u4")
+    return rows
+
+
+def pack_reduced(values: Sequence[int], limbs: int, moduli) -> np.ndarray:
+    """ints -> uint32 rows of their residues modulo `moduli` (one modulus, or one per group of consecutive
+    values): the bulk C conversion plus reduce_rows; values that do not fit the rows or are negative take the
+    per-element path."""
+    if not isinstance(values, (list, tuple)):
+        values = list(values)
+    try:
+        rows = pack(values, limbs)
+    except ValueError:
+        if isinstance(moduli, int):
+            return pack([int(v) % moduli for v in values], limbs)
+        mods = [int(m) for m in moduli]
+        group = len(values) // len(mods)
+        return pack([int(v) % mods[k // group] for k, v in enumerate(values)], limbs)
+    return reduce_rows(rows, moduli)
+
+
 def pack_one(value: int, limbs: int) -> np.ndarray:
     return pack([value], limbs)[0]
 

@@ -104,8 +104,19 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
             for name in names:
                 if hasattr(mod, name):
                     _saved_names.setdefault(mod, {}).setdefault(name, getattr(mod, name))
-                    op = getattr(operators, name)
-                    setattr(mod, name, (lambda f: (lambda *a: f(*a, engine=engine)))(op))
+                    op, original = getattr(operators, name), _saved_names[mod][name]
+
+                    def rebound(*a, _op=op, _orig=original):
+                        # the engine's arithmetic is Montgomery arithmetic: odd moduli >= 3 (N, N^2 and the
+                        # Shamir prime all are).  The leaf the reference imported is total, so anything else
+                        # (an even or tiny modulus: no call site of this package produces one) goes to the
+                        # function that was bound here before the patch — the reference's own.
+                        modulus = a[-1]
+                        if isinstance(modulus, int) and (modulus < 3 or modulus % 2 == 0):
+                            return _orig(*a)
+                        return _op(*a, engine=engine)
+
+                    setattr(mod, name, rebound)
 
     # ------------------------------------------------------------------ PaillierSharedKey
     # The scalar methods keep the reference's semantics and hold NO state between calls: any number of

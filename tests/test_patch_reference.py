@@ -410,6 +410,8 @@ def test_leaf_operators_can_be_rebound(ref):
         from oracle import oracle
 
         assert p == oracle.partial_decrypt(cts[0].peek_value(), key["n"], 1, key["degree"], key["n_fac"], key["shares"][1])
+        # moduli outside the engine's domain (even, < 3) fall through to the reference's own leaf: the rebound name is total
+        assert psk.pow_mod(7, 5, 1 << 40) == pow(7, 5, 1 << 40) and psk.pow_mod(3, 4, 2) == 1 and psk.mod_inv(3, 16) == 11
         assert operators.pow_mod(7, -3, 101, engine=eng) == pow(7, -3, 101)
         assert operators.mod_inv(7, 101, engine=eng) == pow(7, -1, 101)
         assert operators.pow_mod_batch_multi([[2, 3], [5]], [10, 3], [101, 103], engine=eng) == [[pow(2, 10, 101), pow(3, 10, 101)], [pow(5, 3, 103)]]

@@ -18,7 +18,10 @@ for every (L, nblk):
         — matches the dispatches to the configs in launch order, solves the 3x3 system from the first
           three exponents and reports the residual of the held-out fourth (a check of the linear model)
 
-The model is committed as profiles/r02_instr_model.json; bench.py reads it.
+The model is committed as profiles/r03_instr_model.json together with a digest of the kernel sources it was
+fitted to; bench.py reads it and refuses it (roofline fraction null, with the reason) when the digest no longer
+matches the sources of the library it runs.  Kinds: "n2" (pair kernel, one wavefront per group), "n2split" (two
+wavefronts per group: the constants are per PAIR of wavefronts), "generic" (fixed-window kernel).
 """
 
 from __future__ import annotations
@@ -35,6 +38,18 @@ sys.path.insert(0, str(ROOT))
 
 W = 29
 WAVES = 4
+KERNEL_SOURCES = ["mx_lanes.hpp", "mx_mont.hpp", "mx_powmod.hpp", "mx_powmod_n2.hpp", "mx_powmod_n2_split.hpp"]
+
+
+def kernel_sources_digest() -> str:
+    """sha256 over the device-code headers whose instruction streams the model describes."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        h.update((ROOT / "protocols" / "distributed_keygen_amd" / "csrc" / name).read_bytes())
+    return h.hexdigest()
+
 
 
 def fixed_window(exp_bits: int) -> int:
@@ -62,7 +77,7 @@ def exponents(rng: random.Random, kind: str):
     def rnd(bits):
         return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
 
-    if kind == "n2":
+    if kind in ("n2", "n2split"):
         return [(1 << 191, 0), ((1 << 192) - 1, 0), (rnd(120), 0), (rnd(192), 0)]
     # (exponent, exponent row width in words): the row width selects the window (mx_host.hpp fixed_window),
     # so a short exponent in wide rows has few squarings and a large table — what separates I_mul from I_sqr
@@ -77,9 +92,11 @@ def run(cfg_path: str) -> None:
     eng = Engine()
     rng = random.Random(20260201)
     configs = []
-    for kind in ("n2", "generic"):
-        for L in (9, 18):
-            max_nblk = {("n2", 9): 32, ("n2", 18): 16, ("generic", 9): 64, ("generic", 18): 32}[(kind, L)]
+    for kind in ("n2", "n2split", "generic"):
+        for L in ((3, 9, 18) if kind == "n2split" else (9, 18)):
+            max_nblk = {("n2", 9): 32, ("n2", 18): 16, ("generic", 9): 64, ("generic", 18): 32,
+                        ("n2split", 3): 64, ("n2split", 9): 32, ("n2split", 18): 16}[(kind, L)]
+            eng.set_wavefronts_per_group(2 if kind == "n2split" else 1)
             for nblk in range(1, max_nblk + 1):
                 bits = W * L * nblk - 4
                 if bits < 8:
@@ -91,8 +108,8 @@ def run(cfg_path: str) -> None:
                 eng.set_limbs_per_lane(L)
                 n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
                 for e, erow in exponents(rng, kind):
-                    if kind == "n2":
-                        assert eng.nsquare_geometry(bits, batch) == (k, L, W, nblk)
+                    if kind in ("n2", "n2split"):
+                        assert eng.nsquare_launch_shape(bits, batch) == (k, L, W, nblk, 2 if kind == "n2split" else 1)
                         n2 = n * n
                         rows = eng.to_device(Lm.pack([rng.randrange(n2) for _ in range(batch)], Lm.limbs_for(n2)))
                         plan = eng.nsquare_plan(n, e)
@@ -129,19 +146,21 @@ def solve3(rows, rhs):
 
 def fit(cfg_path: str, pmc_dir: str, model_path: str) -> None:
     configs = json.loads(Path(cfg_path).read_text())
-    disp = {"n2": [], "generic": []}
+    disp = {"n2": [], "n2split": [], "generic": []}
     for f in glob.glob(pmc_dir + "/**/*_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
             if r["Counter_Name"] != "SQ_INSTS_VALU":
                 continue
             name = r["Kernel_Name"]
-            kind = "n2" if "powmod_n2_kernel" in name else ("generic" if "mx::powmod_kernel" in name else None)
+            kind = ("n2" if "powmod_n2_kernel" in name else "n2split" if "powmod_n2_split_kernel" in name
+                    else "generic" if "mx::powmod_kernel" in name else None)
             if kind:
                 disp[kind].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), name))
-    model = {"n2": {"9": {}, "18": {}}, "generic": {"9": {}, "18": {}}, "max_residual": 0.0,
+    model = {"n2": {"9": {}, "18": {}}, "n2split": {"3": {}, "9": {}, "18": {}}, "generic": {"9": {}, "18": {}}, "max_residual": 0.0,
+             "kernel_sources_sha256": kernel_sources_digest(), "kernel_sources": KERNEL_SOURCES,
              "source": "tools/calibrate_instr.py: SQ_INSTS_VALU of 4 exponents per (kernel, L, nblk); wave-instructions "
-                       "per wavefront = n_sqr*I_sqr + n_mul*I_mul + F"}
-    for kind in ("n2", "generic"):
+                       "per wavefront (n2split: per pair of wavefronts) = n_sqr*I_sqr + n_mul*I_mul + F"}
+    for kind in ("n2", "n2split", "generic"):
         d = sorted(disp[kind])
         cfgs = [c for c in configs if c["kind"] == kind]
         assert len(d) == len(cfgs), (kind, len(d), len(cfgs))
@@ -156,9 +175,11 @@ def fit(cfg_path: str, pmc_dir: str, model_path: str) -> None:
             model[kind][str(grp[0]["L"])][str(grp[0]["nblk"])] = [round(sol[0], 2), round(sol[1], 2), round(sol[2], 1)]
     Path(model_path).write_text(json.dumps(model, indent=0))
     print("max residual of the held-out exponent:", model["max_residual"])
-    for kind in ("n2", "generic"):
-        for L in ("9", "18"):
-            for nblk in ("4", "8", "16"):
+    for kind in ("n2", "n2split", "generic"):
+        for L in ("3", "9", "18"):
+            for nblk in ("4", "8", "16", "24"):
+                if L not in model[kind]:
+                    continue
                 if nblk in model[kind][L]:
                     print(kind, "L", L, "nblk", nblk, model[kind][L][nblk])
 
