@@ -236,7 +236,8 @@ int mx_modinv(const uint32_t* d_values, uint32_t* d_out, uint8_t* d_status, cons
  * d_out[g*group_size + k] = Jacobi symbol (d_values[g*group_size + k] / h_mods[g]) in {-1, 0, +1}.
  * Replaces the filter `sympy.jacobi_symbol(g, modulus) != 1` of the biprimality test (DK:1089),
  * evaluated for the up to 4*40 jointly random generators of every candidate (DK:1028, 1084-1099).
- * Values must be < their modulus (UT:361); moduli odd; limbs <= 129 (4128 bits). */
+ * Values must be < their modulus (UT:361); moduli odd; limbs <= 257 (8224 bits: key_length 8192,
+ * the widest key whose N^2 the modexp kernels take). */
 int64_t mx_jacobi_workspace_bytes(int limbs, int64_t groups);
 int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
               int64_t group_size, void* d_workspace, int64_t workspace_bytes, void* stream);

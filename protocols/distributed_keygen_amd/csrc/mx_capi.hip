@@ -647,7 +647,7 @@ extern "C" int mx_jacobi_dev_range(const uint32_t* d_values, int8_t* d_out, cons
                                    int skip_threshold, void* stream) {
   if (!d_values || !d_out || !d_mods || limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
   if (first < 0 || count <= 0 || (int64_t)first + count > group_size) return MX_ERR_ARG;
-  if (limbs > 129) return MX_ERR_SIZE;
+  if (limbs > 257) return MX_ERR_SIZE;
   hipStream_t s = (hipStream_t)stream;
   mx::JacobiArgs a;
   a.a = d_values; a.mods = d_mods; a.out = (signed char*)d_out;
@@ -661,7 +661,10 @@ extern "C" int mx_jacobi_dev_range(const uint32_t* d_values, int8_t* d_out, cons
   if (limbs <= 17) return launch_jacobi<17>(a, s);
   if (limbs <= 33) return launch_jacobi<33>(a, s);
   if (limbs <= 65) return launch_jacobi<65>(a, s);
-  return launch_jacobi<129>(a, s);
+  if (limbs <= 129) return launch_jacobi<129>(a, s);
+  // key_length 8192 (the widest modulus the modexp kernels take for N^2): operands no longer fit the register file
+  // (512 VGPRs + scratch, one wavefront per SIMD) — slower per symbol, still a rounding error beside 8200-bit modexps
+  return launch_jacobi<257>(a, s);
 }
 
 extern "C" int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint32_t* d_mods, int limbs,
@@ -673,7 +676,7 @@ extern "C" int mx_jacobi_dev(const uint32_t* d_values, int8_t* d_out, const uint
 extern "C" int mx_jacobi(const uint32_t* d_values, int8_t* d_out, const uint32_t* h_mods, int limbs, int64_t groups,
                          int64_t group_size, void* d_ws, int64_t ws_bytes, void* stream) {
   if (!d_values || !d_out || !h_mods || !d_ws || limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
-  if (limbs > 129) return MX_ERR_SIZE;
+  if (limbs > 257) return MX_ERR_SIZE;
   for (int64_t g = 0; g < groups; ++g)
     if (!(h_mods[g * limbs] & 1u)) return MX_ERR_MODULUS;
   if (align256((int64_t)groups * limbs * 4) > ws_bytes) return MX_ERR_WORKSPACE;

@@ -363,7 +363,7 @@ struct Mont {
 #pragma unroll
       for (int j = 0; j < L; ++j) { nb[j] = lds[j]; nd[j] = (F & F_TWO) ? lds[LDS_D + j] : 0u; }
     }
-    for (int blk = 0; blk < nsteps_blk; ++blk) {
+    auto do_block = [&](int blk) {
       // The multiplicand limbs are loop invariant, and the compiler would hoist their zero
       // extension to 64 bits out of this loop — every limb then occupies a register PAIR for the
       // whole product (v_mad_u64_u32 only reads the low half).  Opaque per block: the extension
@@ -388,6 +388,14 @@ struct Mont {
         for (int j = 0; j < L; ++j) dd[j] = (F & F_TWO) ? lds[LDS_D + blk * L + j] : 0u;
       }
       block_steps<F>(t, a, c, bb, dd, qr, blk, emit, std::make_integer_sequence<int, L>{});
+    };
+    if constexpr (PREFETCH) {
+      // two blocks per trip: with 3 limbs per lane the loop control of a trip is a tenth of its instructions
+      int blk = 0;
+      for (; blk + 1 < nsteps_blk; blk += 2) { do_block(blk); do_block(blk + 1); }
+      if (blk < nsteps_blk) do_block(blk);
+    } else {
+      for (int blk = 0; blk < nsteps_blk; ++blk) do_block(blk);
     }
     normalize_weak(r, t);
     if constexpr (F & F_RECORD_Q) {

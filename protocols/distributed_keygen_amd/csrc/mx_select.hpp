@@ -31,7 +31,7 @@ __global__ void __launch_bounds__(64) select_first_kernel(SelectArgs A) {
     const bool on = (k < A.group_size) && (fl[k] == 1);
     const unsigned long long m = __ballot(on);
     const int slot = kept + __popcll(m & ((1ull << lane) - 1ull));
-    // the selected row is copied by its own lane, one word at a time (rows are short: <= 129 words)
+    // the selected row is copied by its own lane, one word at a time (rows are short: <= 257 words)
     if (on && slot < A.keep) {
       for (int w = 0; w < A.limbs; ++w) dst[(long long)slot * A.limbs + w] = src[(long long)k * A.limbs + w];
     }

@@ -44,7 +44,7 @@ def _save(cls: Any, name: str) -> None:
 # Engine limits that the reference does not have (include/mxpaillier.h); checked once at install time
 # and again at the start of compute_modulus, before any message of a keygen round has been exchanged.
 MAX_SIEVE_PRIME = (1 << 21) - 1          # mx_sieve: primes < 2^21
-MAX_JACOBI_BITS = 129 * 32               # mx_jacobi: moduli up to 129 words (key_length <= 4096)
+MAX_JACOBI_BITS = 257 * 32               # mx_jacobi: moduli up to 257 words (key_length <= 8192, the modexp engine's own limit for N^2)
 
 
 def check_limits(engine: Any = None, prime_list: Optional[Iterable[int]] = None, prime_length: Optional[int] = None,
@@ -64,7 +64,7 @@ def check_limits(engine: Any = None, prime_list: Optional[Iterable[int]] = None,
         if bits > MAX_JACOBI_BITS:
             raise ValueError(
                 f"key_length {2 * prime_length} gives candidate moduli of up to {bits} bits; the GPU Jacobi kernel "
-                f"takes {MAX_JACOBI_BITS} (key_length <= 4096)")
+                f"takes {MAX_JACOBI_BITS} (key_length <= 8192, the widest key whose N^2 the modexp kernels take)")
 
 
 def _gpu_key(key: Any, engine: Any) -> GpuPaillierSharedKey:

@@ -131,7 +131,8 @@ def test_verdict_negative_and_zero_products(eng):
 
 
 # ------------------------------------------------------------------ Jacobi symbol (DK:1089)
-@pytest.mark.parametrize("bits,groups,gsize", [(20, 7, 33), (68, 9, 80), (131, 5, 160), (515, 3, 64), (1028, 4, 160), (2053, 3, 160), (4100, 2, 40)])
+@pytest.mark.parametrize("bits,groups,gsize", [(20, 7, 33), (68, 9, 80), (131, 5, 160), (515, 3, 64), (1028, 4, 160), (2053, 3, 160), (4100, 2, 40),
+                                               (4200, 2, 20), (8197, 2, 24)])
 def test_jacobi_random(eng, bits, groups, gsize):
     rng = random.Random(bits)
     mods = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(groups)]
@@ -478,7 +479,7 @@ def test_jacobi_unbalanced_operands_and_safety_net(eng, monkeypatch):
     binary algorithm that backs them up has to finish every symbol from an intermediate state."""
     rng = random.Random(77)
     rows, mods = [], []
-    for bits in (61, 300, 1028, 2053, 4100):
+    for bits in (61, 300, 1028, 2053, 4100, 8197):
         m = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
         vals = [0, 1, 2, 3, 4, 5, 12345, m - 1, m - 2, m - 12345, (m + 1) // 2, rng.getrandbits(20), rng.getrandbits(bits // 3),
                 3 * 5 * 7 * rng.getrandbits(40)] + [rng.randrange(m) for _ in range(18)]
@@ -536,3 +537,73 @@ def test_operator_surface_pow_mod_and_mod_inv(eng):
         operators.mod_inv(0, mod, engine=eng)
     with pytest.raises(ValueError):
         operators.pow_mod(3, 5, 1 << 64, engine=eng)           # even modulus: no Montgomery arithmetic, no CPU path
+
+
+def test_small_kernels_on_the_priority_companion_stream(eng, golden_decrypt_synth):
+    """Engine.set_priority_aux: recombination, verdict and the Jacobi filter + selection run on a high-priority
+    companion of the calling stream, ordered by events on both sides — same results, from several caller streams
+    at once and without any host synchronisation in between."""
+    import torch
+
+    from protocols.distributed_keygen_amd import limbs as L
+
+    grp = golden_decrypt_synth["k1024_n3_t1"]
+    n, theta_inv = unhex(grp["n"]), unhex(grp["theta_inv"])
+    n2 = n * n
+    limbs2 = L.limbs_for(n2)
+    cases = grp["cases"]
+    partials = torch.stack([eng.to_device(L.pack([unhex(c["partials"][str(i)]) for c in cases], limbs2)) for i in (1, 2, 3)])
+    want = [unhex(c["m"]) for c in cases]
+    rng = random.Random(31)
+    mods = [rng.getrandbits(515) | (1 << 514) | 1 for _ in range(6)]
+    exps = [rng.getrandbits(500) for _ in mods]
+    gens = [[rng.randrange(m) for _ in range(24)] for m in mods]
+    eng.set_priority_aux(True)
+    try:
+        streams = [torch.cuda.Stream() for _ in range(3)]
+        outs = []
+        for k in range(6):
+            with torch.cuda.stream(streams[k % 3]):
+                m_t, st_t = eng.combine_t(partials, n, theta_inv)
+                outs.append((m_t, st_t))
+        torch.cuda.synchronize()
+        for m_t, st_t in outs:
+            assert L.unpack(eng.to_host(m_t)) == want and int(st_t.sum().item()) == 0
+        got = eng.biprime_v_batch(gens, exps, mods, 8)
+        for g, e, m, row in zip(gens, exps, mods, got):
+            kept = [x for x in g if oracle.jacobi_symbol(x, m) == 1][:8]
+            assert row == [pow(x, e, m) for x in kept]
+        assert len(eng._aux) >= 3
+    finally:
+        eng.set_priority_aux(False)
+
+
+def test_stream_concurrency_probe_and_clock_probe(eng):
+    """mx_spin / mx_clock_probe: the streams the engine would cut a long batch over are verified to run side
+    by side (at least one does; with 16 hardware queues all of them), and the shader clock measured by a probe
+    wavefront is a plausible MI355X clock."""
+    import torch
+
+    streams = [torch.cuda.Stream(priority=-1) for _ in range(4)]
+    ok = eng.stream_concurrency(streams, spin_us=300)
+    assert 1 <= len(ok) <= 4 and ok[0] is streams[0]
+    chunk = eng._chunk_streams(4)
+    assert 1 <= len(chunk) <= 4
+    mhz = eng.clock_probe_mhz(eng.clock_probe_start(200))
+    assert 500.0 < mhz < 3000.0
+
+
+def test_combine_columns_with_unreduced_peer_values(eng, golden_decrypt_synth):
+    """a peer's partial decryptions that are not canonical residues (v + k N^2, as plain
+    ints and in wire form) recombine to the same plaintexts."""
+    from protocols.distributed_keygen_amd import codec
+
+    grp = golden_decrypt_synth["k1024_n3_t1"]
+    n, theta_inv = unhex(grp["n"]), unhex(grp["theta_inv"])
+    n2 = n * n
+    cols = [[unhex(c["partials"][str(i)]) for c in grp["cases"]] for i in (1, 2, 3)]
+    want = [unhex(c["m"]) for c in grp["cases"]]
+    cols[1] = [v + n2 for v in cols[1]]
+    cols[2] = [codec.encode_int(v + 2 * n2) if k % 2 else v + n2 for k, v in enumerate(cols[2])]
+    msgs, ok = eng.combine_columns(cols, n, theta_inv)
+    assert all(ok) and msgs == want

@@ -239,20 +239,28 @@ def test_one_engine_driven_from_several_streams(eng):
 @pytest.mark.parametrize("segments", [1, 2, 3, 4, 7, 64])
 def test_powmod_nsquare_segments_are_bit_identical(eng, segments):
     """One exponentiation enqueued as several consecutive launches (tape segments, the accumulator
-    travelling through the workspace): the same result bit for bit, in both lane geometries."""
+    travelling through the workspace): the same result bit for bit, in every launch shape of the pair kernel."""
     rng = random.Random(1000 + segments)
     n = rng.getrandbits(1027) | (1 << 1026) | 1
     n2 = n * n
     bases = [0, 1, n, n2 - 1] + [rng.randrange(n2) for _ in range(29)]
     try:
-        for lpl in (9, 18):
+        for lpl, wpg in ((9, 1), (18, 1), (3, 2), (9, 2), (18, 2)):
             eng.set_limbs_per_lane(lpl)
+            eng.set_wavefronts_per_group(wpg)
             for e in (rng.getrandbits(700) | (1 << 699) | 1, (1 << 300), 5, 0):
                 eng.set_segments(segments)
-                assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (lpl, e.bit_length())
+                assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (lpl, wpg, e.bit_length())
+        # the developer knob overrides the library's automatic choice (segments = 0) and nothing else
+        eng.set_segments(0)
+        eng.debug_knob("n2_segments", segments)
+        e = rng.getrandbits(600) | 1
+        assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases]
     finally:
+        eng.debug_knob("n2_segments", 0)
         eng.set_segments(0)
         eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
 
 
 def test_exponent_with_a_very_long_run_of_zero_bits(eng):

@@ -18,6 +18,7 @@ def eng():
     e = Engine()
     yield e
     e.set_limbs_per_lane(0)
+    e.set_wavefronts_per_group(0)
 
 
 def _special_moduli(bits):
@@ -78,17 +79,43 @@ def test_randomized_differential(eng):
         assert eng.mulmod_batch(a, bases, mod) == [x * y % mod for x, y in zip(a, bases)]
 
 
-@pytest.mark.parametrize("lpl", [9, 18])
-def test_nsquare_pair_kernel_special_operands(eng, lpl):
-    """The N-adic pair kernel (mx_powmod_nsquare) in both lane geometries: bases that are multiples of
-    N (lazy digit carries in the final conversion), all-ones patterns, tiny and huge exponents."""
+@pytest.mark.parametrize("lpl,wpg", [(9, 1), (18, 1), (3, 2), (9, 2), (18, 2)])
+def test_nsquare_pair_kernel_special_operands(eng, lpl, wpg):
+    """The N-adic pair kernel (mx_powmod_nsquare) in every launch shape — one wavefront per group in both lane
+    geometries, two wavefronts per group in all three: bases that are multiples of N (lazy digit carries in
+    the final conversion), all-ones patterns, tiny and huge exponents."""
     eng.set_limbs_per_lane(lpl)
+    eng.set_wavefronts_per_group(wpg)
     rng = random.Random(99 + lpl)
-    for bits in (33, 261, 300, 1028, 2051):
-        for n in _special_moduli(bits)[:4]:
+    try:
+        for bits in (33, 261, 300, 1028, 2051):
+            for n in _special_moduli(bits)[:4]:
+                n2 = n * n
+                bases = [0, 1, n - 1, n, n + 1, 2 * n, n * (n - 1), n2 - 1, n2 - n, (n2 - 1) // 2]
+                bases += _special_bases(n2, rng)[9:]
+                for e in (0, 1, 2, 3, n, rng.getrandbits(200) | 1):
+                    assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (bits, e.bit_length())
+    finally:
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
+
+
+def test_nsquare_randomized_differential_over_launch_shapes(eng):
+    """Random moduli, exponents, batch sizes and launch shapes (incl. the library's own choice) of the pair
+    kernel against pow(): ragged last workgroups, odd pair counts, exponents of 0 .. 700 bits."""
+    rng = random.Random(20261003)
+    try:
+        for trial in range(40):
+            bits = rng.choice([rng.randint(20, 260), rng.randint(261, 1100), rng.randint(1100, 2100)])
+            n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
             n2 = n * n
-            bases = [0, 1, n - 1, n, n + 1, 2 * n, n * (n - 1), n2 - 1, n2 - n, (n2 - 1) // 2]
-            bases += _special_bases(n2, rng)[9:]
-            for e in (0, 1, 2, 3, n, rng.getrandbits(200) | 1):
-                assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (bits, e.bit_length())
-    eng.set_limbs_per_lane(0)
+            e = rng.getrandbits(rng.choice([1, 2, 64, rng.randint(1, 700)]))
+            batch = rng.choice([1, 2, 3, 5, 17, 33, 64, 65, 130])
+            bases = [rng.randrange(n2) for _ in range(batch)]
+            lpl, wpg = rng.choice([(0, 0), (9, 1), (18, 1), (3, 2), (9, 2), (18, 2), (0, 2), (0, 1)])
+            eng.set_limbs_per_lane(lpl)
+            eng.set_wavefronts_per_group(wpg)
+            assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (trial, bits, batch, lpl, wpg)
+    finally:
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)

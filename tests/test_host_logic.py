@@ -343,6 +343,30 @@ def test_rows_from_wire_fast_path_and_reduction():
     assert limbs.unpack(codec.rows_from_wire([5], 4, modulus=m)) == [5]            # modulus wider than the rows
 
 
+def test_bulk_residue_packing():
+    """limbs.pack_reduced / reduce_rows: the int-level paths reduce whole columns at once (the word holding a
+    modulus' top bit decides for almost every row) instead of one Python `%` per element."""
+    import random
+
+    from protocols.distributed_keygen_amd import limbs
+
+    rng = random.Random(8)
+    for bits in (33, 64, 65, 200, 2051):
+        m = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+        width = limbs.limbs_for(m) + (1 if bits == 200 else 0)
+        top = 1 << (32 * width)
+        vals = [0, 1, m - 1, m, m + 1, 2 * m - 1, top - 1] + [rng.randrange(m) for _ in range(50)] + [rng.getrandbits(32 * width) for _ in range(20)]
+        assert limbs.unpack(limbs.pack_reduced(vals, width, m)) == [v % m for v in vals], bits
+        odd = vals + [-5, top << 3]                      # negative / too wide: the per-element path
+        assert limbs.unpack(limbs.pack_reduced(odd, width, m)) == [v % m for v in odd], bits
+    mods = [rng.getrandbits(130) | (1 << 129) | 1 for _ in range(4)]
+    vals = [rng.getrandbits(160) for _ in range(4 * 7)]
+    assert limbs.unpack(limbs.pack_reduced(vals, 5, mods)) == [v % mods[k // 7] for k, v in enumerate(vals)]
+    assert limbs.pack_reduced([], 3, 7).shape == (0, 3)
+    wide = 1 << 200                                       # modulus wider than the rows: nothing to reduce
+    assert limbs.unpack(limbs.pack_reduced([5, (1 << 96) - 1], 3, wide)) == [5, (1 << 96) - 1]
+
+
 def test_c_codec_matches_int_to_bytes():
     import random
 

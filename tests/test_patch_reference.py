@@ -351,8 +351,9 @@ def test_limits_are_checked_before_any_round(ref):
     patch.check_limits(None, [3, 5, 1999], 1024, 3)
     with pytest.raises(ValueError, match="prime_threshold"):
         patch.check_limits(None, [3, 5, (1 << 21) + 7], 1024, 3)
+    patch.check_limits(None, [3, 5], 4096, 5)                    # key_length 8192 is inside the engine's range
     with pytest.raises(ValueError, match="key_length"):
-        patch.check_limits(None, [3, 5], 2100, 3)
+        patch.check_limits(None, [3, 5], 4200, 3)
 
 
 def test_install_can_leave_the_scalar_methods_to_the_reference(ref):
