@@ -323,7 +323,6 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   a.ntape = plan->ntape;
   a.slots = (u32*)d_ws;
   a.batch = batch; a.limbsn = plan->limbs_n; a.limbs2 = limbs2; a.nblk = p.geo.nblk; a.ksplit = bits - 1;
-  a.cus = device_cus();
   hipStream_t s = (hipStream_t)stream;
   // segments: consecutive launches that each execute a stretch of the tape (mx_powmod_n2.hpp); positions
   // are counted in squarings, the accumulator travels through a scratch slot of the workspace

@@ -63,7 +63,6 @@ struct PowmodN2Args {
   // then lives 1/segments as long, which is the granularity at which a burst of launches drains.
   int pos_begin, pos_end;
   int first, last;    // first segment: input conversion prologue; last segment: output epilogue
-  int cus;            // compute units of the device (the two-wavefront kernel alternates roles per residence round)
 };
 
 template <class M_t>

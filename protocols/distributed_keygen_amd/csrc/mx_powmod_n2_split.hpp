@@ -27,7 +27,8 @@
 // took 1.5x as long as one with a single one).  With four wavefronts a workgroup covers the CU evenly.  The two
 // pairs share nothing but the copy of C' (with a workgroup barrier per operation instead of the counters they
 // waited for each other: 35.2 instead of 32.9 ms per wide launch at key_length 2048, 23.3 instead of 21.5 at L = 9;
-// A/B on one box).  The role a wavefront takes alternates with the residence round of its workgroup (see `half`).
+// A/B on one box).  (Swapping the roles of the two wavefronts in every second workgroup a CU receives, so that every
+// SIMD carries the same mix of light and heavy wavefronts, changed nothing measurable: not kept.)
 //
 // Small-L instances (L = 3: 32 lanes per element at key_length 2048, 64 at 4096) exist only in this form:
 // they are the latency geometry — a limb step costs 2 L multiply-accumulates plus ~10 instructions of
@@ -58,10 +59,7 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   const int lane = threadIdx.x & 63;
   // 0: wavefront A (first digits), 1: wavefront B (second digits); in an SGPR, so that the two roles are
   // uniform branches
-  // Which wavefront of a pair takes which role alternates with the workgroup's round of residence: the second
-  // workgroup a CU receives (blockIdx + number of CUs, as the dispatcher deals them) puts its heavier B wavefronts
-  // on the SIMDs that hold the first one's lighter A wavefronts, so that every SIMD carries the same mix.
-  const int half = __builtin_amdgcn_readfirstlane((int)(((threadIdx.x >> 6) ^ (blockIdx.x / (unsigned)A.cus)) & 1));
+  const int half = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 1));
   const int pair = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));          // which pair of the workgroup
   const int gw = lane / K;
   const i64 wave_slot = (i64)blockIdx.x * N2_SPLIT_PAIRS + pair;                     // the pair's index in the launch

@@ -5,12 +5,14 @@ name into the two modules that use them (``from tno.mpc.encryption_schemes.utils
 pow_mod`` at distributed_keygen.py:35 and paillier_shared_key.py:20; call sites
 distributed_keygen.py:1094, 1097 and paillier_shared_key.py:50, 90, 92).  This module offers the same
 two operators with the same argument order and result — a Python int, the canonical residue — plus
-the batched forms the patched call sites use.  A scalar call is a one-element launch (39 ms at
-key_length 2048): the scalar forms exist so that the leaf itself can be rebound
-(``patch.install(leaf=True)``), the batched forms are what makes the GPU worthwhile.
+the batched forms the patched call sites use.  A scalar call is a one-element launch (a generic-modulus
+modexp; the N^2 partial decryption has its own 15 ms latency path): the scalar forms
+exist so that the leaf itself can be rebound (``patch.install(leaf=True)``), the batched forms are what
+makes the GPU worthwhile.
 
 Moduli must be odd and >= 3 (N, N^2 and the Shamir prime all are): the engine's arithmetic is
-Montgomery arithmetic, and there is no CPU path to fall through to.
+Montgomery arithmetic, and there is no CPU path inside this package to fall through to
+(``patch.install(leaf=True)`` sends such moduli to the function the reference had bound before).
 """
 
 from __future__ import annotations

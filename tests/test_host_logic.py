@@ -264,7 +264,7 @@ def test_c_abi_status_codes_without_gpu():
     assert lib.mx_combine(fake, fake, fake, p(mod), p(mod), 8, 8, 3, 4, fake, 1 << 30, None) == -1       # rows too narrow for N^2
     assert lib.mx_biprime_verdict(fake, fake, p(even), 8, 3, 1, 40, fake, 1 << 30, None) == -3
     assert lib.mx_jacobi(fake, fake, p(even), 8, 1, 4, fake, 1 << 30, None) == -3
-    assert lib.mx_jacobi(fake, fake, p(mod), 130, 1, 4, fake, 1 << 30, None) == -2
+    assert lib.mx_jacobi(fake, fake, p(mod), 258, 1, 4, fake, 1 << 30, None) == -2
     assert lib.mx_mulmod_shared(fake, fake, fake, p(even), 8, 4, fake, 1 << 30, None) == -3
     assert lib.mx_set_limbs_per_lane(7) == -1 and lib.mx_set_limbs_per_lane(0) == 0
     assert lib.mx_sieve_workspace_bytes(65, 302) > 0 and lib.mx_combine_workspace_bytes(65, 129, 3, 10) > 0
