@@ -20,12 +20,14 @@ def main():
     ap.add_argument("--parties", type=int, default=3)
     ap.add_argument("--cands", type=int, default=1024)
     ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--limbs-per-lane", type=int, default=0, help="lane geometry 9|18, 0 = the library's choice")
     args = ap.parse_args()
     import torch
     import sympy
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
     eng = Engine()
+    eng.set_limbs_per_lane(args.limbs_per_lane)
     rng = random.Random(args.key_length)
     half = args.key_length // 2
     primes = [int(p) for p in sympy.primerange(3, 2001)]
