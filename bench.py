@@ -247,6 +247,15 @@ def hbm_block(alg_bytes: float, kernel_ms: float, traffic_model, traffic_key: st
 # decryption workload (c3 / c5): partial decryption + share recombination
 # ---------------------------------------------------------------------------------------------------
 _LANE_STREAMS = []
+_SMALL_STREAMS = []
+
+
+def small_stream(torch, k: int):
+    """High-priority streams for the small kernels of lane k (created once per process, like the lane streams)."""
+    while len(_SMALL_STREAMS) <= k:
+        _SMALL_STREAMS.append(torch.cuda.Stream(priority=-1))
+    return _SMALL_STREAMS[k]
+
 
 
 def lane_stream(torch, k: int, nstreams: int):
@@ -292,41 +301,59 @@ class DecryptWorkload:
         self.lanes = []
 
     def make_lanes(self, nstreams: int, dist, world: int) -> None:
+        """One lane per step in flight.  A lane has TWO sets of buffers and a high-priority stream for its
+        recombinations: the recombination of step k reads set A on that stream while the modexp of step k+1
+        already writes set B on the lane's stream (a caller that pipelines decryptions double-buffers the same way),
+        so the 0.5 ms recombination no longer holds up the next 30 ms launch while it waits for wavefront slots."""
         torch, eng = self.torch, self.eng
         self.lanes = []
         for k in range(nstreams):
-            self.lanes.append({
-                "stream": lane_stream(torch, k, nstreams),
-                "partials": self.partials_t if k == 0 else self.partials_t.clone(),
-                "msg": torch.empty((self.batch, self.limbs), dtype=torch.int32, device=eng.device),
-                "status": torch.empty(self.batch, dtype=torch.uint8, device=eng.device),
-                "gathered": torch.empty((world, self.batch, self.limbs2), dtype=torch.int32, device=eng.device) if dist is not None else None,
-            })
+            bufs = []
+            for b in range(2):
+                bufs.append({
+                    "partials": self.partials_t if (k == 0 and b == 0) else self.partials_t.clone(),
+                    "msg": torch.empty((self.batch, self.limbs), dtype=torch.int32, device=eng.device),
+                    "status": torch.zeros(self.batch, dtype=torch.uint8, device=eng.device),
+                    "gathered": torch.empty((world, self.batch, self.limbs2), dtype=torch.int32, device=eng.device) if dist is not None else None,
+                    "work": None, "done": None,
+                })
+            self.lanes.append({"stream": lane_stream(torch, k, nstreams), "hp": small_stream(torch, k), "bufs": bufs, "turn": 0})
         torch.cuda.synchronize()
 
     def step(self, k: int, dist) -> None:
         ln = self.lanes[k % len(self.lanes)]
-        eng = self.eng
-        with self.torch.cuda.stream(ln["stream"]):
-            if ln.get("work") is not None:       # the all-gather of this lane's previous step must have read its rows
-                ln["work"].wait()
-                ln["work"] = None
+        buf = ln["bufs"][ln["turn"]]
+        ln["turn"] ^= 1
+        eng, torch = self.eng, self.torch
+        with torch.cuda.stream(ln["stream"]):
+            if buf["done"] is not None:          # the recombination that read this set two steps ago
+                ln["stream"].wait_event(buf["done"])
+            if buf["work"] is not None:          # the all-gather that read this set's rows
+                buf["work"].wait()
+                buf["work"] = None
             if self.generic:
-                eng.powmod_shared_t(self.own_in_t, self.n2, self.own_exp, out_t=ln["partials"][self.own_slot])
+                eng.powmod_shared_t(self.own_in_t, self.n2, self.own_exp, out_t=buf["partials"][self.own_slot])
             else:
-                eng.powmod_nsquare_t(self.own_in_t, self.n, self.own_exp, out_t=ln["partials"][self.own_slot])
+                eng.powmod_nsquare_t(self.own_in_t, self.n, self.own_exp, out_t=buf["partials"][self.own_slot])
             if dist is not None:
-                # the one exchange step of the path, on RCCL's own stream: the recombination below needs only this
-                # rank's rows, so it and the next step's launches run beside the gather (waited for when the lane is reused)
-                ln["work"] = dist.all_gather_into_tensor(ln["gathered"].view(-1), ln["partials"][self.own_slot].reshape(-1), async_op=True)
-            eng.combine_t(ln["partials"], self.n, self.theta_inv, out_t=ln["msg"], status_t=ln["status"])
+                # the one exchange step of the path, on RCCL's own stream: the recombination needs only this rank's
+                # rows, so it and the next step's launches run beside the gather (waited for when the set is reused)
+                buf["work"] = dist.all_gather_into_tensor(buf["gathered"].view(-1), buf["partials"][self.own_slot].reshape(-1), async_op=True)
+            ready = torch.cuda.Event()
+            ready.record(ln["stream"])
+        with torch.cuda.stream(ln["hp"]):
+            ln["hp"].wait_event(ready)
+            eng.combine_t(buf["partials"], self.n, self.theta_inv, out_t=buf["msg"], status_t=buf["status"])
+            buf["done"] = torch.cuda.Event()
+            buf["done"].record(ln["hp"])
 
     def verify(self, check: int, rank: int, dist) -> str:
         L, eng = self.L, self.eng
         for ln in self.lanes:
-            assert int(ln["status"].sum().item()) == 0, "share recombination flagged ciphertexts as inconsistent"
+            for buf in ln["bufs"]:
+                assert int(buf["status"].sum().item()) == 0, "share recombination flagged ciphertexts as inconsistent"
         if dist is not None:
-            assert self.torch.equal(self.lanes[0]["gathered"][rank], self.partials_t[self.own_slot]), "all-gather shard mismatch"
+            assert self.torch.equal(self.lanes[0]["bufs"][0]["gathered"][rank], self.partials_t[self.own_slot]), "all-gather shard mismatch"
         if check <= 0:
             return "skipped"
         # spot check with CPython big-int arithmetic (the definition of the reference's pow_mod /
@@ -334,7 +361,7 @@ class DecryptWorkload:
         batch, n, n2 = self.batch, self.n, self.n2
         idx = [0, batch - 1] + [(k * 7919) % batch for k in range(1, max(1, check - 1))]
         rows = eng.to_host(self.partials_t[self.own_slot][idx])
-        msgs = L.unpack(eng.to_host(self.lanes[0]["msg"][idx]))
+        msgs = L.unpack(eng.to_host(self.lanes[0]["bufs"][0]["msg"][idx]))
         allp = [L.unpack(eng.to_host(self.partials_t[k][idx])) for k in range(len(self.parties))]
         for j, e in enumerate(idx):
             base = self.cts[e] if self.exps[self.own] >= 0 else pow(self.cts[e], -1, n2)
@@ -451,7 +478,7 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
     lpl, wpg = pick_decrypt_shape(eng, args, wl.n.bit_length(), batch, nstreams)
     eng.set_limbs_per_lane(lpl)
     eng.set_wavefronts_per_group(wpg)
-    eng.set_priority_aux(nstreams > 1)          # the recombination does not queue behind the other lanes' modexp launches
+    eng.set_priority_aux(False)                 # the lanes run their recombinations on their own high-priority streams (make_lanes)
     wl.make_lanes(nstreams, dist, world)
     elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), args.steps, args.warmup, nstreams)
     assert launches == args.steps, (launches, args.steps)
