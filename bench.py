@@ -91,6 +91,9 @@ def parse() -> argparse.Namespace:
                     help="lane geometry 3|9|18; 0 / default = the library's choice for the launches in flight taken together")
     ap.add_argument("--wavefronts-per-group", type=int, default=0,
                     help="c3/c5 pair kernel: 1 | 2 wavefronts per group of elements, 0 = the library's choice")
+    ap.add_argument("--cu-slices", type=int, default=-1,
+                    help="c3/c5: 1 = every step in flight on a stream confined to its own slice of the CUs, 0 = ordinary streams, "
+                         "-1 = slices when the launches in flight fit the chip side by side at one wavefront per SIMD")
     ap.add_argument("--segments", type=int, default=0,
                     help="c3/c5: launches per exponentiation (mx_powmod_nsquare_run), 0 = the library's choice")
     ap.add_argument("--generic-modulus", action="store_true",
@@ -300,8 +303,9 @@ class DecryptWorkload:
         self.theta_inv = key.theta_inv
         self.lanes = []
 
-    def make_lanes(self, nstreams: int, dist, world: int) -> None:
-        """One lane per step in flight.  A lane has TWO sets of buffers and a high-priority stream for its
+    def make_lanes(self, nstreams: int, dist, world: int, cu_slices: bool = False) -> None:
+        """One lane per step in flight (with `cu_slices` each lane's stream is confined to its own slice of the compute
+        units, Engine.cu_slice_streams: for launches so small that several of them fit the chip side by side).  A lane has TWO sets of buffers and a high-priority stream for its
         recombinations: the recombination of step k reads set A on that stream while the modexp of step k+1
         already writes set B on the lane's stream (a caller that pipelines decryptions double-buffers the same way),
         so the 0.5 ms recombination no longer holds up the next 30 ms launch while it waits for wavefront slots."""
@@ -317,7 +321,8 @@ class DecryptWorkload:
                     "gathered": torch.empty((world, self.batch, self.limbs2), dtype=torch.int32, device=eng.device) if dist is not None else None,
                     "work": None, "done": None,
                 })
-            self.lanes.append({"stream": lane_stream(torch, k, nstreams), "hp": small_stream(torch, k), "bufs": bufs, "turn": 0})
+            stream = eng.cu_slice_streams(nstreams)[k] if cu_slices else lane_stream(torch, k, nstreams)
+            self.lanes.append({"stream": stream, "hp": small_stream(torch, k), "bufs": bufs, "turn": 0})
         torch.cuda.synchronize()
 
     def step(self, k: int, dist) -> None:
@@ -479,7 +484,14 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
     eng.set_limbs_per_lane(lpl)
     eng.set_wavefronts_per_group(wpg)
     eng.set_priority_aux(False)                 # the lanes run their recombinations on their own high-priority streams (make_lanes)
-    wl.make_lanes(nstreams, dist, world)
+    # Launches that fit a 1/nstreams slice of the chip at one wavefront per SIMD: the dispatcher would stack them on the
+    # same CUs of every XCD, so every lane gets its own CUs (same range in every XCD) instead.
+    cu_slices = False
+    if not args.generic_modulus and 2 <= nstreams <= 8 and args.cu_slices != 0:
+        k_, _, _, _, w_ = eng.nsquare_launch_shape(wl.n.bit_length(), batch)
+        waves = -(-batch // (64 // k_)) * w_
+        cu_slices = args.cu_slices == 1 or waves * nstreams <= 1024
+    wl.make_lanes(nstreams, dist, world, cu_slices=cu_slices)
     elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), args.steps, args.warmup, nstreams)
     assert launches == args.steps, (launches, args.steps)
     note = wl.verify(args.check if rank == 0 else 0, rank, dist)
@@ -499,6 +511,7 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
             "batch_per_gpu": batch, "mod_bits": wl.n2.bit_length(), "exp_bits": wl.own_exp.bit_length(),
             "limbs_u32": wl.limbs2, "party": wl.own, "parallelism": f"dp{world}", "steps_in_flight": nstreams,
             "geometry_K_L_W_blocks": list(geo[:4]), "wavefronts_per_group": geo[4] if len(geo) > 4 else 1,
+            "cu_slices": cu_slices,
             "algorithm": "Montgomery modulo N^2" if args.generic_modulus else "N-adic pairs, two Montgomery passes modulo N per product",
             "call_path": "per-key plan (mx_powmod_nsquare_prepare once) + mx_powmod_nsquare_run + mx_combine_run per step",
             "segments_per_exponentiation": args.segments or "library default (4 for long exponents on large batches)",

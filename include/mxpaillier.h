@@ -285,6 +285,15 @@ int mx_debug_knob(int knob, int value);
  * decides whether chunks of a batch launched on those streams fill the machine together or serialise
  * (GPU_MAX_HW_QUEUES is read once when the runtime initialises and cannot be queried).  Never synchronises. */
 int mx_spin(int64_t microseconds, void* stream);
+/* Streams confined to a slice of the compute units, for callers that keep several SMALL launches in flight: the
+ * dispatcher places concurrent launches of a few dozen workgroups each on the same CUs of every XCD (four 64-workgroup
+ * launches on four ordinary streams ran 1.7x longer than one of them alone), while launches on streams whose CU
+ * masks are disjoint each get their own part of the chip.  Slice k of n is the same CU range [k*CUs/n, (k+1)*CUs/n) of
+ * the mask in EVERY XCD (mask bit i = CU i/8 of XCD i%8 on MI355X; a mask that empties an XCD is ignored by the
+ * runtime), n <= 8.  The stream belongs to the caller (mx_stream_destroy).  Not for launches that fill the machine
+ * on their own: a static partition cannot balance load. */
+int mx_stream_create_cu_slice(int slice, int n_slices, int reserved, void** stream_out);
+int mx_stream_destroy(void* stream);
 /* Enqueues a kernel of ONE wavefront that idles for `microseconds` and writes two counters to d_ticks[0..1]: the
  * advance of the shader clock counter and of the 100 MHz real-time counter over that interval; their ratio x 100 MHz
  * is the clock the SIMDs run at under the load that is in flight at that moment (MI355X drops from its nominal

@@ -81,6 +81,8 @@ SYMBOLS = {
     "mx_debug_knob": (c_int, [c_int, c_int]),
     "mx_spin": (c_int, [c_int64, c_void_p]),
     "mx_clock_probe": (c_int, [c_int64, c_void_p, c_void_p]),
+    "mx_stream_create_cu_slice": (c_int, [c_int, c_int, c_int, POINTER(c_void_p)]),
+    "mx_stream_destroy": (c_int, [c_void_p]),
     "mx_geometry": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int)]),
     "mx_profile": (c_int, [c_int]),
     "mx_profile_collect": (c_int, [POINTER(ctypes.c_double), POINTER(c_int)]),

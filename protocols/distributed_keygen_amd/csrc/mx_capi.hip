@@ -377,6 +377,31 @@ int mx_spin(int64_t microseconds, void* stream) {
   return MX_OK;
 }
 
+int mx_stream_create_cu_slice(int slice, int n_slices, int reserved, void** stream_out) {
+  // CU mask bit i is CU (i / n_xcd) of XCD (i % n_xcd) (tools/ubench/cu_mask_probe.hip: 32 consecutive bits = 4 CUs
+  // in each of the 8 XCDs; a mask that leaves an XCD without any CU is ignored by the runtime).  A slice is a
+  // contiguous range of bits: the same CUs of every XCD.
+  if (!stream_out || n_slices < 1 || slice < 0 || slice >= n_slices) return MX_ERR_ARG;
+  int dev = 0, cus = 0;
+  MX_HIP(hipGetDevice(&dev));
+  MX_HIP(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+  if (cus < 32 * n_slices || n_slices > 8) return MX_ERR_ARG;      // at least 4 CUs per XCD and slice
+  const int per = cus / n_slices, lo = slice * per, hi = slice == n_slices - 1 ? cus : lo + per;
+  std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+  for (int i = lo; i < hi; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+  hipStream_t s = nullptr;
+  (void)reserved;
+  MX_HIP(hipExtStreamCreateWithCUMask(&s, (uint32_t)mask.size(), mask.data()));
+  *stream_out = (void*)s;
+  return MX_OK;
+}
+
+int mx_stream_destroy(void* stream) {
+  if (!stream) return MX_ERR_ARG;
+  MX_HIP(hipStreamDestroy((hipStream_t)stream));
+  return MX_OK;
+}
+
 int mx_clock_probe(int64_t microseconds, uint64_t* d_ticks, void* stream) {
   if (microseconds <= 0 || microseconds > 1000000 || !d_ticks) return MX_ERR_ARG;
   hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (unsigned long long)microseconds * 100ull,

@@ -177,6 +177,24 @@ class Engine:
         ids = {"n2_segments": 1, "jacobi_max_batches": 2}
         _lib.check(self.lib.mx_debug_knob(ids[knob], int(value)), "mx_debug_knob")
 
+    def cu_slice_streams(self, n: int) -> List[Any]:
+        """`n` streams (2..8) whose kernels are confined to disjoint slices of the compute units — the same CU range
+        in every XCD (mx_stream_create_cu_slice) — as torch streams.  For callers that keep several SMALL launches in
+        flight (each fitting its slice at about one wavefront per SIMD): on ordinary streams the dispatcher stacks
+        them on the same CUs.  Created once per engine and n; they live as long as the engine."""
+        import ctypes
+
+        cache = self.__dict__.setdefault("_cu_streams", {})
+        if n not in cache:
+            out = []
+            with self.torch.cuda.device(self.device):
+                for k in range(n):
+                    ptr = ctypes.c_void_p()
+                    _lib.check(self.lib.mx_stream_create_cu_slice(k, n, 0, ctypes.byref(ptr)), "mx_stream_create_cu_slice")
+                    out.append(self.torch.cuda.ExternalStream(ptr.value, device=self.device))
+            cache[n] = out
+        return cache[n]
+
     def clock_probe_start(self, microseconds: int = 300):
         """Enqueue a shader-clock probe (mx_clock_probe) on a high-priority stream of its own, so that it runs
         beside whatever the other streams have in flight; returns a handle for clock_probe_mhz."""

@@ -607,3 +607,30 @@ def test_combine_columns_with_unreduced_peer_values(eng, golden_decrypt_synth):
     cols[2] = [codec.encode_int(v + 2 * n2) if k % 2 else v + n2 for k, v in enumerate(cols[2])]
     msgs, ok = eng.combine_columns(cols, n, theta_inv)
     assert all(ok) and msgs == want
+
+
+def test_cu_slice_streams_run_small_launches_side_by_side(eng):
+    """Engine.cu_slice_streams: launches on streams confined to disjoint slices of the CUs give the same results
+    as on ordinary streams (four small N^2 modexp launches in flight, no host synchronisation in between)."""
+    import torch
+
+    from protocols.distributed_keygen_amd import limbs as L
+
+    rng = random.Random(4242)
+    n = rng.getrandbits(1027) | (1 << 1026) | 1
+    n2 = n * n
+    e = rng.getrandbits(500) | 1
+    bases = [rng.randrange(n2) for _ in range(200)]
+    rows = eng.to_device(L.pack(bases, L.limbs_for(n2)))
+    streams = eng.cu_slice_streams(4)
+    assert len(streams) == 4 and len({int(s.cuda_stream) for s in streams}) == 4
+    assert eng.cu_slice_streams(4) is streams                       # created once per engine
+    torch.cuda.synchronize()
+    outs = []
+    for k in range(8):
+        with torch.cuda.stream(streams[k % 4]):
+            outs.append(eng.powmod_nsquare_t(rows, n, e))
+    torch.cuda.synchronize()
+    want = [pow(b, e, n2) for b in bases]
+    for out in outs:
+        assert L.unpack(eng.to_host(out)) == want

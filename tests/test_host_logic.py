@@ -267,6 +267,15 @@ def test_c_abi_status_codes_without_gpu():
     assert lib.mx_jacobi(fake, fake, p(mod), 258, 1, 4, fake, 1 << 30, None) == -2
     assert lib.mx_mulmod_shared(fake, fake, fake, p(even), 8, 4, fake, 1 << 30, None) == -3
     assert lib.mx_set_limbs_per_lane(7) == -1 and lib.mx_set_limbs_per_lane(0) == 0
+    # developer knobs, probes and CU-slice streams: argument checks come before any HIP call
+    import ctypes
+
+    assert lib.mx_debug_knob(99, 1) == -1 and lib.mx_debug_knob(1, 65) == -1 and lib.mx_debug_knob(2, -1) == -1
+    assert lib.mx_debug_knob(1, 0) == 0 and lib.mx_debug_knob(2, 0) == 0
+    assert lib.mx_spin(-1, None) == -1 and lib.mx_clock_probe(0, fake, None) == -1 and lib.mx_clock_probe(10, None, None) == -1
+    sp = ctypes.c_void_p()
+    assert lib.mx_stream_create_cu_slice(4, 4, 0, ctypes.byref(sp)) == -1 and lib.mx_stream_create_cu_slice(0, 0, 0, ctypes.byref(sp)) == -1
+    assert lib.mx_stream_create_cu_slice(0, 4, 0, None) == -1 and lib.mx_stream_destroy(None) == -1
     assert lib.mx_sieve_workspace_bytes(65, 302) > 0 and lib.mx_combine_workspace_bytes(65, 129, 3, 10) > 0
     assert lib.mx_verdict_workspace_bytes(65, 3, 10, 40) > 0 and lib.mx_jacobi_workspace_bytes(65, 10) > 0
     assert lib.mx_mulmod_workspace_bytes(129) > 0
