@@ -956,7 +956,7 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
         for py in ("/opt/conda/bin/python3.9", sys.executable):
             if os.path.exists(py):
                 try:
-                    r = subprocess.run([py, script, path], capture_output=True, text=True, timeout=180)
+                    r = subprocess.run([py, script, path], capture_output=True, text=True, timeout=75)
                     if r.returncode == 0 and r.stdout.strip():
                         res = json.loads(r.stdout.strip().splitlines()[-1])
                         break
@@ -1098,7 +1098,7 @@ def main() -> None:
 
                     out["extra"]["biprime_k2048"] = guarded("biprime_k2048", lambda: biprime_leg(2048, 4096, 8, True))
                     # configs[1]: key_length 1024, at the size of a keygen round's survivors and at a saturating size
-                    out["extra"]["biprime_k1024_c256"] = guarded("biprime_k1024_c256", lambda: biprime_leg(1024, 256, 8, True))
+                    out["extra"]["biprime_k1024_c256"] = guarded("biprime_k1024_c256", lambda: biprime_leg(1024, 256, 8, False))
                     out["extra"]["biprime_k1024_c8192"] = guarded("biprime_k1024_c8192", lambda: biprime_leg(1024, 8192, 6, False))
                     # configs[4]: the sweep points of key_length 4096
                     out["extra"]["c5_k4096"] = guarded("c5_k4096", lambda: c5_leg(4096, 8, 4, True))

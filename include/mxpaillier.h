@@ -14,7 +14,8 @@
  *     element e occupies words [e*limbs, (e+1)*limbs).  This is `int.to_bytes(4*limbs,"little")`.
  *   - d_* pointers are DEVICE pointers (e.g. torch.Tensor.data_ptr()), h_* are HOST pointers.
  *   - The caller owns every buffer, including the workspace; the library allocates nothing that
- *     outlives a call.  All work is enqueued on `stream` (a hipStream_t, NULL = default stream);
+ *     outlives a call (the one exception is explicit: mx_stream_create_cu_slice hands out a stream that
+ *     the caller destroys), keeps no state between calls and reads no environment variable.  All work is enqueued on `stream` (a hipStream_t, NULL = default stream);
  *     calls return after enqueueing and NEVER synchronise the stream or the device.  Host arrays
  *     (h_*) travel by value in kernel-argument blocks and may be freed/reused on return; operand
  *     sets of thousands of moduli should use the *_dev entry points (device-resident operands).

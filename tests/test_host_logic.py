@@ -29,7 +29,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    assert lib.mx_version() >= 100
+    assert lib.mx_version() == 300          # ABI 3.0: mx_powmod_nsquare_run gained wavefronts_per_group, mx_nsquare_plan.geometries
     assert lib.mx_error_string(-3).decode().startswith("modulus")
 
 
