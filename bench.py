@@ -533,13 +533,16 @@ def leg_single_batch(eng, torch, wl: DecryptWorkload, key_length: int) -> dict:
     steps = 6
     elapsed, kernel_ms, _ = time_steps(eng, torch, None, lambda k: wl.step(k, None), steps, 1, 1)
     geo = eng.nsquare_launch_shape(wl.n.bit_length(), wl.batch)
+    sliced = eng.nsquare_launch_timesliced(wl.n.bit_length(), wl.batch)
     eng.set_limbs_per_lane(saved[0])
     eng.set_wavefronts_per_group(saved[1])
     waves = -(-wl.batch // (64 // geo[0])) * geo[4]
     return {"value": wl.batch * steps / elapsed, "unit": "modexps/s", "steps": steps, "ms_per_step": elapsed / steps * 1e3,
             "kernel_ms": kernel_ms, "geometry_K_L_W_blocks": list(geo[:4]), "wavefronts_per_group": geo[4],
+            "time_sliced": {"resident_workgroups_per_cu": sliced[0], "units_per_group": sliced[1]} if sliced[0] else None,
             "shader_clock_mhz_measured": CLOCK["mhz"],
-            "note": f"one {wl.batch}-ciphertext launch at a time: {waves} wavefronts for 1024 SIMDs"}
+            "note": f"one {wl.batch}-ciphertext launch at a time: {waves} wavefronts for 1024 SIMDs"
+                    + (f", time-sliced over {sliced[0]} resident workgroups per CU" if sliced[0] else "")}
 
 
 def leg_latency(eng, torch, wl: DecryptWorkload, single_core_rate) -> dict:

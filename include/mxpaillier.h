@@ -119,7 +119,10 @@ int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* 
  * segments of run: the exponentiation is enqueued as this many consecutive launches, each executing a
  * stretch of the tape (the accumulator travels through the workspace); a wavefront then lives
  * 1/segments as long, which is the grain at which a burst of launches on several streams drains.
- * 1..64, 0 = automatic (4 for long exponents on large batches, else 1).  Same result bit for bit. */
+ * 1..64, 0 = automatic (4 for long exponents on large batches, else 1).  Same result bit for bit.
+ * A two-wavefront launch with somewhat more groups of elements than the GPU holds at once runs in the time-sliced
+ * form (mx_nsquare_launch_timesliced): ONE launch of resident workgroups whose wavefront pairs take the segments of
+ * all groups from a queue kept in the workspace; `segments` (at most 16 then) is the number of units per group. */
 typedef struct mx_nsquare_plan {
   const void* d_plan;     /* device block written by prepare */
   int64_t plan_bytes;
@@ -276,9 +279,13 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
 /* Developer overrides, explicit calls only (the library reads no environment variables).  value 0 restores
  * the default.  MX_KNOB_N2_SEGMENTS: launches per mx_powmod_nsquare_run exponentiation when the caller passes
  * segments = 0 (1..64).  MX_KNOB_JACOBI_MAX_BATCHES: value v > 0 limits the Jacobi kernel to v - 1 divstep batches
- * so that its fallback kernel has to finish the symbols (test knob for the safety net).  Process-wide; returns MX_OK / MX_ERR_ARG. */
+ * so that its fallback kernel has to finish the symbols (test knob for the safety net).  MX_KNOB_N2_TIMESLICE: the
+ * time-sliced form of two-wavefront launches (resident workgroups that share the groups of elements segment by
+ * segment): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
+ * workgroups per CU (r = 1..3).  Process-wide; returns MX_OK / MX_ERR_ARG. */
 #define MX_KNOB_N2_SEGMENTS 1
 #define MX_KNOB_JACOBI_MAX_BATCHES 2
+#define MX_KNOB_N2_TIMESLICE 3
 int mx_debug_knob(int knob, int value);
 /* Enqueues a kernel of ONE wavefront that idles for `microseconds` (0..1 000 000) on `stream` and touches no
  * memory.  A concurrency probe: two streams that the HIP runtime has mapped to the same hardware queue run
@@ -326,6 +333,13 @@ int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_lane, int* 
 int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                             int* lanes_per_element, int* limbs_per_lane_out, int* limb_bits, int* blocks,
                             int* wavefronts_per_group_out);
+/* Whether mx_powmod_nsquare_run runs this launch in the time-sliced form of the two-wavefront kernel: a fixed number
+ * of resident workgroups per CU that take (segment, group of elements) units from a queue in the workspace, chosen
+ * when a lone launch has somewhat more groups than the GPU holds at once (e.g. 10 000 ciphertexts at key_length
+ * 2048: 47 ms instead of 54).  *resident_per_cu = 0: the plain launch; otherwise the workgroups per CU and
+ * *units_per_group the segments each group is cut into when run is called with segments = 0. */
+int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
+                                 int* resident_per_cu, int* units_per_group);
 int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* lanes_per_element,
                            int* limbs_per_lane_out, int* limb_bits, int* blocks);
 

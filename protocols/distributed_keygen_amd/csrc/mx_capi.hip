@@ -17,6 +17,7 @@ namespace mxh {
 thread_local hipError_t g_last_hip = hipSuccess;
 int g_limbs_per_lane = 0;
 int g_knob_n2_segments = 0;
+int g_knob_n2_timeslice = 0;
 int g_knob_jacobi_max_batches = 0;
 }
 MxProfile g_mx_profile;
@@ -270,6 +271,7 @@ int mx_debug_knob(int knob, int value) {
   if (value < 0) return MX_ERR_ARG;
   switch (knob) {
     case MX_KNOB_N2_SEGMENTS: if (value > 64) return MX_ERR_ARG; g_knob_n2_segments = value; return MX_OK;
+    case MX_KNOB_N2_TIMESLICE: if (value > 2 && (value < 17 || value > 19)) return MX_ERR_ARG; g_knob_n2_timeslice = value; return MX_OK;
     case MX_KNOB_JACOBI_MAX_BATCHES: g_knob_jacobi_max_batches = value; return MX_OK;
   }
   return MX_ERR_ARG;

@@ -11,6 +11,8 @@ struct N2Shape {
   int64_t nblocks = 0, nlanes = 0;
   int nslots = 0;
   int64_t table_bytes = 0;
+  int64_t groups = 0;          // groups of elements (one per wavefront or pair of wavefronts)
+  int64_t sched_bytes = 0;     // scheduling words of the time-sliced form, behind the table in the workspace
 };
 
 // limbs_per_lane values of the pair kernel: 9 and 18 in both forms (one or two wavefronts per group of
@@ -30,6 +32,8 @@ inline int max_lanes(int lpl, int wpg) {
   return wpg == 2 ? 64 : 0;                 // L = 3 exists as a split kernel only
 }
 
+constexpr int N2_TIMESLICE_MAX_SEGMENTS = 16;      // units per group of a time-sliced launch, at most
+
 bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg, N2Shape& p) {
   if (geo_index(limbs_per_lane) < 0 || (wpg != 1 && wpg != 2)) return false;
   if (!choose_geometry(n_bits, p.geo, limbs_per_lane)) return false;
@@ -39,6 +43,8 @@ bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg
   p.nlanes = p.nblocks * 64 * (wpg == 2 ? mx::N2_SPLIT_PAIRS : 1);
   p.nslots = mx::N2_SLOT_TABLE + (1 << (window - 1));
   p.table_bytes = align256((int64_t)p.nslots * 2 * p.geo.L * p.nlanes * 4);
+  p.groups = (batch + 64 / p.geo.K - 1) / (64 / p.geo.K);
+  p.sched_bytes = wpg == 2 ? align256((2 + p.groups * (N2_TIMESLICE_MAX_SEGMENTS - 1)) * 4) : 0;
   return true;
 }
 
@@ -55,13 +61,17 @@ int launch_n2_kl(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
 // mx_capi_n2sw.hip (L = 18): translation units of their own, built in parallel
 namespace mxw { int launch_n2_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s); }
 namespace mxs {
-int launch_n2_split(int K, int L, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
-int launch_n2_split_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
+int launch_n2_split(int K, int L, bool timesliced, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
+int launch_n2_split_wide(int K, bool timesliced, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
 }
 namespace {
-int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t s) {
+int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t s, int64_t timesliced_blocks = 0) {
   const int K = p.geo.K, L = p.geo.L;
-  if (wpg == 2) return L == LIMBS_PER_LANE_WIDE ? mxs::launch_n2_split_wide(K, a, p.nblocks, s) : mxs::launch_n2_split(K, L, a, p.nblocks, s);
+  if (wpg == 2) {
+    const bool ts = timesliced_blocks > 0;
+    const int64_t nb = ts ? timesliced_blocks : p.nblocks;
+    return L == LIMBS_PER_LANE_WIDE ? mxs::launch_n2_split_wide(K, ts, a, nb, s) : mxs::launch_n2_split(K, L, ts, a, nb, s);
+  }
   if (L == LIMBS_PER_LANE_WIDE) return mxw::launch_n2_wide(K, a, p.nblocks, s);
   switch (K) {
     case 1: return launch_n2_kl<1, LIMBS_PER_LANE>(a, p.nblocks, s);
@@ -92,7 +102,9 @@ int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t 
 // fills the machine on its own (from ~24 000).  Callers that keep several launches in flight fill the machine
 // between them and should say so by passing limbs_per_lane = 18, wavefronts_per_group = 1 (bench.py's
 // steady-state leg does).
-struct N2Choice { int lpl, wpg; };
+// units per group of a time-sliced launch of r workgroups per CU unless the caller says
+inline int n2_timeslice_segments(int resident) { return resident == 1 ? 8 : 2; }
+struct N2Choice { int lpl, wpg, resident; };      // resident: workgroups per CU of the time-sliced form, 0 = plain launch
 int device_cus() {
   static const int cus = [] {
     int dev = 0, n = 0;
@@ -101,7 +113,8 @@ int device_cus() {
   }();
   return cus;
 }
-double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg) {
+double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = nullptr) {
+  if (resident) *resident = 0;
   N2Shape p;
   if (!shape_n2(n_bits, 1, batch, lpl, wpg, p)) return -1.0;
   const double L = p.geo.L, steps = (double)p.geo.nblk * p.geo.L;
@@ -112,23 +125,57 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg) {
   const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
   const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;
   auto round = [&](int64_t r) { return r <= 0 ? 0.0 : alone + (double)(r - 1) * shared; };
-  if (per_simd <= fit) return round(per_simd);          // everything resident at once: the fullest SIMD bounds the launch
-  // more wavefronts than fit: the launch streams through full SIMDs at the rate of a full round
-  const double per_simd_mean = wpg == 2 ? (double)p.nblocks / cus : (double)p.nblocks / (4.0 * cus);
-  return per_simd_mean / (double)fit * round(fit);
+  double plain;
+  if (per_simd <= fit) {
+    plain = round(per_simd);          // everything resident at once: the fullest SIMD bounds the launch
+  } else if (fit <= 2) {
+    // two per SIMD at most (L = 18): whole rounds — 3 per SIMD measured as a round of 2 plus 0.9 of a round of 1
+    plain = (double)(per_simd / fit) * round(fit) + 0.9 * round(per_simd % fit);
+  } else {
+    // more wavefronts than fit: the launch streams through full SIMDs at the rate of a full round
+    const double per_simd_mean = wpg == 2 ? (double)p.nblocks / cus : (double)p.nblocks / (4.0 * cus);
+    plain = per_simd_mean / (double)fit * round(fit);
+  }
+  // Time-sliced form (mx_powmod_n2_split.hpp; instances: 9 limbs per lane, groups of at most 16 lanes): r workgroups
+  // per CU stay resident and take the groups' segments from a queue.  Measured over r = 1..3 and 2..8 segments at
+  // key_length 2048 and 4096 (tools/ts_probe.py, profiles/r03_ts_probe_*.txt), two settings pay:
+  //   r = 2 with 2 segments: the launch costs groups / resident pairs x a full launch of 2 per SIMD (when a wavefront
+  //     runs out of work its neighbour speeds up, so the coarse grain costs nothing) — 44-47 ms instead of 54 for
+  //     9 200..10 500 ciphertexts at key_length 2048;
+  //   r = 1 with 8 segments, for launches just above one workgroup per CU (up to 1.25x): the fine grain costs ~13 %
+  //     per operation (hand-overs on a SIMD that has nothing else to issue), still 12-23 % below the plain launch.
+  const bool sliceable = wpg == 2 && lpl == LIMBS_PER_LANE && p.geo.K <= 16;
+  if (!sliceable || !resident || g_knob_n2_timeslice == 1) return plain;
+  const bool forced = g_knob_n2_timeslice >= 2;
+  double best = forced ? -1.0 : plain * 0.97;          // a time-sliced launch has to win by 3 %
+  for (int64_t r = 1; r <= 2; ++r) {
+    int64_t rr = r;
+    if (g_knob_n2_timeslice > 16) {               // developer: this many per CU
+      if (r != 1) break;
+      rr = std::min<int64_t>(fit, g_knob_n2_timeslice - 16);
+    }
+    const int64_t pairs = rr * cus * mx::N2_SPLIT_PAIRS;
+    if (p.groups <= pairs && !forced) continue;
+    const double load = std::max(1.0, (double)p.groups / (double)pairs);
+    if (rr == 1 && load > 1.5 && !forced) continue;
+    const double t = load * round(rr) * (rr == 1 ? 1.15 : 1.0);
+    if (best < 0 || t < best) { best = t; *resident = (int)rr; }
+  }
+  return *resident ? best : plain;
 }
 N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
-  N2Choice best{LIMBS_PER_LANE, 1};
+  N2Choice best{LIMBS_PER_LANE, 1, 0};
   double best_t = -1.0;
   for (int l : N2_LPLS) {
     if (limbs_per_lane && l != limbs_per_lane) continue;
     for (int w : {1, 2}) {
       if (wpg && w != wpg) continue;
-      const double t = n2_estimate(n_bits, batch, l, w);
-      if (t > 0 && (best_t < 0 || t < best_t)) { best_t = t; best = N2Choice{l, w}; }
+      int resident = 0;
+      const double t = n2_estimate(n_bits, batch, l, w, &resident);
+      if (t > 0 && (best_t < 0 || t < best_t)) { best_t = t; best = N2Choice{l, w, resident}; }
     }
   }
-  if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1};   // reported as MX_ERR_SIZE by the caller
+  if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1, 0};   // reported as MX_ERR_SIZE by the caller
   return best;
 }
 
@@ -182,6 +229,19 @@ extern "C" int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_
   N2Shape p;
   if (!shape_n2(n_bits, 1, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
   *k = p.geo.K; *l = p.geo.L; *w = p.geo.W; *blocks = p.geo.nblk; *wavefronts = ch.wpg;
+  return MX_OK;
+}
+
+extern "C" int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
+                                            int* resident_per_cu, int* units_per_group) {
+  if (!resident_per_cu || !units_per_group || batch <= 0) return MX_ERR_ARG;
+  if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
+  const N2Choice ch = n2_auto_shape(n_bits, batch, limbs_per_lane, wavefronts_per_group);
+  N2Shape p;
+  if (!shape_n2(n_bits, 1, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
+  *resident_per_cu = ch.resident;
+  *units_per_group = ch.resident ? n2_timeslice_segments(ch.resident) : 0;
   return MX_OK;
 }
 
@@ -292,7 +352,7 @@ extern "C" int64_t mx_powmod_nsquare_run_workspace_bytes(const mx_nsquare_plan* 
   int64_t most = -1;
   for (int l : N2_LPLS) {
     N2Shape p;
-    if (shape_n2(plan->n_bits, plan->window, batch, l, 2, p) && p.table_bytes > most) most = p.table_bytes;
+    if (shape_n2(plan->n_bits, plan->window, batch, l, 2, p) && p.table_bytes + p.sched_bytes > most) most = p.table_bytes + p.sched_bytes;
   }
   return most < 0 ? MX_ERR_SIZE : most;
 }
@@ -312,7 +372,7 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   if (!shape_n2(bits, plan->window, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
   const int gi = geo_index(ch.lpl);
   if (!(plan->geometries & (1 << gi))) return MX_ERR_SIZE;
-  if (p.table_bytes > ws_bytes) return MX_ERR_WORKSPACE;
+  if (p.table_bytes + (ch.resident ? p.sched_bytes : 0) > ws_bytes) return MX_ERR_WORKSPACE;
   if (2 * p.geo.K * p.geo.L + 8 < limbs2 + 2) return MX_ERR_ARG;   // row wider than the staging area
   const int64_t cb = n2_consts_bytes(plan->limbs_n);
   const char* dp = (const char*)plan->d_plan;
@@ -330,6 +390,22 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   if (nseg > plan->n_sqr / 16) nseg = plan->n_sqr / 16;
   if (nseg < 1) nseg = 1;
   MxKernelTimer timer(s);                        // one timed interval per exponentiation (all its segments)
+  if (ch.resident > 0) {
+    // time-sliced: one launch of resident workgroups, the segments are units of its own scheduler
+    nseg = segments > 0 ? segments : n2_timeslice_segments(ch.resident);
+    if (nseg > N2_TIMESLICE_MAX_SEGMENTS) nseg = N2_TIMESLICE_MAX_SEGMENTS;
+    if (nseg > plan->n_sqr / 16) nseg = plan->n_sqr / 16;
+    if (nseg < 1) nseg = 1;
+    a.sched = (u32*)((char*)d_ws + p.table_bytes);
+    a.sched_groups = (int)p.groups; a.sched_segments = nseg; a.sched_n_sqr = plan->n_sqr;
+    a.first = a.last = 1; a.pos_begin = 0; a.pos_end = 0x7FFFFFFF;
+    MX_HIP(hipMemsetAsync(a.sched, 0, (size_t)(2 + p.groups * (nseg - 1)) * 4, s));
+    // no more workgroups than there are groups for their pairs
+    int64_t wgs = (int64_t)ch.resident * device_cus();
+    if (wgs > p.nblocks) wgs = p.nblocks;
+    return launch_n2(a, p, ch.wpg, s, wgs);
+  }
+  a.sched = nullptr; a.sched_groups = a.sched_segments = a.sched_n_sqr = 0;
   for (int sg = 0; sg < nseg; ++sg) {
     a.first = sg == 0;
     a.last = sg == nseg - 1;

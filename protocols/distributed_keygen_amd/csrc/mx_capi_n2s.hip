@@ -4,35 +4,45 @@
 #include "mx_powmod_n2_split.hpp"
 
 namespace mxs {
-template <int K, int L>
-static int launch(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+template <int K, int L, bool TS>
+static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   size_t lds = mx::powmod_n2_split_lds_bytes<K, L>();
   if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, L, LIMB_BITS>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     MX_HIP(attr);
   }
-  hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, L, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
+  hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
 }
+// time-sliced instances exist for 9 limbs per lane and groups of at most 16 lanes (key_length up to 4096): a launch
+// of wider groups that outnumbers the resident wavefronts is better served by more limbs per lane
+template <int K, int L>
+static int launch(bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  if constexpr (L == LIMBS_PER_LANE && K <= 16) {
+    if (ts) return launch_form<K, L, true>(a, nblocks, s);
+  }
+  if (ts) return MX_ERR_SIZE;
+  return launch_form<K, L, false>(a, nblocks, s);
+}
 
 template <int L>
-static int launch_l(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+static int launch_l(int K, bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   switch (K) {
-    case 1: return launch<1, L>(a, nblocks, s);
-    case 2: return launch<2, L>(a, nblocks, s);
-    case 4: return launch<4, L>(a, nblocks, s);
-    case 8: return launch<8, L>(a, nblocks, s);
-    case 16: return launch<16, L>(a, nblocks, s);
-    case 32: return launch<32, L>(a, nblocks, s);
+    case 1: return launch<1, L>(ts, a, nblocks, s);
+    case 2: return launch<2, L>(ts, a, nblocks, s);
+    case 4: return launch<4, L>(ts, a, nblocks, s);
+    case 8: return launch<8, L>(ts, a, nblocks, s);
+    case 16: return launch<16, L>(ts, a, nblocks, s);
+    case 32: return launch<32, L>(ts, a, nblocks, s);
   }
   return MX_ERR_SIZE;
 }
 
-int launch_n2_split(int K, int L, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
-  if (L == 3) return K == 64 ? launch<64, 3>(a, nblocks, s) : launch_l<3>(K, a, nblocks, s);
-  if (L == LIMBS_PER_LANE) return launch_l<LIMBS_PER_LANE>(K, a, nblocks, s);
+int launch_n2_split(int K, int L, bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  if (L == 3) return K == 64 ? launch<64, 3>(ts, a, nblocks, s) : launch_l<3>(K, ts, a, nblocks, s);
+  if (L == LIMBS_PER_LANE) return launch_l<LIMBS_PER_LANE>(K, ts, a, nblocks, s);
   return MX_ERR_SIZE;
 }
 }  // namespace mxs

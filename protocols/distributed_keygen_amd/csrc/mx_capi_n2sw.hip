@@ -4,26 +4,34 @@
 #include "mx_powmod_n2_split.hpp"
 
 namespace mxs {
-template <int K>
-static int launch(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+template <int K, bool TS>
+static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   size_t lds = mx::powmod_n2_split_lds_bytes<K, LIMBS_PER_LANE_WIDE>();
   if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS, TS>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     MX_HIP(attr);
   }
-  hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
+  hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS, TS>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
 }
 
-int launch_n2_split_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+// no time-sliced instances at 18 limbs per lane: measured (tools/ts_probe.py), they cost 10-20 % more per operation
+// than the plain launch (the unit loop pushes the kernel over its 256 registers) and never beat the 9-limb ones
+template <int K>
+static int launch(bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  if (ts) return MX_ERR_SIZE;
+  return launch_form<K, false>(a, nblocks, s);
+}
+
+int launch_n2_split_wide(int K, bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   switch (K) {
-    case 1: return launch<1>(a, nblocks, s);
-    case 2: return launch<2>(a, nblocks, s);
-    case 4: return launch<4>(a, nblocks, s);
-    case 8: return launch<8>(a, nblocks, s);
-    case 16: return launch<16>(a, nblocks, s);
+    case 1: return launch<1>(ts, a, nblocks, s);
+    case 2: return launch<2>(ts, a, nblocks, s);
+    case 4: return launch<4>(ts, a, nblocks, s);
+    case 8: return launch<8>(ts, a, nblocks, s);
+    case 16: return launch<16>(ts, a, nblocks, s);
   }
   return MX_ERR_SIZE;
 }

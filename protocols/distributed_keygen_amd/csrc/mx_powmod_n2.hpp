@@ -63,6 +63,10 @@ struct PowmodN2Args {
   // then lives 1/segments as long, which is the granularity at which a burst of launches drains.
   int pos_begin, pos_end;
   int first, last;    // first segment: input conversion prologue; last segment: output epilogue
+  // persistent (time-sliced) form of the two-wavefront kernel, mx_powmod_n2_split.hpp: scheduling words in device
+  // memory (ticket, finished segments per group), groups of elements, segments per group, squarings of the tape
+  u32* sched;
+  int sched_groups, sched_segments, sched_n_sqr;
 };
 
 template <class M_t>

@@ -30,6 +30,17 @@
 // A/B on one box).  (Swapping the roles of the two wavefronts in every second workgroup a CU receives, so that every
 // SIMD carries the same mix of light and heavy wavefronts, changed nothing measurable: not kept.)
 //
+// PERSISTENT form (time-slicing).  A launch runs at its "one workgroup per CU" time until it needs a second workgroup
+// per CU, then at its "two per CU" time, and so on: 10 000 ciphertexts are 625 workgroups of the
+// L = 9 shape, 2.44 per CU, and cost what 768 would.  In the persistent form the launch has exactly r x CUs
+// workgroups (r = 1, 2 ...), and every pair of wavefronts repeatedly takes the next UNIT of work from a queue in
+// device memory: a unit is one segment (a stretch of the tape, as between the launches of a segmented
+// exponentiation: the accumulator travels through the scratch slot) of one group of elements.  The queue starts
+// with the first segment of every group; the pair that finishes a segment appends the group's next one (release /
+// acquire at agent scope around the slots in device memory), and it is taken — by whichever pair is free, on
+// whichever CU — when its turn comes.  The groups thus share the resident wavefronts in time and the launch costs
+// (groups / resident pairs) x the time of a full CU instead of the next whole multiple.
+//
 // Small-L instances (L = 3: 32 lanes per element at key_length 2048, 64 at 4096) exist only in this form:
 // they are the latency geometry — a limb step costs 2 L multiply-accumulates plus ~10 instructions of
 // quotient / carry handling, so fewer limbs per lane shortens the dependent chain of one element at the
@@ -44,11 +55,13 @@ constexpr int N2_SPLIT_PAIRS = 2;      // wavefront pairs per workgroup (4 wavef
 template <int K, int L>
 constexpr size_t powmod_n2_split_lds_bytes() {
   // per pair: two wavefronts' Montgomery scratch, the two mailbox entries of 2 L words per lane and the two
-  // hand-over counters; one C'
+  // hand-over counters (+ the unit word of the persistent form); one C'
   return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64 + 4) + (size_t)K * L) * 4;
 }
 
-template <int K, int L, int W>
+// Scheduling state of a time-sliced launch in device memory (zeroed by the host before the launch): the work queue
+// described at the unit loop below, 2 + groups x (segments - 1) words.
+template <int K, int L, int W, bool PERSISTENT>
 __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true, false>;          // wavefront-level ordering of the group scratch
   constexpr int S = M_t::S;
@@ -62,16 +75,13 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   const int half = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 1));
   const int pair = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));          // which pair of the workgroup
   const int gw = lane / K;
-  const i64 wave_slot = (i64)blockIdx.x * N2_SPLIT_PAIRS + pair;                     // the pair's index in the launch
-  const i64 elem_raw = wave_slot * GPW + gw;
-  const bool valid = elem_raw < A.batch;
-  const i64 elem = valid ? elem_raw : A.batch - 1;
   constexpr int PAIR_WORDS = 2 * GPW * GROUP_WORDS + 2 * 2 * L * 64 + 4;
   u32* pair_lds = smem + pair * PAIR_WORDS;
   u32* wide = pair_lds + (half * GPW + gw) * GROUP_WORDS;  // this wavefront's scratch of this group
   u32* mbox = pair_lds + 2 * GPW * GROUP_WORDS;             // [2 entries][2 L words][64 lanes]
   u32* produced = mbox + 2 * 2 * L * 64;                    // entries A has handed over / B has taken (this pair)
   u32* consumed = produced + 1;
+  u32* unit_word = produced + 2;                            // persistent form: the unit A has taken for the pair
   if (half == 0 && lane == 0) { *produced = 0; *consumed = 0; }
   u32* cp_lds = smem + N2_SPLIT_PAIRS * PAIR_WORDS;
   auto mb = [&](int entry, int j) -> u32& { return mbox[(entry * 2 * L + j) * 64 + lane]; };
@@ -90,59 +100,9 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
     }
   }
   PairArithT<M_t> P(M, cp_lds);
-  const i64 nlanes = (i64)gridDim.x * N2_SPLIT_PAIRS * 64;
-  u32* slots = A.slots + (wave_slot * 64 + lane);
-  // this wavefront's digit of a pair slot
-  auto slot_at = [&](int slot, int j) -> u32& { return slots[(((i64)slot * 2 + half) * L + j) * nlanes]; };
-  auto slot_other = [&](int slot, int j) -> u32& { return slots[(((i64)slot * 2 + (1 - half)) * L + j) * nlanes]; };
+  __syncthreads();            // C' and the counters are in place (the kernel's only workgroup barrier)
 
-  // ---- prologue: constant pairs and the two halves of x into their slots, every wavefront its own digit
-  if (A.first) {
-    u32 v[L];
-    const int rows[4][3] = {{N2_SLOT_K1, 3, 4}, {N2_SLOT_K2, 5, 6}, {N2_SLOT_ONE, 1, 2}, {N2_SLOT_E, -1, -1}};
-    for (int r = 0; r < 4; ++r) {
-      const int row = rows[r][1 + half];
-      if (row >= 0) {
-        M.load(v, A.consts + (i64)row * A.limbsn, A.limbsn);
-      } else {
-        M.set_small(v, half == 0 ? 1u : 0u);
-      }
-#pragma unroll
-      for (int j = 0; j < L; ++j) slot_at(rows[r][0], j) = v[j];
-    }
-    if (half == 0) {
-      M_t::sync();
-      const u32* src = A.bases + elem * A.limbs2;
-      for (int k = p; k < WIDE; k += K) wide[k] = (k < A.limbs2) ? src[k] : 0u;
-      M_t::sync();
-#pragma unroll
-      for (int j = 0; j < L; ++j) {
-        const int bit = W * (p * L + j);
-        const int room = A.ksplit - bit;                       // bits of this limb that belong to x_lo
-        const u32 lo = room <= 0 ? 0u : extract_field(wide, bit, room < W ? room : W);
-        const int hbit = A.ksplit + bit;
-        const u32 hi = (hbit + W + 32 <= 32 * WIDE) ? extract_field(wide, hbit, W) : 0u;
-        slot_at(N2_SLOT_LO, j) = lo;
-        slot_at(N2_SLOT_HI, j) = hi;
-      }
-    } else {
-#pragma unroll
-      for (int j = 0; j < L; ++j) { slot_at(N2_SLOT_LO, j) = 0; slot_at(N2_SLOT_HI, j) = 0; }
-    }
-  }
-  __syncthreads();            // C', the counters and the prologue's slots are in place (the kernel's only workgroup barrier)
-
-  // ---- the tape (this segment's part of it): acc is THIS wavefront's digit of the accumulator pair
-  u32 acc[L];
-  if (A.first) {
-#pragma unroll
-    for (int j = 0; j < L; ++j) acc[j] = 0;
-  } else {
-#pragma unroll
-    for (int j = 0; j < L; ++j) acc[j] = slot_at(N2_SLOT_CARRY, j);
-  }
-  int pos = 0;                                      // squarings executed by the tape so far
-  u32 seq = 0;                                      // operations handed over so far (the same count in both wavefronts)
+  u32 seq = 0;                                      // entries handed over so far (the same count in both wavefronts)
   // A: after pass 1 of an operation, hand (X0 before it, Q) to B.  B: take them before its pass 2.
   auto send = [&](const u32 (&x0)[L], const u32 (&q)[L]) {
     while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + 2u <= seq) __builtin_amdgcn_s_sleep(2);
@@ -160,125 +120,259 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
     ++seq;
     __hip_atomic_store(consumed, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
   };
-  for (int k = 0; k < A.ntape; ++k) {
-    const u32 word = A.tape[k];
-    const u32 op = word >> 28;
-    const int arg = (int)(word & 0x0FFFFFFFu);
-    if (op == N2_SQR) {
-      const int lo = pos > A.pos_begin ? pos : A.pos_begin;
-      const int hi = pos + arg < A.pos_end ? pos + arg : A.pos_end;
-      for (int s = lo; s < hi; ++s) {
-        u32 q[L];
+  // entries without payload: "everything I stored before this is yours to read" (A -> B)
+  auto send_token = [&]() {
+    while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) + 2u <= seq) __builtin_amdgcn_s_sleep(2);
+    ++seq;
+    __hip_atomic_store(produced, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+  auto receive_token = [&]() {
+    while (__hip_atomic_load(produced, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) <= seq) __builtin_amdgcn_s_sleep(2);
+    ++seq;
+    __hip_atomic_store(consumed, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+  };
+
+  // ---- the units of this pair: one (the launch's segment of its own group) in the plain form.  Time-sliced form:
+  // a work queue in device memory.  Unit = (segment, group), numbered segment-major; the first `groups` entries of
+  // the queue are the first segments of all groups (implicit), every further entry is written by the pair that
+  // finished the previous segment of that group.  A pair pops by taking the next index of `head` and waiting for
+  // that entry: it waits for the next COMPLETION on the device, whichever group it is, so the resident pairs stay
+  // busy as long as there are at least as many groups as pairs.  Every popped index below groups x segments does get
+  // written: its writer holds a lower index, i.e. is already running.
+  const u32 groups = (u32)A.sched_groups, nseg = (u32)A.sched_segments;
+  u32* const q_head = A.sched;           // indices popped so far
+  u32* const q_tail = A.sched + 1;       // entries pushed so far (beyond the implicit ones)
+  u32* const q_ring = A.sched + 2;       // entry i - groups for index i >= groups: unit + 1, 0 = not yet pushed
+  for (;;) {
+    i64 slot, nlanes;
+    int first, last, pos_begin, pos_end;
+    u32 g = 0, sg = 0;
+    if constexpr (!PERSISTENT) {
+      slot = (i64)blockIdx.x * N2_SPLIT_PAIRS + pair;
+      nlanes = (i64)gridDim.x * N2_SPLIT_PAIRS * 64;
+      first = A.first; last = A.last; pos_begin = A.pos_begin; pos_end = A.pos_end;
+    } else {
+      u32 u;
+      if (half == 0) {
+        // B has taken everything of the previous unit (its last entry is the end token): the pair is free
+        while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(2);
+        u32 idx = 0;
+        if (lane == 0) idx = __hip_atomic_fetch_add(q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
+        u = idx;
+        if (idx >= groups && idx < groups * nseg) {
+          u32 v;
+          while ((v = __hip_atomic_load(q_ring + (idx - groups), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(16);
+          u = (u32)__builtin_amdgcn_readfirstlane((int)v) - 1u;
+        }
+        if (lane == 0) *unit_word = u;
+        send_token();
+      } else {
+        receive_token();
+        u = (u32)__builtin_amdgcn_readfirstlane((int)*unit_word);
+      }
+      if (u >= groups * nseg) break;
+      g = u % groups; sg = u / groups;
+      // what the pair that pushed this unit stored (slots, accumulator) before its release of the entry
+      if (sg > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      slot = (i64)g;
+      nlanes = (i64)groups * 64;
+      first = sg == 0;
+      last = sg == nseg - 1;
+      pos_begin = (int)((i64)A.sched_n_sqr * sg / nseg);
+      pos_end = last ? 0x7FFFFFFF : (int)((i64)A.sched_n_sqr * (sg + 1) / nseg);
+    }
+    // ---- one unit of work: the part of the tape with positions [pos_begin, pos_end) for the group `slot`
+    const i64 elem_raw = slot * GPW + gw;
+    const bool valid = elem_raw < A.batch;
+    const i64 elem = valid ? elem_raw : A.batch - 1;
+    u32* slots = A.slots + (slot * 64 + lane);
+    // this wavefront's digit of a pair slot
+    auto slot_at = [&](int sl, int j) -> u32& { return slots[(((i64)sl * 2 + half) * L + j) * nlanes]; };
+    auto slot_other = [&](int sl, int j) -> u32& { return slots[(((i64)sl * 2 + (1 - half)) * L + j) * nlanes]; };
+
+    // ---- prologue: constant pairs and the two halves of x into their slots, every wavefront its own digit
+    if (first) {
+      u32 v[L];
+      const int rows[4][3] = {{N2_SLOT_K1, 3, 4}, {N2_SLOT_K2, 5, 6}, {N2_SLOT_ONE, 1, 2}, {N2_SLOT_E, -1, -1}};
+      for (int r = 0; r < 4; ++r) {
+        const int row = rows[r][1 + half];
+        if (row >= 0) {
+          M.load(v, A.consts + (i64)row * A.limbsn, A.limbsn);
+        } else {
+          M.set_small(v, half == 0 ? 1u : 0u);
+        }
+#pragma unroll
+        for (int j = 0; j < L; ++j) slot_at(rows[r][0], j) = v[j];
+      }
+      if (half == 0) {
+        M_t::sync();
+        const u32* src = A.bases + elem * A.limbs2;
+        for (int k = p; k < WIDE; k += K) wide[k] = (k < A.limbs2) ? src[k] : 0u;
+        M_t::sync();
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          const int bit = W * (p * L + j);
+          const int room = A.ksplit - bit;                       // bits of this limb that belong to x_lo
+          const u32 lo = room <= 0 ? 0u : extract_field(wide, bit, room < W ? room : W);
+          const int hbit = A.ksplit + bit;
+          const u32 hi = (hbit + W + 32 <= 32 * WIDE) ? extract_field(wide, hbit, W) : 0u;
+          slot_at(N2_SLOT_LO, j) = lo;
+          slot_at(N2_SLOT_HI, j) = hi;
+        }
+        send_token();           // A's constant digits are in their slots before B multiplies by them
+      } else {
+#pragma unroll
+        for (int j = 0; j < L; ++j) { slot_at(N2_SLOT_LO, j) = 0; slot_at(N2_SLOT_HI, j) = 0; }
+        receive_token();
+      }
+    }
+
+    // ---- the tape (this segment's part of it): acc is THIS wavefront's digit of the accumulator pair
+    u32 acc[L];
+    if (first) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) acc[j] = 0;
+    } else {
+#pragma unroll
+      for (int j = 0; j < L; ++j) acc[j] = slot_at(N2_SLOT_CARRY, j);
+    }
+    int pos = 0;                                      // squarings executed by the tape so far
+    for (int k = 0; k < A.ntape; ++k) {
+      const u32 word = A.tape[k];
+      const u32 op = word >> 28;
+      const int arg = (int)(word & 0x0FFFFFFFu);
+      if (op == N2_SQR) {
+        const int lo = pos > pos_begin ? pos : pos_begin;
+        const int hi = pos + arg < pos_end ? pos + arg : pos_end;
+        for (int s = lo; s < hi; ++s) {
+          u32 q[L];
+          if (half == 0) {
+            u32 t0[L];
+            P.sqr_pass1(t0, q, acc);
+            send(acc, q);
+#pragma unroll
+            for (int j = 0; j < L; ++j) acc[j] = t0[j];
+          } else {
+            u32 x0[L];
+            receive(x0, q);
+            P.sqr_pass2(acc, x0, acc, q);
+          }
+        }
+        pos += arg;
+        continue;
+      }
+      if (pos < pos_begin || pos >= pos_end) continue;   // another segment's operation
+      if (op == N2_STORE) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) slot_at(arg, j) = acc[j];
+      } else if (op == N2_MUL) {
+        u32 q[L], f0[L];
         if (half == 0) {
           u32 t0[L];
-          P.sqr_pass1(t0, q, acc);
+#pragma unroll
+          for (int j = 0; j < L; ++j) f0[j] = slot_at(arg, j);
+          P.mul_pass1_unstaged(t0, q, acc, f0);
           send(acc, q);
 #pragma unroll
           for (int j = 0; j < L; ++j) acc[j] = t0[j];
         } else {
-          u32 x0[L];
+          u32 x0[L], f1[L];
+#pragma unroll
+          for (int j = 0; j < L; ++j) f1[j] = slot_at(arg, j);
+          // the first digit of the table entry was written by wavefront A: read it behind the hand-over of this
+          // operation (A stored it before it released `produced`; the acquire orders this wavefront's loads after it)
           receive(x0, q);
-          P.sqr_pass2(acc, x0, acc, q);
+#pragma unroll
+          for (int j = 0; j < L; ++j) f0[j] = slot_other(arg, j);
+          M.stage_multipliers(f0, f1);
+          P.mul_pass2(acc, x0, acc, q);
+        }
+      } else {
+        u32 f[L];
+#pragma unroll
+        for (int j = 0; j < L; ++j) f[j] = slot_at(arg, j);
+        if (op == N2_ADD) {
+          M.add(acc, acc, f);
+        } else {   // N2_LOAD
+#pragma unroll
+          for (int j = 0; j < L; ++j) acc[j] = f[j];
         }
       }
-      pos += arg;
-      continue;
     }
-    if (pos < A.pos_begin || pos >= A.pos_end) continue;   // another segment's operation
-    if (op == N2_STORE) {
+    if (!last) {
 #pragma unroll
-      for (int j = 0; j < L; ++j) slot_at(arg, j) = acc[j];
-    } else if (op == N2_MUL) {
-      u32 q[L], f0[L];
-      if (half == 0) {
-        u32 t0[L];
-#pragma unroll
-        for (int j = 0; j < L; ++j) f0[j] = slot_at(arg, j);
-        P.mul_pass1_unstaged(t0, q, acc, f0);
-        send(acc, q);
-#pragma unroll
-        for (int j = 0; j < L; ++j) acc[j] = t0[j];
-      } else {
-        u32 x0[L], f1[L];
-#pragma unroll
-        for (int j = 0; j < L; ++j) f1[j] = slot_at(arg, j);
-        // the first digit of the table entry was written by wavefront A: read it behind the hand-over of this
-        // operation (A stored it before it released `produced`; the acquire orders this wavefront's loads after it)
-        receive(x0, q);
-#pragma unroll
-        for (int j = 0; j < L; ++j) f0[j] = slot_other(arg, j);
-        M.stage_multipliers(f0, f1);
-        P.mul_pass2(acc, x0, acc, q);
-      }
+      for (int j = 0; j < L; ++j) slot_at(N2_SLOT_CARRY, j) = acc[j];
+    } else if (half == 0) {
+      send(acc, acc);
     } else {
-      u32 f[L];
+    // ---- epilogue on wavefront B, which receives A's final first digit through the mailbox
+    u32 acc0[L], acc1[L];
+    {
+      u32 unused[L];
+      receive(acc0, unused);
+    }
 #pragma unroll
-      for (int j = 0; j < L; ++j) f[j] = slot_at(arg, j);
-      if (op == N2_ADD) {
-        M.add(acc, acc, f);
-      } else {   // N2_LOAD
+    for (int j = 0; j < L; ++j) acc1[j] = acc[j];
+    {
+      u64 t[L];
 #pragma unroll
-        for (int j = 0; j < L; ++j) acc[j] = f[j];
+      for (int j = 0; j < L; ++j) t[j] = acc0[j];
+      M.normalize_full(acc0, t);
+      const u32 carry = M.cond_sub(acc0);
+#pragma unroll
+      for (int j = 0; j < L; ++j) t[j] = acc1[j];
+      if (p == 0) t[0] += carry;
+      M.normalize_full(acc1, t);
+      M.cond_sub(acc1);
+    }
+    u32 hi[L];
+    M_t::sync();
+    M.template mulx<M_t::F_INIT | M_t::F_PLAIN>(hi, acc1, M.n, acc1, M.n, acc0, nullptr, wide, A.nblk);
+    {
+      u64 t[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) t[j] = hi[j];
+      M.normalize_full(hi, t);
+    }
+    const int it = A.nblk * L;
+#pragma unroll
+    for (int j = 0; j < L; ++j) wide[it + p * L + j] = hi[j];
+    if (p == 0) { wide[it + S] = 0; wide[it + S + 1] = 0; wide[it + S + 2] = 0; wide[it + S + 3] = 0; }
+    M_t::sync();
+    u32* dst = A.out + elem * A.limbs2;
+    const int nl = it + S;
+    for (int k = p; k < A.limbs2; k += K) {
+      const int bit = 32 * k;
+      const int g = bit / W, off = bit - g * W;
+      u32 o = 0;
+      if (g < nl) {
+        u64 v = (u64)wide[g] >> off;
+        v |= (u64)wide[g + 1] << (W - off);
+        if (2 * W - off < 32) v |= (u64)wide[g + 2] << (2 * W - off);
+        o = (u32)v;
+      }
+      if (valid) dst[k] = o;
+    }
+    M_t::sync();          // the scratch is reused by the next unit of a time-sliced launch
+    }
+
+    if constexpr (!PERSISTENT) {
+      break;
+    } else {
+      // end of the unit: A's stores are ordered before its token, B pushes the group's next segment for both
+      if (half == 0) {
+        send_token();
+      } else {
+        receive_token();
+        if (!last) {
+          u32 t = 0;
+          if (lane == 0) t = __hip_atomic_fetch_add(q_tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          t = (u32)__builtin_amdgcn_readfirstlane((int)t);
+          __hip_atomic_store(q_ring + t, (sg + 1) * groups + g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        }
       }
     }
-  }
-  if (!A.last) {
-#pragma unroll
-    for (int j = 0; j < L; ++j) slot_at(N2_SLOT_CARRY, j) = acc[j];
-    return;
-  }
-
-  // ---- epilogue on wavefront B, which receives A's final first digit through the mailbox
-  u32 acc0[L], acc1[L];
-  if (half == 0) {
-    send(acc, acc);
-    return;
-  }
-  {
-    u32 unused[L];
-    receive(acc0, unused);
-  }
-#pragma unroll
-  for (int j = 0; j < L; ++j) acc1[j] = acc[j];
-  {
-    u64 t[L];
-#pragma unroll
-    for (int j = 0; j < L; ++j) t[j] = acc0[j];
-    M.normalize_full(acc0, t);
-    const u32 carry = M.cond_sub(acc0);
-#pragma unroll
-    for (int j = 0; j < L; ++j) t[j] = acc1[j];
-    if (p == 0) t[0] += carry;
-    M.normalize_full(acc1, t);
-    M.cond_sub(acc1);
-  }
-  u32 hi[L];
-  M_t::sync();
-  M.template mulx<M_t::F_INIT | M_t::F_PLAIN>(hi, acc1, M.n, acc1, M.n, acc0, nullptr, wide, A.nblk);
-  {
-    u64 t[L];
-#pragma unroll
-    for (int j = 0; j < L; ++j) t[j] = hi[j];
-    M.normalize_full(hi, t);
-  }
-  const int it = A.nblk * L;
-#pragma unroll
-  for (int j = 0; j < L; ++j) wide[it + p * L + j] = hi[j];
-  if (p == 0) { wide[it + S] = 0; wide[it + S + 1] = 0; wide[it + S + 2] = 0; wide[it + S + 3] = 0; }
-  M_t::sync();
-  u32* dst = A.out + elem * A.limbs2;
-  const int nl = it + S;
-  for (int k = p; k < A.limbs2; k += K) {
-    const int bit = 32 * k;
-    const int g = bit / W, off = bit - g * W;
-    u32 o = 0;
-    if (g < nl) {
-      u64 v = (u64)wide[g] >> off;
-      v |= (u64)wide[g + 1] << (W - off);
-      if (2 * W - off < 32) v |= (u64)wide[g + 2] << (2 * W - off);
-      o = (u32)v;
-    }
-    if (valid) dst[k] = o;
   }
 }
 

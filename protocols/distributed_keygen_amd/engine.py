@@ -173,8 +173,8 @@ class Engine:
 
     def debug_knob(self, knob: str, value: int) -> None:
         """Developer overrides of the library (include/mxpaillier.h: mx_debug_knob; process-wide, 0 restores
-        the default): "n2_segments", "jacobi_max_batches"."""
-        ids = {"n2_segments": 1, "jacobi_max_batches": 2}
+        the default): "n2_segments", "jacobi_max_batches", "n2_timeslice" (1 never, 2 always)."""
+        ids = {"n2_segments": 1, "jacobi_max_batches": 2, "n2_timeslice": 3}
         _lib.check(self.lib.mx_debug_knob(ids[knob], int(value)), "mx_debug_knob")
 
     def cu_slice_streams(self, n: int) -> List[Any]:
@@ -241,6 +241,15 @@ class Engine:
         k, l, w, b, wv = (ctypes.c_int() for _ in range(5))
         _lib.check(self.lib.mx_nsquare_launch_shape(n_bits, batch, self._lpl, self._wpg, k, l, w, b, wv), "mx_nsquare_launch_shape")
         return k.value, l.value, w.value, b.value, wv.value
+
+    def nsquare_launch_timesliced(self, n_bits: int, batch: int) -> Tuple[int, int]:
+        """(resident workgroups per CU, units per group) when a powmod_nsquare launch of `batch` elements with this
+        engine's settings runs in the time-sliced form (mx_nsquare_launch_timesliced), (0, 0) for a plain launch."""
+        import ctypes
+
+        r, u = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.mx_nsquare_launch_timesliced(n_bits, batch, self._lpl, self._wpg, r, u), "mx_nsquare_launch_timesliced")
+        return r.value, u.value
 
     def _mods_operand(self, mods, limbs: int, odd_only: bool = True):
         """Moduli of a per-group launch as (device rows [groups, limbs], max bits).  `mods` is a sequence

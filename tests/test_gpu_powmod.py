@@ -263,6 +263,36 @@ def test_powmod_nsquare_segments_are_bit_identical(eng, segments):
         eng.set_wavefronts_per_group(0)
 
 
+@pytest.mark.parametrize("n_bits,batch,exp_bits", [(131, 70000, 300), (131, 40, 300), (515, 20000, 200), (1027, 33, 700),
+                                                   (2051, 5200, 70), (2051, 9, 2100), (4099, 1500, 40), (4099, 5, 600)])
+def test_powmod_nsquare_timesliced_is_bit_identical(eng, n_bits, batch, exp_bits):
+    """The time-sliced form of the two-wavefront kernel (resident workgroups that take (segment, group) units from a
+    ticket counter; csrc/mx_powmod_n2_split.hpp): forced on with the developer knob, with more groups than resident
+    pairs (the large batches) and fewer, for every segment count — bit for bit the plain launch's result."""
+    rng = random.Random(n_bits * 31 + batch)
+    n = rng.getrandbits(n_bits) | (1 << (n_bits - 1)) | 1
+    n2 = n * n
+    bases = [0, 1, n, n + 1, n2 - 1][: batch] + [rng.randrange(n2) for _ in range(max(0, batch - 5))]
+    e = rng.getrandbits(exp_bits) | (1 << (exp_bits - 1)) | 1
+    want = [pow(b, e, n2) for b in bases]
+    try:
+        eng.debug_knob("n2_timeslice", 2)
+        for lpl in (9, 18):
+            eng.set_limbs_per_lane(lpl)
+            eng.set_wavefronts_per_group(2)
+            for segments in ((0, 1, 3) if batch < 1000 else (0, 2)):
+                eng.set_segments(segments)
+                assert eng.powmod_nsquare_batch(bases, e, n) == want, (lpl, segments)
+        eng.debug_knob("n2_timeslice", 1)
+        eng.set_segments(0)
+        assert eng.powmod_nsquare_batch(bases, e, n) == want
+    finally:
+        eng.debug_knob("n2_timeslice", 0)
+        eng.set_segments(0)
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
+
+
 def test_exponent_with_a_very_long_run_of_zero_bits(eng):
     """the squaring count of a schedule step used to be packed into 16 bits, so an
     exponent with >= 65536 consecutive zero bits (2^70000) silently gave a wrong power.  Both the

@@ -271,7 +271,8 @@ def test_c_abi_status_codes_without_gpu():
     import ctypes
 
     assert lib.mx_debug_knob(99, 1) == -1 and lib.mx_debug_knob(1, 65) == -1 and lib.mx_debug_knob(2, -1) == -1
-    assert lib.mx_debug_knob(1, 0) == 0 and lib.mx_debug_knob(2, 0) == 0
+    assert lib.mx_debug_knob(3, 3) == -1 and lib.mx_debug_knob(3, 20) == -1
+    assert lib.mx_debug_knob(1, 0) == 0 and lib.mx_debug_knob(2, 0) == 0 and lib.mx_debug_knob(3, 0) == 0
     assert lib.mx_spin(-1, None) == -1 and lib.mx_clock_probe(0, fake, None) == -1 and lib.mx_clock_probe(10, None, None) == -1
     sp = ctypes.c_void_p()
     assert lib.mx_stream_create_cu_slice(4, 4, 0, ctypes.byref(sp)) == -1 and lib.mx_stream_create_cu_slice(0, 0, 0, ctypes.byref(sp)) == -1

@@ -53,3 +53,29 @@ def test_auto_launch_shapes_match_the_measured_crossovers():
     assert ic.case_instance(lib, ("n2", 2051, 18, 10, 0, 0)) == ("n2", 4, 18, 2)
     assert ic.case_instance(lib, ("n2", 2051, 0, 10, 0, 1)) == ("n2", 8, 9, 1)
     assert ic.case_instance(lib, ("n2", 2051, 3, 10, 0, 1)) is None          # the latency geometry has no one-wavefront form
+
+
+def test_time_sliced_launches_where_they_were_measured_to_pay():
+    """The time-sliced form of the two-wavefront kernel (resident workgroups taking segment units from a queue) is
+    chosen just above a capacity step of a lone launch and nowhere else (tools/ts_probe.py,
+    profiles/r03_ts_probe_2048.txt, _4096.txt); an explicit one-wavefront or wide shape never is."""
+    import ctypes
+
+    from protocols.distributed_keygen_amd import _lib
+
+    lib = _lib.lib()
+
+    def sliced(bits, batch, lpl=0, wpg=0):
+        r, u = ctypes.c_int(), ctypes.c_int()
+        assert lib.mx_nsquare_launch_timesliced(bits, batch, lpl, wpg, r, u) == 0
+        return r.value, u.value
+
+    for batch in (1, 1000, 4096, 8192, 12288, 16384, 20000, 40000):
+        assert sliced(2051, batch) == (0, 0), batch
+    for batch in (9216, 10000, 10240):
+        assert sliced(2051, batch) == (2, 2), batch
+    assert sliced(2051, 4608) == (1, 8)
+    assert sliced(4099, 5120) == (2, 2) and sliced(4099, 2304) == (1, 8) and sliced(4099, 2048) == (0, 0)
+    assert sliced(2051, 10000, 18, 0) == (0, 0) and sliced(2051, 10000, 0, 1) == (0, 0) and sliced(2051, 10000, 9, 2) == (2, 2)
+    assert sliced(8195, 3000) == (0, 0)                   # groups of 32 lanes have no time-sliced instance
+    assert lib.mx_nsquare_launch_timesliced(2051, 0, 0, 0, ctypes.c_int(), ctypes.c_int()) == -1

@@ -1,0 +1,37 @@
+#!/usr/bin/env python3
+"""Time-sliced vs plain two-wavefront launches over batch sizes, resident workgroups per CU and segment counts
+(developer probe behind the choice in csrc/mx_capi_n2.hip: n2_estimate).  usage: ts_probe.py [key_length]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
+eng = Engine()
+key_length = int(sys.argv[1]) if len(sys.argv) > 1 else 2048
+key = synthetic.make_key(key_length, 3, 1)
+own = next(i for i in (1, 2, 3) if key.exponent(i) > 0)
+exp = key.exponent(own); n = key.n
+limbs2 = L.limbs_for(key.n_square)
+sizes = [4608, 5120, 5632, 6144, 7168, 9216, 10000, 10240, 11264, 13312, 14336, 17408, 18432, 20000, 22528, 24576]
+if key_length > 2048:
+    sizes = [2304, 2560, 3072, 4608, 5120, 6144]
+cts = synthetic.random_ciphertexts(key, max(sizes), seed=7)
+c_all = eng.to_device(L.pack(cts, limbs2))
+def t(b, lpl, wpg, ts, seg):
+    eng.set_limbs_per_lane(lpl); eng.set_wavefronts_per_group(wpg); eng.debug_knob("n2_timeslice", ts)
+    eng.powmod_nsquare_t(c_all[:b], n, exp, segments=seg); torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(2):
+        t0 = time.perf_counter(); eng.powmod_nsquare_t(c_all[:b], n, exp, segments=seg); torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best * 1e3
+for b in sizes:
+    plain = {f"L{l}x{w}": t(b, l, w, 1, 1) for l, w in ((9, 2), (18, 2), (18, 1))}
+    row = [f"b{b}: plain " + " ".join(f"{k} {v:.1f}" for k, v in plain.items()) + " | ts"]
+    best = (min(plain.values()), "plain")
+    for lpl, rs in ((9, (1, 2, 3)), (18, (1, 2))):
+        for r in rs:
+            for seg in (2, 3, 4, 8):
+                v = t(b, lpl, 2, 16 + r, seg)
+                best = min(best, (v, f"L{lpl}r{r}s{seg}"))
+                row.append(f"L{lpl}r{r}s{seg} {v:.1f}")
+    print(" ".join(row), f"|| best {best[1]} {best[0]:.1f} vs plain {min(plain.values()):.1f}", flush=True)
