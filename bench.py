@@ -389,6 +389,8 @@ def pick_decrypt_shape(eng, args, n_bits: int, batch: int, nstreams: int):
         return lpl, wpg
     eng.set_limbs_per_lane(lpl)
     eng.set_wavefronts_per_group(wpg)
+    if nstreams >= 3:
+        return eng.saturating_shape(n_bits, batch * nstreams)
     _, l, _, _, w = eng.nsquare_launch_shape(n_bits, batch * nstreams)
     return (lpl or l), (wpg or w)
 

@@ -94,7 +94,8 @@ int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t 
 //   ~80 / L cycles per step for the multiplier limbs it fetches from LDS once per L steps;
 //   every further wavefront resident on the same SIMD adds what its instructions cost when the SIMD is shared:
 //   4.2 cycles per multiply-accumulate, 2.3 per other instruction (tools/ubench/valu_peak.hip);
-//   wavefronts beyond what the register file holds per SIMD (2 at L = 18, 3 at L = 9, 8 at L = 3) run in rounds.
+//   wavefronts beyond what the register file holds per SIMD (2 at L = 18, 3 at L = 9, 8 at L = 3) are back-filled
+//   as the first ones finish.
 // Two-wavefront groups: the second pass (m = 2L, o = 11) bounds an operation, its wavefronts sit on SIMDs 1 and 3 of
 // a CU, one per workgroup.  One-wavefront groups: both passes (m = L/2 + 1 + 3L, o = 20), a wavefront per workgroup.
 // What comes out (key_length 2048): up to ~1000 ciphertexts the latency geometry (3 limbs per lane, two
@@ -119,8 +120,8 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   if (!shape_n2(n_bits, 1, batch, lpl, wpg, p)) return -1.0;
   const double L = p.geo.L, steps = (double)p.geo.nblk * p.geo.L;
   const double m = wpg == 2 ? 2 * L : (p.geo.L / 2 + 1) + 3 * L, o = wpg == 2 ? 11.0 : 20.0;
-  const double alone = steps * (5.3 * (m + o) + 80.0 / L) * (wpg == 2 ? 1.0 : 0.92);
-  const double shared = steps * (4.2 * m + 2.3 * o);
+  const double alone = steps * (5.3 * (m + o) + 80.0 / L);
+  const double shared = steps * (4.2 * m + 2.3 * o) * (wpg == 2 ? 1.0 : 1.17);     // one wavefront doing both passes overlaps less
   const int cus = device_cus();
   const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
   const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;
@@ -128,13 +129,11 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   double plain;
   if (per_simd <= fit) {
     plain = round(per_simd);          // everything resident at once: the fullest SIMD bounds the launch
-  } else if (fit <= 2) {
-    // two per SIMD at most (L = 18): whole rounds — 3 per SIMD measured as a round of 2 plus 0.9 of a round of 1
-    plain = (double)(per_simd / fit) * round(fit) + 0.9 * round(per_simd % fit);
   } else {
-    // more wavefronts than fit: the launch streams through full SIMDs at the rate of a full round
-    const double per_simd_mean = wpg == 2 ? (double)p.nblocks / cus : (double)p.nblocks / (4.0 * cus);
-    plain = per_simd_mean / (double)fit * round(fit);
+    // more wavefronts than fit: every further one per SIMD (whole ones: the fullest SIMD bounds the launch) adds
+    // 0.93 of its share of a full round — measured at 9 limbs per lane, two-wavefront groups: 53.4 ms for 3 per
+    // SIMD, then 70 / 86.5 / 102.5 for 4 / 5 / 6; at 18: 59.9 for 2, 89 for 3, 115 for 4
+    plain = round(fit) * (1.0 + 0.93 * (double)(per_simd - fit) / (double)fit);
   }
   // Time-sliced form (mx_powmod_n2_split.hpp; instances: 9 limbs per lane, groups of at most 16 lanes): r workgroups
   // per CU stay resident and take the groups' segments from a queue.  Measured over r = 1..3 and 2..8 segments at

@@ -242,6 +242,23 @@ class Engine:
         _lib.check(self.lib.mx_nsquare_launch_shape(n_bits, batch, self._lpl, self._wpg, k, l, w, b, wv), "mx_nsquare_launch_shape")
         return k.value, l.value, w.value, b.value, wv.value
 
+    def saturating_shape(self, n_bits: int, total: int) -> Tuple[int, int]:
+        """(limbs per lane, wavefronts per group) for powmod_nsquare launches that run SIDE BY SIDE on several
+        streams, `total` elements between them.  When they bring about two wavefronts per SIMD or more at one
+        wavefront per group of elements and 18 limbs per lane, that shape: fewest instructions per ciphertext
+        (include/mxpaillier.h: "callers that keep several launches in flight ... should pass 18 / 1").  Otherwise
+        the library's choice for ONE launch of the total, which is what the launches then resemble.  The engine's
+        explicit settings win."""
+        import ctypes
+
+        k, l, w, b, wv = (ctypes.c_int() for _ in range(5))
+        if not (self._lpl and self._wpg) and self.lib.mx_nsquare_launch_shape(n_bits, total, self._lpl or 18, self._wpg or 1, k, l, w, b, wv) == 0:
+            simds = 4 * self.torch.cuda.get_device_properties(self.device).multi_processor_count
+            if wv.value == 1 and l.value == 18 and total * k.value // 64 >= 15 * simds // 8:
+                return (18, 1)
+        _, l_, _, _, w_ = self.nsquare_launch_shape(n_bits, total)
+        return (self._lpl or l_, self._wpg or w_)
+
     def nsquare_launch_timesliced(self, n_bits: int, batch: int) -> Tuple[int, int]:
         """(resident workgroups per CU, units per group) when a powmod_nsquare launch of `batch` elements with this
         engine's settings runs in the time-sliced form (mx_nsquare_launch_timesliced), (0, 0) for a plain launch."""
@@ -434,8 +451,12 @@ class Engine:
             rows = _limbs.pack_reduced(vals, limbs2, n2)
             t1 = _t.perf_counter()
             # a lone launch that is waited for right away: nothing else is in flight whose drain segments
-            # could shorten, and the three extra segment boundaries would cost ~1 %
-            out_t = self.powmod_nsquare_t(self.to_device(rows), n, exp, segments=1 if self._segments == 0 else None)
+            # could shorten, and the three extra segment boundaries would cost ~1 % (a time-sliced launch keeps the
+            # library's number of units per group)
+            lone_segments = None
+            if self._segments == 0:
+                lone_segments = 0 if self.nsquare_launch_timesliced(n.bit_length(), len(vals))[0] else 1
+            out_t = self.powmod_nsquare_t(self.to_device(rows), n, exp, segments=lone_segments)
             out = self.to_host(out_t)
             t2 = _t.perf_counter()
             res = _limbs.unpack(out)
@@ -443,10 +464,9 @@ class Engine:
             return (res, out_t) if keep_rows else res
         self.nsquare_plan(n, exp)          # prepared once, before the chunks fan out over streams
         kept: List[Any] = []
-        # the chunks run side by side: the launch shape is the one that suits the WHOLE sequence (the library's
-        # choice for a single launch of that size), not the one a lone chunk would get
-        k_, l_, _, _, w_ = self.nsquare_launch_shape(n.bit_length(), len(vals))
-        chunk_shape = (self._lpl or l_, self._wpg or w_)
+        # the chunks run side by side and fill the machine between them: the shape for that is not the one a lone
+        # chunk would get
+        chunk_shape = self.saturating_shape(n.bit_length(), len(vals))
 
         def launch(t):
             out_t = self.powmod_nsquare_t(t, n, exp, shape=chunk_shape)
