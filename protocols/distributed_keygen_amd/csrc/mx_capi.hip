@@ -245,7 +245,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 300; }
+int mx_version(void) { return 301; }
 
 const char* mx_error_string(int code) {
   switch (code) {
