@@ -1,21 +1,23 @@
 #!/usr/bin/env python3
-"""Builds libmxpaillier with extra compiler flags into protocols/distributed_keygen_amd/build/variants/<name>.so
-(developer tool for A/B runs through MX_LIBRARY, tools/ab_variants.sh).  usage: build_variant.py <name> [flags ...]"""
-import os, subprocess, sys
+"""Builds libmxpaillier with extra compiler flags and/or another run length of the alignment pass into
+protocols/distributed_keygen_amd/build/variants/<name>.so (developer tool for A/B runs through MX_LIBRARY,
+tools/ab_variants.sh, tools/variant_probe.py).
+usage: build_variant.py <name> [--align-run N] [flags ...]      (N = 0: no alignment pass)"""
+import sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
 ROOT = Path(__file__).resolve().parent.parent
 sys.path.insert(0, str(ROOT))
 from protocols.distributed_keygen_amd import build as B
-name, extra = sys.argv[1], sys.argv[2:]
+args = sys.argv[1:]
+name = args.pop(0)
+align_run = None
+if args and args[0] == "--align-run":
+    align_run = int(args[1]); args = args[2:]
 out = B.PKG / "build" / "variants"; objdir = out / name; objdir.mkdir(parents=True, exist_ok=True)
-flags = ["-O3", "--offload-arch=gfx950", "-std=c++17", "-fPIC", "-Wno-unused-value", "-Wno-pass-failed", *extra]
-def one(src):
-    obj = objdir / (src.stem + ".o")
-    subprocess.run([B._hipcc(), *flags, "-c", str(src), "-o", str(obj)], check=True, cwd=str(B.CSRC))
-    return obj
 with ThreadPoolExecutor(max_workers=len(B.SOURCES)) as pool:
-    objs = list(pool.map(one, B.SOURCES))
-subprocess.run([B._hipcc(), "--offload-arch=gfx950", "-shared", "-fPIC", *map(str, objs), "-o", str(out / f"{name}.so")], check=True)
-for o in objs: os.remove(o)
-print(out / f"{name}.so")
+    objs = list(pool.map(lambda src: B.compile_unit(src, objdir, args, align_run), B.SOURCES))
+print(B.link(objs, out / f"{name}.so"))
+for o in objs:
+    o.unlink()
+objdir.rmdir()

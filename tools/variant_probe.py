@@ -3,9 +3,19 @@
 differently built libraries (MX_LIBRARY=... python tools/variant_probe.py)."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import ctypes
 import torch
-from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
+from protocols.distributed_keygen_amd import Engine, _lib, limbs as L, synthetic
+if os.environ.get("MX_LIBRARY"):                     # builds of older sources lack the newest entry points
+    probe = ctypes.CDLL(os.environ["MX_LIBRARY"])
+    for name in [n for n in _lib.SYMBOLS if not hasattr(probe, n)]:
+        del _lib.SYMBOLS[name]
 eng = Engine()
+def knob(name, v):
+    try:
+        eng.debug_knob(name, v)
+    except Exception:
+        pass
 POINTS = {4096: [(1024, 18, 2), (4096, 18, 2), (2048, 9, 2), (8192, 18, 1), (1, 3, 2)],
           2048: [(8192, 18, 2), (4096, 9, 2), (12288, 9, 2), (32768, 18, 1), (1, 3, 2)]}
 row = []
@@ -16,7 +26,7 @@ for key_length, pts in POINTS.items():
     cts = synthetic.random_ciphertexts(key, max(p[0] for p in pts), seed=7)
     c_all = eng.to_device(L.pack(cts, L.limbs_for(key.n_square)))
     for b, lpl, wpg in pts:
-        eng.set_limbs_per_lane(lpl); eng.set_wavefronts_per_group(wpg); eng.debug_knob("n2_timeslice", 1)
+        eng.set_limbs_per_lane(lpl); eng.set_wavefronts_per_group(wpg); knob("n2_timeslice", 1)
         eng.powmod_nsquare_t(c_all[:b], n, exp, segments=1); torch.cuda.synchronize()
         best = 1e9
         for _ in range(2):
