@@ -125,7 +125,13 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   const int cus = device_cus();
   const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
   const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;
-  auto round = [&](int64_t r) { return r <= 0 ? 0.0 : alone + (double)(r - 1) * shared; };
+  // every further wavefront of a two-wavefront shape costs ~12 % more than the one before (L9: 21.3 / 35.7 / 51.1 ms
+  // for 1 / 2 / 3 per SIMD; L3: increments of 7.4, 8.1, 8.9 ms)
+  auto round = [&](int64_t r) {
+    double t = r <= 0 ? 0.0 : alone, add = shared;
+    for (int64_t k = 1; k < r; ++k) { t += add; if (wpg == 2) add *= 1.12; }
+    return t;
+  };
   double plain;
   if (per_simd <= fit) {
     plain = round(per_simd);          // everything resident at once: the fullest SIMD bounds the launch
@@ -157,7 +163,10 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
     if (p.groups <= pairs && !forced) continue;
     const double load = std::max(1.0, (double)p.groups / (double)pairs);
     if (rr == 1 && load > 1.5 && !forced) continue;
-    const double t = load * round(rr) * (rr == 1 ? 1.15 : 1.0);
+    // the time-sliced instances run 5 % (shared SIMDs) to 11 % (alone) slower per operation than the plain ones since
+    // the build aligns 64-bit instructions (asm_align.py: the plain instances gained, these did not), and one
+    // workgroup per CU pays ~13 % for its hand-overs
+    const double t = load * round(rr) * (rr == 1 ? 1.28 : 1.05);
     if (best < 0 || t < best) { best = t; *resident = (int)rr; }
   }
   return *resident ? best : plain;

@@ -16,8 +16,8 @@ def knob(name, v):
         eng.debug_knob(name, v)
     except Exception:
         pass
-POINTS = {4096: [(1024, 18, 2), (4096, 18, 2), (2048, 9, 2), (8192, 18, 1), (1, 3, 2)],
-          2048: [(8192, 18, 2), (4096, 9, 2), (12288, 9, 2), (32768, 18, 1), (1, 3, 2)]}
+POINTS = {4096: [(1024, 18, 2), (4096, 18, 2), (2048, 9, 2), (2048, 9, 22), (8192, 18, 1), (1, 3, 2)],
+          2048: [(8192, 18, 2), (4096, 9, 2), (4096, 9, 22), (10000, 9, 22), (12288, 9, 2), (32768, 18, 1), (1, 3, 2)]}      # wpg 22: two wavefronts, time-sliced form forced
 row = []
 for key_length, pts in POINTS.items():
     key = synthetic.make_key(key_length, 3, 1)
@@ -26,11 +26,13 @@ for key_length, pts in POINTS.items():
     cts = synthetic.random_ciphertexts(key, max(p[0] for p in pts), seed=7)
     c_all = eng.to_device(L.pack(cts, L.limbs_for(key.n_square)))
     for b, lpl, wpg in pts:
-        eng.set_limbs_per_lane(lpl); eng.set_wavefronts_per_group(wpg); knob("n2_timeslice", 1)
-        eng.powmod_nsquare_t(c_all[:b], n, exp, segments=1); torch.cuda.synchronize()
+        ts = wpg == 22
+        eng.set_limbs_per_lane(lpl); eng.set_wavefronts_per_group(2 if ts else wpg); knob("n2_timeslice", 2 if ts else 1)
+        seg = 0 if ts else 1
+        eng.powmod_nsquare_t(c_all[:b], n, exp, segments=seg); torch.cuda.synchronize()
         best = 1e9
         for _ in range(2):
-            t0 = time.perf_counter(); eng.powmod_nsquare_t(c_all[:b], n, exp, segments=1); torch.cuda.synchronize()
+            t0 = time.perf_counter(); eng.powmod_nsquare_t(c_all[:b], n, exp, segments=seg); torch.cuda.synchronize()
             best = min(best, time.perf_counter() - t0)
-        row.append(f"k{key_length}/b{b}/L{lpl}x{wpg} {best * 1e3:.2f}")
+        row.append(f"k{key_length}/b{b}/L{lpl}x{'2ts' if ts else wpg} {best * 1e3:.2f}")
 print(os.environ.get("MX_LIBRARY", "default").split("/")[-1], " | ".join(row), flush=True)
