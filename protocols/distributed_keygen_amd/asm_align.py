@@ -10,12 +10,16 @@ this one works on its assembly output:
 
     hipcc --cuda-device-only -S   ->  x.s
     assemble, llvm-objdump -d     ->  the size of every instruction, in order
-    insert `s_nop 0` in front of every run of >= RUN 64-bit instructions that would start at 4 mod 8
+    choose, per function, where to re-encode an e32 instruction as e64 and where to insert `s_nop 0` so that as few
+    64-bit instructions as possible start at 4 mod 8 (a small dynamic programme, see align_text)
     assemble the result (build.py links, bundles and embeds it into the host object)
 
-An s_nop costs an issue slot itself, hence the minimum run length.  The pass changes no instruction and no
-register; it only adds s_nop 0 between instructions — never inside an inline-asm block, and never within the
-four instructions behind an s_getpc_b64: the s_add_u32 / s_addc_u32 that follow it carry sym@rel32 literals whose
+Where the 32-bit instructions right in front of such a run include a plain VALU operation in its e32 encoding
+(v_mov_b32, v_and_b32, v_add_u32, shifts ... on registers and inline constants), that one is re-encoded as e64
+instead — the same operation in 8 bytes, which moves everything behind it by 4 bytes at no cost in issue slots; this
+is done for runs of any length.  An s_nop costs an issue slot itself, hence the minimum run length for it.  The pass changes no instruction and no
+register; it only re-encodes e32 as e64 and adds s_nop 0 between instructions — never inside an inline-asm block, and
+never within the four instructions behind an s_getpc_b64: the s_add_u32 / s_addc_u32 that follow it carry sym@rel32 literals whose
 addends (+4, +12) assume that they follow it directly.  If the assembly and the disassembly of a function cannot be
 matched line by line the function is left as the compiler wrote it.
 """
@@ -28,11 +32,38 @@ from pathlib import Path
 from typing import Dict, List, Optional, Tuple
 
 LLVM_BIN = Path("/opt/rocm/lib/llvm/bin")
-RUN = 5           # minimum number of consecutive 64-bit instructions worth an s_nop (3, 5, 8 measured alike; 5 inserts a third fewer)
+NOP_COST = 4.0    # an inserted s_nop is taken when it aligns more than this many 64-bit instructions (3, 5, 8 measured alike)
 # Left alone: the instances with 3 limbs per lane (template arguments <K, 3, 29, ...>).  Their blocks are a few dozen
-# instructions on ONE dependent chain (the latency geometry), where an s_nop costs more than the fetch it saves:
-# 14.8 -> 15.3 ms and 55.9 -> 59.5 ms per decrypt with the pass, measured.
+# instructions on ONE dependent chain (the latency geometry); measured, s_nop insertion cost them 3-6 % (14.8 -> 15.3 ms
+# and 55.9 -> 59.5 ms per decrypt) and re-encoding alone changed nothing (14.87 -> 14.99, 55.9 -> 55.4).
 SKIP = re.compile(r"ELi3ELi29E")
+# e32 -> e64 re-encoding: VOP1 / VOP2 / VOPC operations whose VOP3 form takes the same operand text.  Operands:
+# VGPRs, inline constants, and at most ONE scalar source (an SGPR or vcc: a VOP3 encoding on this target reads the
+# constant bus once and takes no literal; a 4-byte e32 instruction has no literal to begin with).
+_promotable = re.compile(
+    r"^(v_(?:mov_b32|not_b32|and_b32|or_b32|xor_b32|add_u32|sub_u32|subrev_u32|add_co_u32|sub_co_u32|subrev_co_u32|"
+    r"addc_co_u32|subb_co_u32|subbrev_co_u32|lshlrev_b32|lshrrev_b32|ashrrev_i32|max_u32|min_u32|max_i32|min_i32|"
+    r"mul_u32_u24|cndmask_b32|cmp_(?:eq|ne|lt|le|gt|ge)_(?:u32|i32)))_e32\s+(.*?)\s*(;.*)?$")
+_vgpr_or_const = re.compile(r"^(v\d+|-?\d+)$")
+_scalar = re.compile(r"^(s\d+|vcc)$")
+
+
+def _promoted(line: str) -> Optional[str]:
+    """The e64 spelling of an e32 VALU line, or None if it is not one of the plain cases."""
+    m = _promotable.match(line.strip())
+    if not m:
+        return None
+    ops = [o.strip() for o in m.group(2).split(",")]
+    scalars = set()
+    for o in ops:
+        if _scalar.match(o):
+            scalars.add(o)
+        elif not _vgpr_or_const.match(o) or (o.lstrip("-").isdigit() and not -16 <= int(o) <= 64):
+            return None
+    if len(scalars) > 1:
+        return None
+    return "\t" + m.group(1) + "_e64 " + ", ".join(ops)
+
 
 _label = re.compile(r"^([A-Za-z_$][\w$.]*):")
 _local_label = re.compile(r"^(\.L[\w$.]*):")
@@ -65,8 +96,18 @@ def disassembly_sizes(obj: Path) -> Dict[str, List[Tuple[str, int]]]:
     return funcs
 
 
-def align_text(asm: str, sizes: Dict[str, List[Tuple[str, int]]], run: int = RUN, skip=SKIP) -> Tuple[str, Dict[str, int]]:
-    """Returns the assembly with s_nop 0 inserted, and {function: nops inserted} (-1: could not be matched, -2: skipped)."""
+_depth = re.compile(r"Depth=(\d+)")
+
+
+def align_text(asm: str, sizes: Dict[str, List[Tuple[str, int]]], nop_cost: float = NOP_COST, skip=SKIP,
+               promote: bool = True) -> Tuple[str, Dict[str, int]]:
+    """Returns the assembly with re-encoded e32 instructions and inserted s_nop 0, and {function: changes made}
+    (-1: the function could not be matched with its disassembly and was left alone, -2: its name matches `skip`).
+
+    Per function a two-state dynamic programme over the instruction sequence (state = address mod 8 in {0, 4}):
+    a 64-bit instruction at 4 mod 8 costs 1, an inserted s_nop `nop_cost`, both weighted 8^loop depth (the compiler
+    annotates blocks with their depth); a 32-bit instruction flips the state, a re-encodable one may keep it
+    instead (and then counts as a 64-bit instruction itself)."""
     lines = asm.split("\n")
     out: List[str] = []
     stats: Dict[str, int] = {}
@@ -91,7 +132,7 @@ def align_text(asm: str, sizes: Dict[str, List[Tuple[str, int]]], run: int = RUN
         body = lines[i + 1 : j]
         dis = sizes[name]
         # match instruction lines with the disassembly (alignment padding shows up there as extra s_nop)
-        seq: List[Tuple[int, int]] = []          # (index into body, size)
+        size_at: Dict[int, int] = {}
         k = 0
         ok = True
         for bi, line in enumerate(body):
@@ -103,46 +144,92 @@ def align_text(asm: str, sizes: Dict[str, List[Tuple[str, int]]], run: int = RUN
             if k >= len(dis) or dis[k][0] != mnem:
                 ok = False
                 break
-            seq.append((bi, dis[k][1]))
+            size_at[bi] = dis[k][1]
             k += 1
         if not ok:
             stats[name] = -1
             out.extend(lines[i:j])
             i = j
             continue
-        size_at = dict(seq)
-        insn_idx = [bi for bi, _ in seq]
-        pos_of = {bi: p for p, bi in enumerate(insn_idx)}
-        inserted = 0
-        offset = 0                                   # the function starts 256-byte aligned
-        new_body: List[str] = []
+        # ---- the items of the dynamic programme
+        items: List[Tuple[int, str, float, bool]] = []      # (body index, kind, weight, nop allowed in front)
         in_asm_block = False
         after_getpc = 0          # s_getpc_b64 + s_add_u32/s_addc_u32 with sym@rel32 literals: position dependent
+        depth = 0
         for bi, line in enumerate(body):
             s = line.strip()
             if s.startswith(";;#ASMSTART"):
                 in_asm_block = True
             elif s.startswith(";;#ASMEND"):
                 in_asm_block = False
+            if _local_label.match(line) or s.startswith("; %bb."):
+                d = _depth.search(line)
+                depth = int(d.group(1)) if d else 0
             if s.startswith(".p2align"):
-                a = 1 << int(re.split(r"[\s,]+", s)[1])
-                offset = (offset + a - 1) // a * a
-            if bi in size_at:
-                sz = size_at[bi]
-                if sz % 8 == 0 and offset % 8 == 4 and not in_asm_block and after_getpc == 0:
-                    # the run of 64-bit instructions that starts here
-                    p = pos_of[bi]
-                    length = 0
-                    while p + length < len(seq) and seq[p + length][1] % 8 == 0:
-                        length += 1
-                    if length >= run:
-                        new_body.append("\ts_nop 0")
-                        offset += 4
-                        inserted += 1
-                offset += sz
-                after_getpc = 4 if s.startswith("s_getpc_b64") else max(0, after_getpc - 1)
-            new_body.append(line)
-        stats[name] = inserted
+                if int(re.split(r"[\s,]+", s)[1]) >= 3:
+                    items.append((bi, "A", 0.0, False))
+                continue
+            if bi not in size_at:
+                continue
+            sz = size_at[bi]
+            w = float(8 ** min(depth, 3))
+            free = not in_asm_block and after_getpc == 0
+            if sz % 8 == 0:
+                kind = "8"
+            elif promote and free and sz == 4 and _promoted(line) is not None:
+                kind = "P"
+            else:
+                kind = "4"
+            items.append((bi, kind, w, free))
+            after_getpc = 4 if s.startswith("s_getpc_b64") else max(0, after_getpc - 1)
+        # ---- forward pass: best[state] = (cost, back pointer)
+        INF = float("inf")
+        cost = [0.0, INF]                                   # the function starts 256-byte aligned
+        back: List[List[Optional[Tuple[int, int, int]]]] = []      # per item, per resulting state: (previous state, nop, promoted)
+        for bi, kind, w, nop_ok in items:
+            nxt = [INF, INF]
+            bp: List[Optional[Tuple[int, int, int]]] = [None, None]
+            for p in (0, 1):
+                if cost[p] == INF:
+                    continue
+                for nop in ((0, 1) if nop_ok else (0,)):
+                    c0 = cost[p] + (nop_cost * w if nop else 0.0)
+                    p1 = p ^ nop
+                    options = []
+                    if kind == "A":
+                        options.append((0, c0, 0))
+                    elif kind == "8":
+                        options.append((p1, c0 + (w if p1 else 0.0), 0))
+                    elif kind == "4":
+                        options.append((p1 ^ 1, c0, 0))
+                    else:
+                        options.append((p1 ^ 1, c0, 0))
+                        options.append((p1, c0 + (w if p1 else 0.0), 1))
+                    for p2, c2, pr in options:
+                        if c2 < nxt[p2]:
+                            nxt[p2] = c2
+                            bp[p2] = (p, nop, pr)
+            cost = nxt
+            back.append(bp)
+        # ---- backward pass: the decisions
+        state = 0 if cost[0] <= cost[1] else 1
+        nop_before: Dict[int, bool] = {}
+        promoted: Dict[int, bool] = {}
+        for idx in range(len(items) - 1, -1, -1):
+            prev = back[idx][state]
+            assert prev is not None
+            p, nop, pr = prev
+            if nop:
+                nop_before[items[idx][0]] = True
+            if pr:
+                promoted[items[idx][0]] = True
+            state = p
+        new_body: List[str] = []
+        for bi, line in enumerate(body):
+            if nop_before.get(bi):
+                new_body.append("\ts_nop 0")
+            new_body.append(_promoted(line) if promoted.get(bi) else line)
+        stats[name] = len(nop_before) + len(promoted)
         out.append(lines[i])
         out.extend(new_body)
         i = j
@@ -168,8 +255,8 @@ def misaligned(sizes: Dict[str, List[Tuple[str, int]]]) -> Tuple[int, int]:
     return bad, total
 
 
-def align_file(asm_in: Path, asm_out: Path, scratch_obj: Path, run: int = RUN) -> Dict[str, int]:
+def align_file(asm_in: Path, asm_out: Path, scratch_obj: Path, nop_cost: float = NOP_COST) -> Dict[str, int]:
     assemble(asm_in, scratch_obj)
-    text, stats = align_text(asm_in.read_text(), disassembly_sizes(scratch_obj), run)
+    text, stats = align_text(asm_in.read_text(), disassembly_sizes(scratch_obj), nop_cost)
     asm_out.write_text(text)
     return stats

@@ -57,7 +57,7 @@ def compile_unit(src: Path, objdir: Path, extra_flags=(), align_run=None, verbos
     from . import asm_align
 
     hipcc = _hipcc()
-    run = asm_align.RUN if align_run is None else align_run
+    run = asm_align.NOP_COST if align_run is None else align_run
     obj = objdir / (src.stem + ".o")
     flags = [*FLAGS, *extra_flags]
 
@@ -74,7 +74,7 @@ def compile_unit(src: Path, objdir: Path, extra_flags=(), align_run=None, verbos
     sh([hipcc, *flags, "--cuda-device-only", "-S", src, "-o", asm])
     stats = asm_align.align_file(asm, aligned, dev_obj, run)
     if verbose:
-        print(f"{src.name}: {sum(v for v in stats.values() if v > 0)} s_nop inserted in {len(stats)} functions"
+        print(f"{src.name}: {sum(v for v in stats.values() if v > 0)} re-encodings / s_nop in {len(stats)} functions"
               + (f", {sum(1 for v in stats.values() if v == -2)} skipped" if any(v == -2 for v in stats.values()) else "")
               + (f", {sum(1 for v in stats.values() if v == -1)} NOT MATCHED" if any(v == -1 for v in stats.values()) else ""))
     asm_align.assemble(aligned, dev_obj)
@@ -108,7 +108,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
 
     objdir = PKG / "build"
     objdir.mkdir(exist_ok=True)
-    align_run = int(os.environ["MX_BUILD_ALIGN_RUN"]) if os.environ.get("MX_BUILD_ALIGN_RUN") else None
+    align_run = float(os.environ["MX_BUILD_ALIGN_RUN"]) if os.environ.get("MX_BUILD_ALIGN_RUN") else None
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:      # translation units in parallel
         objs = list(pool.map(lambda src: compile_unit(src, objdir, (), align_run, verbose), SOURCES))
     return link(objs, LIB, verbose)

@@ -13,7 +13,7 @@ args = sys.argv[1:]
 name = args.pop(0)
 align_run = None
 if args and args[0] == "--align-run":
-    align_run = int(args[1]); args = args[2:]
+    align_run = float(args[1]); args = args[2:]
 out = B.PKG / "build" / "variants"; objdir = out / name; objdir.mkdir(parents=True, exist_ok=True)
 with ThreadPoolExecutor(max_workers=len(B.SOURCES)) as pool:
     objs = list(pool.map(lambda src: B.compile_unit(src, objdir, args, align_run), B.SOURCES))
