@@ -195,15 +195,19 @@ int n2_auto_segments(int n_sqr, int64_t nblocks) {
   return (n_sqr >= 2048 && nblocks >= 256) ? 4 : 1;
 }
 
-inline int64_t n2_consts_bytes(int limbs_n) { return align256((int64_t)8 * limbs_n * 4); }
+inline int64_t n2_consts_words(int limbs_n) { return (int64_t)8 * limbs_n + 2 * (limbs_n + 1); }
+inline int64_t n2_consts_bytes(int limbs_n) { return align256(n2_consts_words(limbs_n) * 4); }
 
 // The eight constant rows of one geometry (R = 2^m), each limbs_n words:
 //   N | ONE0 ONE1 | K1_0 K1_1 | K2_0 K2_1 | C'
+// followed by two rows of limbs_n + 1 words for the passes modulo the friendly multiple N~ = u N, u = -N^-1 mod 2^W
+// (mx_powmod_n2.hpp; read by the 3-limb instances):
+//   N~ + 1 | C2' = C2 - u (R - 1),  C2 = N * ceil(u (R - 1) / N)
 void n2_constants(u32* c, const u32* h_n, int limbs_n, int m, int k) {
   const int l2 = 2 * limbs_n;
   std::vector<u32> n2(l2), tmp(l2), qq(l2), rr(limbs_n);
   mul_words(n2.data(), h_n, limbs_n, h_n, limbs_n);
-  std::memset(c, 0, (size_t)8 * limbs_n * 4);
+  std::memset(c, 0, (size_t)n2_consts_words(limbs_n) * 4);
   std::memcpy(&c[0], h_n, (size_t)limbs_n * 4);
   auto pair_of = [&](int pow2, int row) {                      // N-adic digits of 2^pow2 mod N^2
     pow2_mod(tmp.data(), n2.data(), l2, pow2);
@@ -225,6 +229,26 @@ void n2_constants(u32* c, const u32* h_n, int limbs_n, int m, int k) {
     cp[i] = (u32)e;
     carry = e >> 32;
   }
+  // ---- friendly rows
+  u32 inv = h_n[0];                                            // Newton: N^-1 mod 2^32
+  for (int i = 0; i < 5; ++i) inv *= 2u - h_n[0] * inv;
+  const u32 u = (0u - inv) & ((1u << LIMB_BITS) - 1u);
+  u32* nt = &c[(size_t)8 * limbs_n];
+  mul_words(nt, h_n, limbs_n, &u, 1);                          // N~ = u N  (limbs_n + 1 words), = -1 mod 2^W
+  for (int i = 0; i <= limbs_n; ++i) { if (++nt[i] != 0u) break; }      // + 1
+  // C2' = (u (1 - R)) mod N = (u * ((N + 1 - R mod N) mod N)) mod N      (rr = R mod N from above, != 0)
+  std::vector<u32> d(limbs_n), prod(limbs_n + 1), quo(limbs_n + 1), rem(limbs_n);
+  u64 br = 0, ca = 1;
+  for (int i = 0; i < limbs_n; ++i) {
+    u64 x = (u64)h_n[i] - rr[i] - br;
+    br = (x >> 63) & 1;
+    u64 e = (u64)(u32)x + ca;
+    d[i] = (u32)e;
+    ca = e >> 32;
+  }
+  mul_words(prod.data(), d.data(), limbs_n, &u, 1);
+  divmod_words(quo.data(), rem.data(), prod.data(), limbs_n + 1, h_n, limbs_n);
+  std::memcpy(&c[(size_t)8 * limbs_n + (limbs_n + 1)], rem.data(), (size_t)limbs_n * 4);
 }
 }  // namespace
 
@@ -292,9 +316,9 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
   auto emit = [&](u32 op, int arg) {
     tape.push_back((op << 28) | (u32)arg);
     if (op == mx::N2_SQR) n_sqr += arg;
-    if (op == mx::N2_MUL) n_mul += 1;
+    if (op == mx::N2_MUL || op == mx::N2_MULC) n_mul += 1;
     if (op == mx::N2_STORE) n_writes += 1;
-    if (op == mx::N2_MUL || op == mx::N2_ADD || op == mx::N2_LOAD) n_reads += 1;
+    if (op == mx::N2_MUL || op == mx::N2_MULC || op == mx::N2_ADD || op == mx::N2_LOAD) n_reads += 1;
   };
   if (ebits == 0) {
     emit(mx::N2_LOAD, mx::N2_SLOT_ONE);
@@ -316,7 +340,7 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
       if (ops[t].index1) emit(mx::N2_MUL, mx::N2_SLOT_TABLE + (int)ops[t].index1 - 1);
     }
   }
-  emit(mx::N2_MUL, mx::N2_SLOT_E);
+  emit(mx::N2_MULC, mx::N2_SLOT_E);          // the last product: digits below 2N for the epilogue (mx_powmod_n2.hpp)
   if ((int)tape.size() > MAX_SLIDING_OPS) return MX_ERR_SIZE;
 
   const int64_t cb = n2_consts_bytes(limbs_n);
@@ -333,7 +357,7 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
     if (same >= 0) {
       rows[g] = rows[same];
     } else {
-      rows[g].resize((size_t)8 * limbs_n);
+      rows[g].resize((size_t)n2_consts_words(limbs_n));
       n2_constants(rows[g].data(), h_n, limbs_n, m, k);
     }
     MX_TRY(upload_words(dp + g * cb, rows[g].data(), rows[g].size(), s));

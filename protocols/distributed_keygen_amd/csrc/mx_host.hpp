@@ -30,7 +30,9 @@ constexpr int MAX_MOD_BITS = LIMB_BITS * LIMBS_PER_LANE * 64 - 4;
 inline bool choose_geometry(int mod_bits, Geometry& g, int limbs_per_lane = LIMBS_PER_LANE) {
   if (mod_bits < 2 || mod_bits > MAX_MOD_BITS) return false;
   g.L = limbs_per_lane;
-  int need = mod_bits + 4;
+  // 3 limbs per lane (the pair kernel's latency instances) reduce modulo a multiple of N that is LIMB_BITS bits
+  // longer (mx_mont.hpp: F_FRIENDLY) and keep two more bits of head room for the lazy bound
+  int need = mod_bits + 4 + (limbs_per_lane == 3 ? LIMB_BITS + 2 : 0);
   int per_blk = g.W * g.L;
   g.nblk = (need + per_blk - 1) / per_blk;
   int k = 1;

@@ -62,10 +62,22 @@ struct Lanes {
     } else if constexpr (K == 16) {
       return dpp_mov<DPP_ROW_NEWBCAST0, 0xF, 0xF, true>(0, x);   // full masks + bound_ctrl: foldable into the consumer
     } else if constexpr (K == 32) {
-      u32 t = dpp_mov<DPP_ROW_NEWBCAST0, 0xF, 0xF, false>(x, x);
+      // the first move writes every lane (full masks, bound_ctrl): no "old" value, so x itself survives without a copy
+      u32 t = dpp_mov<DPP_ROW_NEWBCAST0, 0xF, 0xF, true>(0, x);
       return dpp_mov<DPP_ROW_BCAST15, 0xA, 0xF, false>(t, t);  // rows 1,3 <- lane 15 of rows 0,2
     } else {
       return (u32)__builtin_amdgcn_readfirstlane((int)x);
+    }
+  }
+
+  // bcast0(x) & m.  The mask commutes with the lane permutation; for 32-lane groups it is applied between the two
+  // moves, where it folds into the first one (v_and_b32_dpp) — behind the second, partial, move it is an instruction.
+  static __device__ __forceinline__ u32 bcast0_and(u32 x, u32 m) {
+    if constexpr (USE_DPP && K == 32) {
+      u32 t = dpp_mov<DPP_ROW_NEWBCAST0, 0xF, 0xF, true>(0, x) & m;
+      return dpp_mov<DPP_ROW_BCAST15, 0xA, 0xF, false>(t, t);
+    } else {
+      return bcast0(x) & m;
     }
   }
 

@@ -50,6 +50,8 @@ struct Mont {
   static constexpr int LDS_D = S + 4;          // offset of the second multiplier
 
   u32 n[L];      // modulus slice (exact W-bit limbs)
+  u32 nf[L];     // F_FRIENDLY: slice of N~ + 1, N~ = uf * N = -1 mod 2^W (set_friendly; unused and dropped otherwise)
+  u32 uf;        // F_FRIENDLY: uf = -N^-1 mod 2^W (= n0inv), kept apart for the quotient bookkeeping of the pair kernel
   u32 n0inv;     // -N^-1 mod 2^W
   u32 keep_next, keep_prev;
   u32 maskv;     // MASK held in a VGPR (a DPP-modified VOP2 cannot take a literal operand)
@@ -137,6 +139,9 @@ struct Mont {
     for (int i = 0; i < 4; ++i) x *= 2u - n0 * x;
     n0inv = (0u - x) & MASK;
   }
+
+  // F_FRIENDLY: nf[] must hold this lane's limbs of N~ + 1 (loaded by the caller from the host's constants)
+  __device__ __forceinline__ void setup_friendly() { uf = n0inv; }
 
   // ------------------------------------------------------------------ carry handling
   // 64-bit columns -> almost-normalised limbs (limb 1 may exceed 2^W by < 2^7).  One local carry
@@ -253,8 +258,16 @@ struct Mont {
   //               in the accumulator is the high part
   //   F_BDOUBLE   the multiplier staged in LDS is 2*b (used for the 2*X0*X1 row of a pair squaring)
   //   F_STAGED    the multiplier(s) are already in LDS (stage_multipliers): b and d are not read
+  //   F_FRIENDLY  reduce modulo N~ = uf * N, the multiple of N that is -1 modulo 2^W, instead of N: the quotient
+  //               digit of a step is then the low limb itself, q = t_0 mod 2^W — no multiplication by n0inv on
+  //               the dependent chain — and t + q * N~ = t - q + q * (N~ + 1): column 0 leaves as before (its low
+  //               W bits are q and are dropped), the other columns take q times the limbs of N~ + 1 (nf[], whose
+  //               limb 0 is 0).  The result is = a*b/R modulo N as always, but only < 2 N~: the caller keeps
+  //               W + 2 more bits of head room in R and reduces modulo N itself where it needs < 2N.  With
+  //               F_RECORD_Q the digits recorded are those of Q~ with a*b + Q~ * N~ = r * R.
+  //   F_INITQ     (with F_INIT) the accumulator starts from init + uf * initq, limb-wise
   static constexpr int F_RECORD_Q = 1, F_SQUARE = 2, F_TWO = 4, F_INIT = 8, F_PLAIN = 16, F_BDOUBLE = 32,
-                       F_STAGED = 64;
+                       F_STAGED = 64, F_FRIENDLY = 128, F_INITQ = 256;
 
   // b (and d) where every lane of the group can read any limb; they stay valid until the next staging
   __device__ __forceinline__ void stage_multipliers(const u32 (&b)[L], const u32 (&d)[L]) {
@@ -270,7 +283,7 @@ struct Mont {
     if constexpr (J != 0) {
       product_mac<(F & F_SQUARE) != 0, I, J>(t, a, bi, bi2);
       if constexpr (F & F_TWO) t[J] += (u64)c[J] * di;
-      if constexpr (!(F & F_PLAIN)) t[J] += (u64)n[J] * q;
+      if constexpr (!(F & F_PLAIN)) t[J] += (u64)((F & F_FRIENDLY) ? nf[J] : n[J]) * q;
     }
   }
 
@@ -295,9 +308,13 @@ struct Mont {
       if (p == 0) emit[blk * L + I] = (u32)t[0] & MASK;
     } else {
       // the mask is applied after the broadcast so that it folds into the DPP move (v_and_b32_dpp)
-      q = LN::bcast0((u32)t[0] * n0inv) & maskv;
+      if constexpr (F & F_FRIENDLY) {
+        q = LN::bcast0_and((u32)t[0], maskv);
+      } else {
+        q = LN::bcast0_and((u32)t[0] * n0inv, maskv);
+      }
       if constexpr (F & F_RECORD_Q) qr[I] = (blk == p) ? q : qr[I];
-      t[0] += (u64)n[0] * q;
+      t[0] += (u64)((F & F_FRIENDLY) ? nf[0] : n[0]) * q;
     }
     row_macs<F, I>(t, a, c, bi, bi2, di, q, std::make_integer_sequence<int, L>{});
     // divide by 2^W: column 0 leaves; its low W bits belong to the lower neighbour's top column
@@ -334,7 +351,8 @@ struct Mont {
   // a and c are not const: their registers are passed through an empty asm once per block (see
   // below); values are unchanged.
   __device__ __forceinline__ void mulx(u32 (&r)[L], u32 (&a)[L], const u32 (&b)[L], u32 (&c)[L],
-                                       const u32 (&d)[L], const u32 (&init)[L], u32* qrec, u32* emit, int nsteps_blk) {
+                                       const u32 (&d)[L], const u32 (&init)[L], u32* qrec, u32* emit, int nsteps_blk,
+                                       const u32* initq = nullptr) {
     // stage the multiplier(s) where every lane of the group can read any limb
     if constexpr (!(F & F_STAGED)) {
       sync();
@@ -348,7 +366,13 @@ struct Mont {
     }
     u64 t[L];
 #pragma unroll
-    for (int j = 0; j < L; ++j) t[j] = (F & F_INIT) ? (u64)init[j] : 0;
+    for (int j = 0; j < L; ++j) {
+      if constexpr ((F & F_INIT) && (F & F_INITQ)) {
+        t[j] = (u64)init[j] + (u64)initq[j] * uf;
+      } else {
+        t[j] = (F & F_INIT) ? (u64)init[j] : 0;
+      }
+    }
     u32 qr[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) qr[j] = 0;
@@ -368,11 +392,18 @@ struct Mont {
       // extension to 64 bits out of this loop — every limb then occupies a register PAIR for the
       // whole product (v_mad_u64_u32 only reads the low half).  Opaque per block: the extension
       // folds into the multiply-add and the limbs stay in single registers.
+      // (not for the few-limb instances: registers are no concern there, and the barriers cost them moves)
 #pragma unroll
-      for (int j = 0; j < L; ++j) {
+      for (int j = 0; j < (PREFETCH ? 0 : L); ++j) {
         asm volatile("" : "+v"(a[j]));
         if constexpr (F & F_TWO) asm volatile("" : "+v"(c[j]));
-        if constexpr (!(F & F_PLAIN)) asm volatile("" : "+v"(n[j]));
+        if constexpr (!(F & F_PLAIN)) {
+          if constexpr (F & F_FRIENDLY) {
+            asm volatile("" : "+v"(nf[j]));
+          } else {
+            asm volatile("" : "+v"(n[j]));
+          }
+        }
       }
       u32 bb[L], dd[L];
       if constexpr (PREFETCH) {

@@ -31,7 +31,9 @@ namespace mx {
 // sliding-window exponentiation are all sequences of five operations on one pair register `acc`
 // and pair slots in device memory.  This keeps ONE squaring and ONE multiplication call site in
 // the kernel (each is two inlined Montgomery passes), which is what bounds code size and registers.
-enum : u32 { N2_SQR = 0, N2_MUL = 1, N2_ADD = 2, N2_LOAD = 3, N2_STORE = 4 };
+// N2_MULC: a multiplication whose digits must come out below 2N (the last one, by (1, 0)); kernels without the friendly
+// passes treat it as N2_MUL
+enum : u32 { N2_SQR = 0, N2_MUL = 1, N2_ADD = 2, N2_LOAD = 3, N2_STORE = 4, N2_MULC = 5 };
 // tape word = (op << 28) | argument   (argument: repeat count for SQR, slot index otherwise)
 // slots: 0 K1 (represents R), 1 K2 (represents 2^k R), 2 E = (1, 0), 3 ONE, 4 (x_lo, 0), 5 (x_hi, 0),
 //        6 scratch, 7 x^2, 8.. odd powers x^(2k+1)
@@ -50,7 +52,7 @@ constexpr size_t powmod_n2_lds_bytes() { return ((size_t)(64 / K) * (2 * K * L +
 struct PowmodN2Args {
   const u32* bases;   // [batch][limbs2] device
   u32* out;           // [batch][limbs2] device
-  const u32* consts;  // [8][limbsn] device: N, ONE0, ONE1, K1_0, K1_1, K2_0, K2_1, C'
+  const u32* consts;  // [8][limbsn] device: N, ONE0, ONE1, K1_0, K1_1, K2_0, K2_1, C'; then [2][limbsn + 1]: N~ + 1, C2' (friendly passes)
   const u32* tape;    // [ntape] device
   u32* slots;         // [nslots][2][L][nlanes] device
   i64 batch;
@@ -69,20 +71,36 @@ struct PowmodN2Args {
   int sched_groups, sched_segments, sched_n_sqr;
 };
 
+// FR ("friendly"): the passes reduce modulo N~ = u * N = -1 mod 2^W instead of N (Mont::F_FRIENDLY: no multiplication
+// on the quotient digit's chain).  Pass 1 then gives X0*Y0 = t0*R - Q~*N~ = t0*R - (u Q~)*N, so the correction in
+// front of N is u*Q~, and the second pass starts from
+//       C2 - u*Q~  =  C2' + u * (R - 1 - Q~),     C2 = N * ceil(u (R - 1) / N),   C2' = C2 - u (R - 1)  in [0, N)
+// limb-wise: c2'_i + u * (MASK - q~_i), again without a borrow (64-bit lazy columns).  Digits stay below 2 N~; the
+// last multiplication of an exponentiation (by (1, 0)) is done with the plain passes, which bring both digits of
+// the result below 2N for the epilogue.
 template <class M_t>
 struct PairArithT {
   static constexpr int L = M_t::LIMBS;
   static constexpr u32 MASK = M_t::MASK;
+  static constexpr int FRF = M_t::F_FRIENDLY;
   M_t& M;
   const u32* cp;      // LDS: limbs of C' = C - R + 1 (one copy per workgroup, slice of lane p at cp[p*L ..])
+  const u32* cp2;     // LDS: limbs of C2' (friendly passes), same layout; nullptr where they are not used
 
-  __device__ __forceinline__ PairArithT(M_t& m, const u32* cprime_lds) : M(m), cp(cprime_lds) {}
+  __device__ __forceinline__ PairArithT(M_t& m, const u32* cprime_lds, const u32* c2prime_lds = nullptr)
+      : M(m), cp(cprime_lds), cp2(c2prime_lds) {}
 
   // accumulator start of the second pass: C' + (R - 1 - Q), limb-wise (in place in q)
   __device__ __forceinline__ void second_pass_init(u32 (&q)[L]) const {
     const bool has_q = M.p < M.nblk;
 #pragma unroll
     for (int j = 0; j < L; ++j) q[j] = cp[M.p * L + j] + (has_q ? (MASK - q[j]) : 0u);
+  }
+  // friendly form: init = C2' (returned in c2), q becomes MASK - q~ (scaled by u inside the product)
+  __device__ __forceinline__ void second_pass_init_friendly(u32 (&c2)[L], u32 (&q)[L]) const {
+    const bool has_q = M.p < M.nblk;
+#pragma unroll
+    for (int j = 0; j < L; ++j) { c2[j] = cp2[M.p * L + j]; q[j] = has_q ? (MASK - q[j]) : 0u; }
   }
 
   // The two passes of a pair product, separately: the first (Z0 and the quotient Q) involves only the
@@ -93,20 +111,36 @@ struct PairArithT {
     M.template mulx<M_t::F_RECORD_Q | M_t::F_STAGED>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
   }
   //   pass 1 on its own (stages y0 itself; the split kernel's first wavefront has no use for y1)
+  template <bool FR = false>
   __device__ __forceinline__ void mul_pass1_unstaged(u32 (&t0)[L], u32 (&q)[L], u32 (&x0)[L], const u32 (&y0)[L]) {
-    M.template mulx<M_t::F_RECORD_Q>(t0, x0, y0, x0, y0, y0, q, nullptr, M.nblk);
+    M.template mulx<M_t::F_RECORD_Q | (FR ? FRF : 0)>(t0, x0, y0, x0, y0, y0, q, nullptr, M.nblk);
   }
+  template <bool FR = false>
   __device__ __forceinline__ void mul_pass2(u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L], u32 (&q)[L]) {
-    second_pass_init(q);
-    M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_STAGED>(z1, x1, x1, x0, x1, q, nullptr, nullptr, M.nblk);
+    if constexpr (FR) {
+      u32 c2[L];
+      second_pass_init_friendly(c2, q);
+      M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_INITQ | M_t::F_STAGED | FRF>(z1, x1, x1, x0, x1, c2, nullptr, nullptr, M.nblk, q);
+    } else {
+      second_pass_init(q);
+      M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_STAGED>(z1, x1, x1, x0, x1, q, nullptr, nullptr, M.nblk);
+    }
   }
   //   squaring
+  template <bool FR = false>
   __device__ __forceinline__ void sqr_pass1(u32 (&t0)[L], u32 (&q)[L], u32 (&x0)[L]) {
-    M.template mulx<M_t::F_RECORD_Q | M_t::F_SQUARE>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
+    M.template mulx<M_t::F_RECORD_Q | M_t::F_SQUARE | (FR ? FRF : 0)>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
   }
+  template <bool FR = false>
   __device__ __forceinline__ void sqr_pass2(u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L], u32 (&q)[L]) {
-    second_pass_init(q);
-    M.template mulx<M_t::F_INIT | M_t::F_BDOUBLE>(z1, x0, x1, x0, x1, q, nullptr, nullptr, M.nblk);   // 2 * X0 * X1
+    if constexpr (FR) {
+      u32 c2[L];
+      second_pass_init_friendly(c2, q);
+      M.template mulx<M_t::F_INIT | M_t::F_INITQ | M_t::F_BDOUBLE | FRF>(z1, x0, x1, x0, x1, c2, nullptr, nullptr, M.nblk, q);   // 2 * X0 * X1
+    } else {
+      second_pass_init(q);
+      M.template mulx<M_t::F_INIT | M_t::F_BDOUBLE>(z1, x0, x1, x0, x1, q, nullptr, nullptr, M.nblk);   // 2 * X0 * X1
+    }
   }
 
   // (z0, z1) = (x0, x1) * (y0, y1); outputs may alias inputs
@@ -239,7 +273,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
       u32 f0[L], f1[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) { f0[j] = slot_at(arg, 0, j); f1[j] = slot_at(arg, 1, j); }
-      if (op == N2_MUL) {
+      if (op == N2_MUL || op == N2_MULC) {
         P.mul(acc0, acc1, acc0, acc1, f0, f1);
       } else if (op == N2_ADD) {
         M.add(acc0, acc0, f0);

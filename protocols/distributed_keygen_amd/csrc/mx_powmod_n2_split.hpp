@@ -56,7 +56,7 @@ template <int K, int L>
 constexpr size_t powmod_n2_split_lds_bytes() {
   // per pair: two wavefronts' Montgomery scratch, the two mailbox entries of 2 L words per lane and the two
   // hand-over counters (+ the unit word of the persistent form); one C'
-  return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64 + 4) + (size_t)K * L) * 4;
+  return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64 + 4) + (size_t)(L == 3 ? 2 : 1) * K * L) * 4;
 }
 
 // Scheduling state of a time-sliced launch in device memory (zeroed by the host before the launch): the work queue
@@ -84,6 +84,11 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   u32* unit_word = produced + 2;                            // persistent form: the unit A has taken for the pair
   if (half == 0 && lane == 0) { *produced = 0; *consumed = 0; }
   u32* cp_lds = smem + N2_SPLIT_PAIRS * PAIR_WORDS;
+  // The 3-limb (latency) instances run their passes modulo the friendly multiple of N (mx_powmod_n2.hpp): the
+  // multiplication by -N^-1 leaves the dependent chain of every limb step.  They have 3 * K * 29 bits of room where
+  // N needs K * 3 * 29 - 35 at most (mx_host.hpp: choose_geometry).
+  constexpr bool FR = L == 3;
+  u32* cp2_lds = cp_lds + K * L;
   auto mb = [&](int entry, int j) -> u32& { return mbox[(entry * 2 * L + j) * 64 + lane]; };
 
   M_t M;
@@ -91,6 +96,10 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   M.load(M.n, A.consts, A.limbsn);
   M.setup_modulus();
   const int p = M.p;
+  if constexpr (FR) {
+    M.load(M.nf, A.consts + 8 * A.limbsn, A.limbsn + 1);          // N~ + 1
+    M.setup_friendly();
+  }
   if (half == 1) {
     u32 v[L];
     M.load(v, A.consts + 7 * A.limbsn, A.limbsn);
@@ -98,8 +107,15 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
 #pragma unroll
       for (int j = 0; j < L; ++j) cp_lds[p * L + j] = v[j];
     }
+    if constexpr (FR) {
+      M.load(v, A.consts + 8 * A.limbsn + (A.limbsn + 1), A.limbsn + 1);      // C2'
+      if (gw == 0 && pair == 0) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) cp2_lds[p * L + j] = v[j];
+      }
+    }
   }
-  PairArithT<M_t> P(M, cp_lds);
+  PairArithT<M_t> P(M, cp_lds, FR ? cp2_lds : nullptr);
   __syncthreads();            // C' and the counters are in place (the kernel's only workgroup barrier)
 
   u32 seq = 0;                                      // entries handed over so far (the same count in both wavefronts)
@@ -249,14 +265,14 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
           u32 q[L];
           if (half == 0) {
             u32 t0[L];
-            P.sqr_pass1(t0, q, acc);
+            P.template sqr_pass1<FR>(t0, q, acc);
             send(acc, q);
 #pragma unroll
             for (int j = 0; j < L; ++j) acc[j] = t0[j];
           } else {
             u32 x0[L];
             receive(x0, q);
-            P.sqr_pass2(acc, x0, acc, q);
+            P.template sqr_pass2<FR>(acc, x0, acc, q);
           }
         }
         pos += arg;
@@ -266,13 +282,19 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
       if (op == N2_STORE) {
 #pragma unroll
         for (int j = 0; j < L; ++j) slot_at(arg, j) = acc[j];
-      } else if (op == N2_MUL) {
+      } else if (op == N2_MUL || op == N2_MULC) {
+        // N2_MULC (the last product of an exponentiation): plain passes, digits below 2N for the epilogue
+        const bool friendly = FR && op == N2_MUL;
         u32 q[L], f0[L];
         if (half == 0) {
           u32 t0[L];
 #pragma unroll
           for (int j = 0; j < L; ++j) f0[j] = slot_at(arg, j);
-          P.mul_pass1_unstaged(t0, q, acc, f0);
+          if (friendly) {
+            P.template mul_pass1_unstaged<FR>(t0, q, acc, f0);
+          } else {
+            P.template mul_pass1_unstaged<false>(t0, q, acc, f0);
+          }
           send(acc, q);
 #pragma unroll
           for (int j = 0; j < L; ++j) acc[j] = t0[j];
@@ -286,7 +308,11 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
 #pragma unroll
           for (int j = 0; j < L; ++j) f0[j] = slot_other(arg, j);
           M.stage_multipliers(f0, f1);
-          P.mul_pass2(acc, x0, acc, q);
+          if (friendly) {
+            P.template mul_pass2<FR>(acc, x0, acc, q);
+          } else {
+            P.template mul_pass2<false>(acc, x0, acc, q);
+          }
         }
       } else {
         u32 f[L];

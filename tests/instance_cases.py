@@ -30,7 +30,7 @@ N2_CASES = [
     ("n2", 400, 18, 70, 130, 2), ("n2", 900, 18, 40, 130, 2), ("n2", 2051, 18, 37, 200, 2),
     ("n2", 3075, 18, 12, 96, 2), ("n2", 4099, 18, 12, 96, 2), ("n2", 6000, 18, 6, 64, 2), ("n2", 8200, 18, 6, 64, 2),
     # two wavefronts per group, latency geometry L = 3: K = 1, 2, 4, 8, 16, 32, 64, 64
-    ("n2", 60, 3, 130, 100, 2), ("n2", 150, 3, 67, 130, 2), ("n2", 300, 3, 35, 130, 2), ("n2", 600, 3, 19, 130, 2),
+    ("n2", 50, 3, 130, 90, 2), ("n2", 130, 3, 67, 130, 2), ("n2", 300, 3, 35, 130, 2), ("n2", 600, 3, 19, 130, 2),
     ("n2", 1027, 3, 9, 130, 2), ("n2", 2051, 3, 5, 200, 2), ("n2", 3075, 3, 3, 96, 2), ("n2", 4099, 3, 3, 96, 2),
     # the library's choice: a handful of elements -> the latency geometry on two wavefronts
     ("n2", 2051, 0, 7, 64, 0),
