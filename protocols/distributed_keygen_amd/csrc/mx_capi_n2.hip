@@ -119,9 +119,12 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   N2Shape p;
   if (!shape_n2(n_bits, 1, batch, lpl, wpg, p)) return -1.0;
   const double L = p.geo.L, steps = (double)p.geo.nblk * p.geo.L;
-  const double m = wpg == 2 ? 2 * L : (p.geo.L / 2 + 1) + 3 * L, o = wpg == 2 ? 11.0 : 20.0;
+  // (3 limbs per lane: the friendly-modulus passes have 8 other instructions per step, and a second wavefront on
+  // the SIMD costs them 1.22x what the issue costs alone would say — 13.0 / 19.9 / 27.4 / 35.3 ms for 1 .. 4 per SIMD)
+  const bool lat = lpl == LIMBS_PER_LANE_LAT;
+  const double m = wpg == 2 ? 2 * L : (p.geo.L / 2 + 1) + 3 * L, o = lat ? 8.0 : wpg == 2 ? 11.0 : 20.0;
   const double alone = steps * (5.3 * (m + o) + 80.0 / L);
-  const double shared = steps * (4.2 * m + 2.3 * o) * (wpg == 2 ? 1.0 : 1.17);     // one wavefront doing both passes overlaps less
+  const double shared = steps * (4.2 * m + 2.3 * o) * (lat ? 1.22 : wpg == 2 ? 1.0 : 1.17);     // one wavefront doing both passes overlaps less
   const int cus = device_cus();
   const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
   const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;

@@ -43,11 +43,11 @@ def test_auto_launch_shapes_match_the_measured_crossovers():
 
     lib = _lib.lib()
     shape = lambda bits, batch: ic.case_instance(lib, ("n2", bits, 0, batch, 0, 0))
-    for batch, want in ((1, (32, 3, 2)), (64, (32, 3, 2)), (1000, (32, 3, 2)), (2000, (8, 9, 2)), (4096, (8, 9, 2)),
+    for batch, want in ((1, (32, 3, 2)), (64, (32, 3, 2)), (1000, (32, 3, 2)), (2000, (32, 3, 2)), (3000, (8, 9, 2)), (4096, (8, 9, 2)),
                         (6144, (4, 18, 2)), (8192, (4, 18, 2)), (10000, (8, 9, 2)), (12288, (8, 9, 2)), (16384, (4, 18, 2)),
                         (20000, (8, 9, 2)), (24576, (4, 18, 2)), (30000, (4, 18, 1))):
         assert shape(2051, batch) == ("n2",) + want, batch
-    for batch, want in ((1, (64, 3, 2)), (512, (64, 3, 2)), (1024, (16, 9, 2)), (4096, (8, 18, 2)), (16000, (8, 18, 1))):
+    for batch, want in ((1, (64, 3, 2)), (512, (64, 3, 2)), (1024, (64, 3, 2)), (2048, (16, 9, 2)), (4096, (8, 18, 2)), (16000, (8, 18, 1))):
         assert shape(4099, batch) == ("n2",) + want, batch
     assert shape(1027, 256) == ("n2", 16, 3, 2) and shape(1027, 1000000)[3] == 1
     # an explicit argument pins that half of the choice
