@@ -98,7 +98,7 @@ def run(cfg_path: str) -> None:
                         ("n2split", 3): 64, ("n2split", 9): 32, ("n2split", 18): 16}[(kind, L)]
             eng.set_wavefronts_per_group(2 if kind == "n2split" else 1)
             for nblk in range(1, max_nblk + 1):
-                bits = W * L * nblk - 4
+                bits = W * L * nblk - (4 if L != 3 else 4 + W + 2)          # the head room of mx_host.hpp: choose_geometry
                 if bits < 8:
                     continue
                 k = 1
