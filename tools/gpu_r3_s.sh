@@ -1,11 +1,3 @@
-# round 3, call S: A/B of library variants on the fixed launch points
 export TMPDIR=/tmp
-O=gpurun_out/r03s; mkdir -p $O
 V=protocols/distributed_keygen_amd/build/variants
-for round in 1 2; do
-for lib in $(ls $V/*.so); do
-  export MX_LIBRARY=$PWD/$lib
-  timeout 300 python tools/ts_r_probe.py 2>/dev/null | tail -1
-done
-done > $O/variants.txt
-cat $O/variants.txt
+FR_B=2048 MX_LIBRARY=$PWD/$V/base.so timeout 800 python tools/fr_check.py 2>&1 | tail -14; FR_B=2048 MX_LIBRARY=$PWD/$V/fr1w.so timeout 800 python tools/fr_check.py 2>&1 | tail -14
