@@ -119,3 +119,44 @@ def test_nsquare_randomized_differential_over_launch_shapes(eng):
     finally:
         eng.set_limbs_per_lane(0)
         eng.set_wavefronts_per_group(0)
+
+
+def test_nsquare_four_streams_at_once_every_launch_shape(eng):
+    """Four launches in flight on four streams, every launch shape (and the time-sliced form forced on): each stream's
+    rows bit for bit against CPython pow at key_length 2048 with a full-length exponent.  Single-stream parity says
+    nothing about what launches share while they overlap — an experimental kernel of round 3 passed every
+    single-stream test at full size and returned wrong rows here."""
+    import multiprocessing as mp
+
+    import torch
+
+    from protocols.distributed_keygen_amd import limbs as L, synthetic
+
+    key = synthetic.make_key(2048, 3, 1)
+    own = next(i for i in (1, 2, 3) if key.exponent(i) > 0)
+    exp, n, n2 = key.exponent(own), key.n, key.n_square
+    batch = 1200
+    cts = synthetic.random_ciphertexts(key, batch, seed=23)
+    with mp.Pool() as pool:
+        want = pool.starmap(pow, [(c, exp, n2) for c in cts], chunksize=8)
+    rows = eng.to_device(L.pack(cts, L.limbs_for(n2)))
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    try:
+        for lpl, wpg, sliced in ((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (3, 2, 0)):
+            eng.set_limbs_per_lane(lpl)
+            eng.set_wavefronts_per_group(wpg)
+            eng.debug_knob("n2_timeslice", sliced)
+            for rep in range(2):
+                outs = []
+                for st in streams:
+                    with torch.cuda.stream(st):
+                        outs.append(eng.powmod_nsquare_t(rows, n, exp))
+                torch.cuda.synchronize()
+                for k, out in enumerate(outs):
+                    got = L.unpack(eng.to_host(out))
+                    bad = [i for i in range(batch) if got[i] != want[i]]
+                    assert not bad, (lpl, wpg, sliced, rep, k, len(bad), bad[:8])
+    finally:
+        eng.debug_knob("n2_timeslice", 0)
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)

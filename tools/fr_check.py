@@ -14,7 +14,7 @@ cts = synthetic.random_ciphertexts(key, B, seed=11)
 with mp.Pool(16) as pool:
     want = pool.starmap(pow, [(c, exp, n2) for c in cts], chunksize=16)
 c_all = eng.to_device(L.pack(cts, L.limbs_for(n2)))
-for lpl, wpg in ((18, 1), (9, 1)):
+for lpl, wpg in ((18, 1), (9, 1), (3, 2), (9, 2)):
     for seg in (1, 4):
         eng.set_limbs_per_lane(lpl); eng.set_wavefronts_per_group(wpg)
         got = L.unpack(eng.to_host(eng.powmod_nsquare_t(c_all, n, exp, segments=seg)))
@@ -26,10 +26,11 @@ for lpl, wpg in ((18, 1), (9, 1)):
             print("   diff mod N:", d % n, " diff // N:", d // n if d % n == 0 else None, " got < n2:", got[i] < n2)
 
 # the same launches from four streams at once (each its own output and workspace), default segments
-for lpl, wpg in ((18, 1),):
+for lpl, wpg in ((18, 1), (9, 2), (18, 2), (3, 2), (9, 1)):
     eng.set_limbs_per_lane(lpl); eng.set_wavefronts_per_group(wpg)
+    print(f"L{lpl}x{wpg}w, time-sliced: {eng.nsquare_launch_timesliced(n.bit_length(), B)}")
     streams = [torch.cuda.Stream() for _ in range(4)]
-    for rep in range(3):
+    for rep in range(2):
         outs = []
         for st in streams:
             with torch.cuda.stream(st):
