@@ -97,8 +97,9 @@ def link(objs, out: Path, verbose: bool = False) -> Path:
 
 
 def build(force: bool = False, verbose: bool = False) -> Path:
-    """Compile the shared library for gfx950; returns its path.  MX_BUILD_ALIGN_RUN=0 in the environment of the BUILD
-    (not read by the library) skips the assembly alignment pass — for A/B runs of the pass itself."""
+    """Compile the shared library for gfx950; returns its path.  MX_BUILD_ALIGN_RUN in the environment of the BUILD
+    (not read by the library): the cost of an inserted s_nop in the assembly alignment pass, 0 = no pass — for A/B runs
+    of the pass itself."""
     if not force and not needs_build():
         return LIB
     build_codec(verbose)

@@ -2,7 +2,7 @@
 """Builds libmxpaillier with extra compiler flags and/or another run length of the alignment pass into
 protocols/distributed_keygen_amd/build/variants/<name>.so (developer tool for A/B runs through MX_LIBRARY,
 tools/ab_variants.sh, tools/variant_probe.py).
-usage: build_variant.py <name> [--align-run N] [flags ...]      (N = 0: no alignment pass)"""
+usage: build_variant.py <name> [--align-run X] [flags ...]      (X: cost of an s_nop in the alignment pass, 0 = no pass)"""
 import sys
 from concurrent.futures import ThreadPoolExecutor
 from pathlib import Path
