@@ -418,6 +418,9 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   a.ntape = plan->ntape;
   a.slots = (u32*)d_ws;
   a.batch = batch; a.limbsn = plan->limbs_n; a.limbs2 = limbs2; a.nblk = p.geo.nblk; a.ksplit = bits - 1;
+  // the passes modulo the friendly multiple of N need LIMB_BITS + 2 more bits of room in R than the plain ones (the
+  // 3-limb geometries always have them, choose_geometry; the 9-limb two-wavefront kernels come in both forms)
+  a.friendly = bits + 4 + LIMB_BITS + 2 <= p.geo.W * p.geo.L * p.geo.nblk;
   hipStream_t s = (hipStream_t)stream;
   // segments: consecutive launches that each execute a stretch of the tape (mx_powmod_n2.hpp); positions
   // are counted in squarings, the accumulator travels through a scratch slot of the workspace

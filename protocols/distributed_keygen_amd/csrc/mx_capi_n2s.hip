@@ -4,15 +4,15 @@
 #include "mx_powmod_n2_split.hpp"
 
 namespace mxs {
-template <int K, int L, bool TS>
+template <int K, int L, bool TS, bool FR = (L == 3)>
 static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
-  size_t lds = mx::powmod_n2_split_lds_bytes<K, L>();
+  size_t lds = mx::powmod_n2_split_lds_bytes<K, L>(FR);
   if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS>),
+    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS, FR>),
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     MX_HIP(attr);
   }
-  hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
+  hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS, FR>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
 }
@@ -20,6 +20,11 @@ static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s
 // of wider groups that outnumbers the resident wavefronts is better served by more limbs per lane
 template <int K, int L>
 static int launch(bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  // friendly-modulus instances of the 9-limb kernel: groups of 8 and 16 lanes (key_length 2048 and 4096), where the
+  // host found LIMB_BITS + 6 bits of room in R (a.friendly)
+  if constexpr (L == LIMBS_PER_LANE && (K == 8 || K == 16)) {
+    if (a.friendly) return ts ? launch_form<K, L, true, true>(a, nblocks, s) : launch_form<K, L, false, true>(a, nblocks, s);
+  }
   if constexpr (L == LIMBS_PER_LANE && K <= 16) {
     if (ts) return launch_form<K, L, true>(a, nblocks, s);
   }

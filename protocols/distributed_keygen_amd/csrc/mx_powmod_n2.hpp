@@ -65,6 +65,7 @@ struct PowmodN2Args {
   // then lives 1/segments as long, which is the granularity at which a burst of launches drains.
   int pos_begin, pos_end;
   int first, last;    // first segment: input conversion prologue; last segment: output epilogue
+  int friendly;       // host: the modulus leaves room for the friendly-modulus passes (the 9-limb two-wavefront kernels pick their instance by it)
   // persistent (time-sliced) form of the two-wavefront kernel, mx_powmod_n2_split.hpp: scheduling words in device
   // memory (ticket, finished segments per group), groups of elements, segments per group, squarings of the tape
   u32* sched;

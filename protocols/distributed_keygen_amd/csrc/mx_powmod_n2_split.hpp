@@ -53,15 +53,15 @@ namespace mx {
 constexpr int N2_SPLIT_PAIRS = 2;      // wavefront pairs per workgroup (4 wavefronts: one per SIMD of a CU)
 
 template <int K, int L>
-constexpr size_t powmod_n2_split_lds_bytes() {
+constexpr size_t powmod_n2_split_lds_bytes(bool friendly = L == 3) {
   // per pair: two wavefronts' Montgomery scratch, the two mailbox entries of 2 L words per lane and the two
   // hand-over counters (+ the unit word of the persistent form); one C'
-  return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64 + 4) + (size_t)(L == 3 ? 2 : 1) * K * L) * 4;
+  return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64 + 4) + (size_t)(friendly ? 2 : 1) * K * L) * 4;
 }
 
 // Scheduling state of a time-sliced launch in device memory (zeroed by the host before the launch): the work queue
 // described at the unit loop below, 2 + groups x (segments - 1) words.
-template <int K, int L, int W, bool PERSISTENT>
+template <int K, int L, int W, bool PERSISTENT, bool FRIENDLY = (L == 3)>
 __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true, false>;          // wavefront-level ordering of the group scratch
   constexpr int S = M_t::S;
@@ -85,9 +85,10 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
   if (half == 0 && lane == 0) { *produced = 0; *consumed = 0; }
   u32* cp_lds = smem + N2_SPLIT_PAIRS * PAIR_WORDS;
   // The 3-limb (latency) instances run their passes modulo the friendly multiple of N (mx_powmod_n2.hpp): the
-  // multiplication by -N^-1 leaves the dependent chain of every limb step.  They have 3 * K * 29 bits of room where
-  // N needs K * 3 * 29 - 35 at most (mx_host.hpp: choose_geometry).
-  constexpr bool FR = L == 3;
+  // multiplication by -N^-1 leaves every limb step.  They have 3 * K * 29 bits of room where N needs K * 3 * 29 - 35
+  // at most (mx_host.hpp: choose_geometry).  The 9-limb instances of key_length 2048 and 4096 (groups of 8 and 16
+  // lanes) exist in both forms; the host launches the friendly one where the modulus leaves that room.
+  constexpr bool FR = FRIENDLY;
   u32* cp2_lds = cp_lds + K * L;
   auto mb = [&](int entry, int j) -> u32& { return mbox[(entry * 2 * L + j) * 64 + lane]; };
 

@@ -32,6 +32,9 @@ N2_CASES = [
     # two wavefronts per group, latency geometry L = 3: K = 1, 2, 4, 8, 16, 32, 64, 64
     ("n2", 50, 3, 130, 90, 2), ("n2", 130, 3, 67, 130, 2), ("n2", 300, 3, 35, 130, 2), ("n2", 600, 3, 19, 130, 2),
     ("n2", 1027, 3, 9, 130, 2), ("n2", 2051, 3, 5, 200, 2), ("n2", 3075, 3, 3, 96, 2), ("n2", 4099, 3, 3, 96, 2),
+    # two wavefronts per group, L = 9, K = 8 and 16 with a modulus that leaves NO room for the friendly-modulus passes
+    # (the cases at 2051 and 4099 bits above run the friendly instances, these the plain ones of the same geometry)
+    ("n2", 2075, 9, 19, 200, 2), ("n2", 4160, 9, 9, 96, 2),
     # the library's choice: a handful of elements -> the latency geometry on two wavefronts
     ("n2", 2051, 0, 7, 64, 0),
 ]

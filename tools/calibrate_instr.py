@@ -99,6 +99,8 @@ def run(cfg_path: str) -> None:
             eng.set_wavefronts_per_group(2 if kind == "n2split" else 1)
             for nblk in range(1, max_nblk + 1):
                 bits = W * L * nblk - (4 if L != 3 else 4 + W + 2)          # the head room of mx_host.hpp: choose_geometry
+                if kind == "n2split" and L == 9 and 4 < nblk <= 16:
+                    bits = W * L * nblk - (4 + W + 2)      # groups of 8 / 16 lanes: the friendly instances (what key_length 2048 / 4096 run)
                 if bits < 8:
                     continue
                 k = 1
