@@ -31,7 +31,22 @@ import subprocess
 from pathlib import Path
 from typing import Dict, List, Optional, Tuple
 
-LLVM_BIN = Path("/opt/rocm/lib/llvm/bin")
+def _llvm_bin() -> Path:
+    """The LLVM tools of the ROCm installation (clang as assembler, lld, llvm-objdump, clang-offload-bundler)."""
+    import os
+    import shutil
+
+    cands = [Path(os.environ.get("ROCM_PATH", "/opt/rocm")) / "lib" / "llvm" / "bin"]
+    hipcc = shutil.which("hipcc")
+    if hipcc:
+        cands.append(Path(hipcc).resolve().parent.parent / "lib" / "llvm" / "bin")
+    for c in cands:
+        if (c / "llvm-objdump").exists() and (c / "lld").exists():
+            return c
+    raise RuntimeError("LLVM tools of ROCm not found (looked in " + ", ".join(map(str, cands)) + "); set ROCM_PATH")
+
+
+LLVM_BIN = _llvm_bin()
 NOP_COST = 4.0    # an inserted s_nop is taken when it aligns more than this many 64-bit instructions (3, 5, 8 measured alike)
 # Left alone: the instances with 3 limbs per lane (template arguments <K, 3, 29, ...>).  Their blocks are a few dozen
 # instructions on ONE dependent chain (the latency geometry); measured, s_nop insertion cost them 3-6 % (14.8 -> 15.3 ms
