@@ -1,5 +1,8 @@
-# round 3, call S: mismatch census of the library as shipped, single launches and four streams at once
 export TMPDIR=/tmp
-O=gpurun_out/r03s; mkdir -p $O
-FR_B=10000 timeout 900 python tools/fr_check.py > $O/census_10000.txt 2>&1; grep -v amdgpu.ids $O/census_10000.txt
-FR_B=1500 timeout 600 python tools/fr_check.py > $O/census_1500.txt 2>&1; grep -v amdgpu.ids $O/census_1500.txt
+V=protocols/distributed_keygen_amd/build/variants
+for round in 1 2; do
+for lib in default $(ls $V/*.so); do
+  if [ "$lib" = default ]; then unset MX_LIBRARY; else export MX_LIBRARY=$PWD/$lib; fi
+  timeout 300 python tools/variant_probe.py 2>/dev/null | tail -1 | python3 -c "import sys; p=sys.stdin.read().split(); print(p[0], [x for x in ' '.join(p).split('|') if 'L3' in x])"
+done
+done
