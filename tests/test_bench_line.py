@@ -1,0 +1,84 @@
+"""bench.py's last stdout line must stay parseable by the driver (it keeps the last 8 KB of stdout): a compact JSON
+object with the contract fields, `roofline` and `cpu_baseline`, whatever the legs put into the full result."""
+import json
+import sys
+from pathlib import Path
+
+import pytest
+
+ROOT = Path(__file__).resolve().parent.parent
+sys.path.insert(0, str(ROOT))
+
+CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+            "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
+CANNED = sorted((ROOT / "profiles").glob("r0[34]_bench_*.json"))
+
+
+@pytest.fixture(scope="module")
+def bench():
+    import bench as module          # import only: no GPU call, the helper it runs sets one environment variable
+
+    return module
+
+
+@pytest.mark.parametrize("path", CANNED, ids=lambda p: p.stem)
+def test_result_line_is_compact_and_complete(bench, path):
+    full = json.loads(path.read_text().strip().splitlines()[-1])
+    if "metric" not in full:
+        pytest.skip("not a bench.py result")
+    text = bench.result_line(full)
+    assert "\n" not in text and len(text) < bench.LINE_LIMIT and len(text.encode()) < 8192
+    line = json.loads(text)
+    for key in CONTRACT:
+        assert key in line, key
+    assert line["value"] == pytest.approx(full["value"], rel=1e-5)
+    assert line["ms_per_step"] == pytest.approx(full["ms_per_step"], rel=1e-5)
+    assert "workload" in line["config"]
+    roof = line["roofline"]
+    for key in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "kernel_ms"):
+        assert key in roof, key
+    if full["roofline"].get("frac") is not None:
+        assert roof["frac"] == pytest.approx(full["roofline"]["frac"], rel=1e-4)
+        assert roof["achieved"] / roof["peak"] == pytest.approx(roof["frac"], rel=1e-3)
+    if full.get("cpu_baseline"):
+        for key in ("value", "unit", "cores", "kind", "sample"):
+            assert key in line["cpu_baseline"], key
+    if full.get("distributed"):
+        assert line["distributed"]["world_size"] == full["distributed"]["world_size"]
+
+
+def test_result_line_survives_oversized_legs(bench):
+    """legs that grow (or fail with long messages) cost summaries, never the contract fields"""
+    full = json.loads(CANNED[0].read_text().strip().splitlines()[-1]) if CANNED else None
+    if full is None or "metric" not in full:
+        full = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+                "config": {"workload": "w"}, "roofline": {"bound": "b", "kernel": "k", "achieved": 1.0, "peak": 2.0, "unit": "x", "frac": 0.5,
+                                                          "traffic": None, "kernel_ms": 1.0}, "cpu_baseline": None}
+    full = dict(full)
+    full["extra"] = {f"leg{k}": {"value": 1.0 * k, "roofline": {"frac": 0.5}, "blob": "x" * 5000} for k in range(400)}
+    full["config"] = dict(full["config"], workload="w" * 3000, verified="v" * 3000)
+    full["cpu_baseline"] = {"value": 1.0, "unit": "u", "cores": 1, "kind": "port", "sample": "s" * 9000}
+    text = bench.result_line(full)
+    assert len(text) < bench.LINE_LIMIT
+    line = json.loads(text)
+    for key in CONTRACT:
+        assert key in line, key
+
+
+def test_emit_writes_one_stdout_line_and_the_details_file(bench, tmp_path, monkeypatch):
+    import os
+
+    monkeypatch.setattr(bench, "EXTRAS_FILE", tmp_path / "bench_extras.json")
+    monkeypatch.setattr(bench, "ROOT", tmp_path)
+    full = {"metric": "m", "value": 2.5, "unit": "u", "n_gpus": 1, "steps": 1, "warmup": 0, "ms_per_step": 1.0,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": "w"}, "roofline": None, "cpu_baseline": None, "single_batch": {"value": 3.0, "note": "n" * 100}}
+    r, w = os.pipe()
+    bench.emit_result(full, w)
+    os.close(w)
+    got = os.read(r, 1 << 16).decode()
+    os.close(r)
+    assert got.endswith("\n") and got.count("\n") == 1
+    assert json.loads(got)["extra_summary"]["single_batch"] == {"value": 3.0}
+    assert json.loads((tmp_path / "bench_extras.json").read_text()) == full
