@@ -106,14 +106,7 @@ int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t 
 // units per group of a time-sliced launch of r workgroups per CU unless the caller says
 inline int n2_timeslice_segments(int resident) { return resident == 1 ? 8 : 2; }
 struct N2Choice { int lpl, wpg, resident; };      // resident: workgroups per CU of the time-sliced form, 0 = plain launch
-int device_cus() {
-  static const int cus = [] {
-    int dev = 0, n = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
-    return n;
-  }();
-  return cus;
-}
+inline int device_cus() { return mx_device_cus(); }      // of the CURRENT device (mx_upload.hpp)
 double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = nullptr) {
   if (resident) *resident = 0;
   N2Shape p;

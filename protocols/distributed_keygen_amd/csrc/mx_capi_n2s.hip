@@ -7,10 +7,9 @@ namespace mxs {
 template <int K, int L, bool TS, bool FR = (L == 3)>
 static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   size_t lds = mx::powmod_n2_split_lds_bytes<K, L>(FR);
-  if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS, FR>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    MX_HIP(attr);
+  if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance and device
+    static bool allowed[MX_MAX_DEVICES] = {};
+    MX_HIP(mx_allow_dynamic_lds(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS, FR>), (int)lds, allowed));
   }
   hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, L, LIMB_BITS, TS, FR>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());

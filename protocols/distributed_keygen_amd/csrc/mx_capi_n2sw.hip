@@ -7,10 +7,9 @@ namespace mxs {
 template <int K, bool TS>
 static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   size_t lds = mx::powmod_n2_split_lds_bytes<K, LIMBS_PER_LANE_WIDE>();
-  if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance
-    static const hipError_t attr = hipFuncSetAttribute(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS, TS>),
-                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    MX_HIP(attr);
+  if (lds > 64 * 1024) {     // above the default limit of dynamic LDS per workgroup: opt in once per instance and device
+    static bool allowed[MX_MAX_DEVICES] = {};
+    MX_HIP(mx_allow_dynamic_lds(reinterpret_cast<const void*>(&mx::powmod_n2_split_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS, TS>), (int)lds, allowed));
   }
   hipLaunchKernelGGL((mx::powmod_n2_split_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS, TS>), dim3((unsigned)nblocks), dim3(64 * 2 * mx::N2_SPLIT_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());

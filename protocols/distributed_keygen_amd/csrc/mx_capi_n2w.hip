@@ -22,3 +22,16 @@ int launch_n2_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_
   return MX_ERR_SIZE;
 }
 }  // namespace mxw
+
+#ifdef MX_PRIVATE_PAD_WORDS
+// developer build: faults the pad check of powmod_n2_kernel counted since the last call (and the first 32 of them,
+// 7 words each: tag, workgroup, lane, index, expected, found, first*2+last); resets the counter
+extern "C" int mx_debug_pad_faults(uint32_t* log_words, int max_entries) {
+  uint32_t n = 0, zero = 0;
+  if (hipMemcpyFromSymbol(&n, HIP_SYMBOL(mx::g_pad_faults), 4) != hipSuccess) return -5;
+  const int m = (int)(n < 32u ? n : 32u) < max_entries ? (int)(n < 32u ? n : 32u) : max_entries;
+  if (m > 0 && log_words && hipMemcpyFromSymbol(log_words, HIP_SYMBOL(mx::g_pad_fault_log), (size_t)m * sizeof(mx::PadFault)) != hipSuccess) return -5;
+  if (hipMemcpyToSymbol(HIP_SYMBOL(mx::g_pad_faults), &zero, 4) != hipSuccess) return -5;
+  return (int)(n > 0x7FFFFFFFu ? 0x7FFFFFFFu : n);
+}
+#endif

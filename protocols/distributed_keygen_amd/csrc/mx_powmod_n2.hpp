@@ -175,6 +175,20 @@ __device__ __forceinline__ u32 extract_field(const u32* words, int bitpos, int n
   return (u32)(v >> off) & (nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
 }
 
+#ifdef MX_PRIVATE_PAD_WORDS
+// Developer build only (tools/build_variant.py -DMX_PRIVATE_PAD_WORDS=n, tools/concurrency_census.py): every lane of the
+// one-wavefront pair kernel keeps a private array of n words in scratch memory, writes a pattern that names its
+// writer (launch tag, workgroup, lane, index) before the tape and checks it after the tape.  A word that changed while
+// the wavefront ran was overwritten by somebody else: the fault is counted and the first few are recorded, so that the
+// census can say whether wrong rows under concurrent launches are the runtime's scratch or the kernel's arithmetic.
+struct PadFault { u32 tag, block, lane, index, want, got, first_last; };
+static __device__ u32 g_pad_faults;
+static __device__ PadFault g_pad_fault_log[32];
+__device__ __forceinline__ u32 pad_word(u32 tag, u32 block, u32 lane, u32 i) {
+  return (tag << 24) ^ (block << 12) ^ (lane << 6) ^ (i & 63u) ^ ((i >> 6) * 0x9E3779B1u);
+}
+#endif
+
 template <int K, int L, int W>
 __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true>;
@@ -245,6 +259,13 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
     }
   }
 
+#ifdef MX_PRIVATE_PAD_WORDS
+  volatile u32 pad[MX_PRIVATE_PAD_WORDS];
+  const u32 pad_tag = (u32)((unsigned long long)A.out >> 12) & 0xFFu;       // distinguishes the launches in flight
+#pragma unroll 1
+  for (int i = 0; i < MX_PRIVATE_PAD_WORDS; ++i)
+    pad[(i + lane) % MX_PRIVATE_PAD_WORDS] = pad_word(pad_tag, blockIdx.x, lane, (u32)((i + lane) % MX_PRIVATE_PAD_WORDS));
+#endif
   // ---- the tape (this segment's part of it)
   u32 acc0[L], acc1[L];
   if (A.first) {
@@ -285,6 +306,17 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
       }
     }
   }
+#ifdef MX_PRIVATE_PAD_WORDS
+#pragma unroll 1
+  for (int i = 0; i < MX_PRIVATE_PAD_WORDS; ++i) {
+    const u32 idx = (u32)((i + lane) % MX_PRIVATE_PAD_WORDS);
+    const u32 want = pad_word(pad_tag, blockIdx.x, lane, idx), got = pad[idx];
+    if (got != want) {
+      const u32 k = atomicAdd(&g_pad_faults, 1u);
+      if (k < 32) g_pad_fault_log[k] = PadFault{pad_tag, blockIdx.x, (u32)lane, idx, want, got, (u32)(A.first * 2 + A.last)};
+    }
+  }
+#endif
   if (!A.last) {
 #pragma unroll
     for (int j = 0; j < L; ++j) { slot_at(N2_SLOT_CARRY, 0, j) = acc0[j]; slot_at(N2_SLOT_CARRY, 1, j) = acc1[j]; }

@@ -387,8 +387,12 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powm
     if constexpr (!PERSISTENT) {
       break;
     } else {
-      // end of the unit: A's stores are ordered before its token, B pushes the group's next segment for both
+      // end of the unit: B pushes the group's next segment for both wavefronts, and the pair that pops it may sit on
+      // another CU or XCD.  B's agent-scope release covers B's own stores only, and A's hand-over to B is a
+      // workgroup-scope LDS release that neither waits for A's global stores (carry slot, table slots) nor writes
+      // them back from this XCD's L2 — so A releases them at agent scope itself, before the token that lets B push.
       if (half == 0) {
+        if (!last) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
         send_token();
       } else {
         receive_token();

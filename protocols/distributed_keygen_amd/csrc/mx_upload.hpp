@@ -65,6 +65,35 @@ struct MxKernelTimer {
 };
 
 namespace {
+// ---- per-device state -----------------------------------------------------------------------------
+// A process may drive several GPUs (Engine(device_index=1)): what the runtime keeps per device is cached per
+// device here, keyed by hipGetDevice() at the time of the call.
+constexpr int MX_MAX_DEVICES = 64;
+inline int mx_current_device() {
+  int dev = 0;
+  return (hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < MX_MAX_DEVICES) ? dev : -1;
+}
+// Opt a kernel into more than 64 KB of dynamic LDS per workgroup, once per (instance, device): the attribute belongs
+// to the device's copy of the function.  `done` is a zero-initialised flag array of MX_MAX_DEVICES entries that the
+// calling template instance owns.
+inline hipError_t mx_allow_dynamic_lds(const void* kernel, int bytes, bool* done) {
+  const int dev = mx_current_device();
+  if (dev >= 0 && done[dev]) return hipSuccess;
+  const hipError_t err = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (err == hipSuccess && dev >= 0) done[dev] = true;
+  return err;
+}
+// Compute units of the current device
+inline int mx_device_cus() {
+  static int cus[MX_MAX_DEVICES] = {};
+  const int dev = mx_current_device();
+  if (dev >= 0 && cus[dev] > 0) return cus[dev];
+  int n = 0;
+  if (dev < 0 || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+  if (dev >= 0) cus[dev] = n;
+  return n;
+}
+
 // Sizing queries only know the row width; assume the widest modulus that fits it.
 inline int sizing_bits(int limbs) { return 32 * limbs < MAX_MOD_BITS ? 32 * limbs : MAX_MOD_BITS; }
 constexpr int MAX_SLIDING_OPS = 16384;   // covers exponents up to 16384 bits

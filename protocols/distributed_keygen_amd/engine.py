@@ -23,6 +23,37 @@ import numpy as np
 from . import _lib, limbs as _limbs
 
 
+def _int_args(fn):
+    """Coerce the integer operands of an entry point once: parameters annotated ``int`` become Python ints and the
+    per-group operand lists (``mods``, ``exps``, ``coeffs``, ``primes`` annotated ``Sequence[int]``) lists of Python
+    ints, so that int-like values — gmpy2.mpz when the reference's utils run on gmpy2, numpy integers — behave like the
+    ints the reference passes (its own leaf accepts them)."""
+    import functools
+    import inspect
+
+    params = inspect.signature(fn).parameters
+    names = list(params)
+    scalars = {k for k, q in params.items() if q.annotation == "int"}
+    lists = {k for k, q in params.items() if q.annotation == "Sequence[int]" and k in ("mods", "exps", "coeffs", "primes")}
+    if not scalars and not lists:
+        return fn
+
+    def conv(name, v):
+        if name in scalars:
+            return v if type(v) is int else int(v)
+        if name in lists and not (isinstance(v, list) and all(type(x) is int for x in v[:1])):
+            return [int(x) for x in v]
+        return v
+
+    @functools.wraps(fn)
+    def wrapper(*args, **kwargs):
+        args = tuple(conv(names[i], a) if i < len(names) else a for i, a in enumerate(args))
+        kwargs = {k: conv(k, v) for k, v in kwargs.items()}
+        return fn(*args, **kwargs)
+
+    return wrapper
+
+
 class _Plan:
     """A per-key plan: the ctypes descriptor, the device block it points to (kept alive here) and the
     event that marks the end of prepare's uploads on the stream they were enqueued on."""
@@ -285,6 +316,7 @@ class Engine:
         return self.to_device(_limbs.pack(mods, limbs)), bits
 
     # ------------------------------------------------------------------ modexp, tensor level
+    @_int_args
     def powmod_shared_t(self, bases_t, mod: int, exp: int, out_t=None):
         """out[e] = bases[e]^exp mod `mod`; bases_t: int32 [batch, limbs] on this device."""
         if exp < 0:
@@ -340,6 +372,7 @@ class Engine:
         return out_t
 
     # ------------------------------------------------------------------ per-key plans
+    @_int_args
     def nsquare_plan(self, n: int, exp: int) -> _Plan:
         """The plan of `x -> x^exp mod n^2` (constants and tape of mx_powmod_nsquare_prepare), cached:
         (n, exp) is a key's public modulus and the party's Lagrange-folded share (PSK:46, PSK:79-85)."""
@@ -372,6 +405,7 @@ class Engine:
             self._n2_plans.popitem(last=False)
         return plan
 
+    @_int_args
     def combine_plan(self, n: int, theta_inv: int, limbs2: int) -> _Plan:
         """The plan of the share recombination for a key (mx_combine_prepare), cached."""
         key = (n, theta_inv, limbs2)
@@ -403,6 +437,7 @@ class Engine:
             self._combine_plans.popitem(last=False)
         return plan
 
+    @_int_args
     def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None, segments: Optional[int] = None,
                          shape: Optional[Tuple[int, int]] = None):
         """out[e] = bases[e]^exp mod n^2 (rows of the width of n^2), computed through pairs modulo n
@@ -430,6 +465,7 @@ class Engine:
         _lib.check(rc, "mx_powmod_nsquare_run")
         return out_t
 
+    @_int_args
     def powmod_nsquare_batch(self, bases: Sequence[int], exp: int, n: int, keep_rows: bool = False):
         """[pow_mod(b, exp, n*n) for b in bases] through the N-adic pair kernel.  Sequences of
         PIPELINE_MIN elements or more are cut into chunks that run on several streams: the chunks
@@ -500,46 +536,66 @@ class Engine:
 
         torch = self.torch
         accepted: List[Any] = []
+
+        def spin_all(trial) -> float:
+            best = None
+            for _ in range(4):                           # the first launch on a fresh stream binds its queue; best of the rest
+                t0 = _t.perf_counter()
+                for st in trial:
+                    _lib.check(self.lib.mx_spin(spin_us, int(st.cuda_stream)), "mx_spin")
+                for st in trial:
+                    st.synchronize()
+                dt = _t.perf_counter() - t0
+                best = dt if best is None else min(best, dt)
+            return best
+
         with torch.cuda.device(self.device):
             torch.cuda.synchronize(self.device)
+            one = None                                   # what ONE spin costs here and now (launch + clock ramp included)
             for cand in streams:
-                trial = accepted + [cand]
-                best = None
-                for _ in range(2):                       # the first launch on a fresh stream binds its queue
-                    t0 = _t.perf_counter()
-                    for st in trial:
-                        _lib.check(self.lib.mx_spin(spin_us, int(st.cuda_stream)), "mx_spin")
-                    for st in trial:
-                        st.synchronize()
-                    dt = _t.perf_counter() - t0
-                    best = dt if best is None else min(best, dt)
-                if len(trial) == 1 or best < 1.6e-6 * spin_us:
+                if one is None:
+                    one = max(spin_all([cand]), 1e-6 * spin_us)
+                    accepted.append(cand)
+                    continue
+                # side by side: about one spin; sharing a queue with an accepted stream: two
+                if spin_all(accepted + [cand]) < 1.6 * one:
                     accepted.append(cand)
         return accepted
+
+    RECHECK_CAPPED_EVERY = 16       # a capped engine probes again every so many long batches (the cap may have been a hiccup)
 
     def _chunk_streams(self, wanted: int) -> List[Any]:
         """`wanted` streams for the chunks of a long int-level batch — or fewer, if the process does not have
         that many concurrently running queues (one warning, then larger chunks on the streams that do run
-        side by side)."""
+        side by side).  The verdict is a wall-clock measurement on a GPU that others may be using, so a capped
+        engine does not keep it forever: it measures again every RECHECK_CAPPED_EVERY requests."""
         torch = self.torch
+        if self._side_streams_capped:
+            self._capped_calls = getattr(self, "_capped_calls", 0) + 1
+            if self._capped_calls % self.RECHECK_CAPPED_EVERY == 0:
+                self._side_streams_capped = False
         if len(self._side_streams) < wanted and not self._side_streams_capped:
             with torch.cuda.device(self.device):
                 # high-priority streams are served by their own set of hardware queues: the chunks do not
                 # collide with (and serialise behind) the caller's other streams even when the process runs
                 # with few hardware queues (profiles/r02_hw_queue_collisions.txt)
-                cands = self._side_streams + [torch.cuda.Stream(device=self.device, priority=-1)
-                                              for _ in range(wanted - len(self._side_streams))]
+                pool = self.__dict__.setdefault("_side_stream_pool", list(self._side_streams))
+                while len(pool) < wanted:
+                    pool.append(torch.cuda.Stream(device=self.device, priority=-1))
+                cands = self._side_streams + [st for st in pool if st not in self._side_streams][: wanted - len(self._side_streams)]
             ok = self.stream_concurrency(cands)
             if len(ok) < len(cands):
                 import warnings
 
+                if not getattr(self, "_capped_warned", False):
+                    self._capped_warned = True
+                    warnings.warn(
+                        f"protocols.distributed_keygen_amd: only {len(ok)} of {len(cands)} HIP streams run concurrently in this "
+                        "process (the HIP runtime was initialised with few hardware queues; call "
+                        "protocols.distributed_keygen_amd.configure_hw_queues() before the first GPU call, or set "
+                        f"GPU_MAX_HW_QUEUES=16): long batches are cut into {max(1, len(ok))} chunks instead of {wanted}",
+                        RuntimeWarning, stacklevel=3)
                 self._side_streams_capped = True
-                warnings.warn(
-                    f"protocols.distributed_keygen_amd: only {len(ok)} of {len(cands)} HIP streams run concurrently in this "
-                    "process (the HIP runtime was initialised with few hardware queues; call "
-                    "protocols.distributed_keygen_amd.configure_hw_queues() before the first GPU call, or set "
-                    f"GPU_MAX_HW_QUEUES=16): long batches are cut into {max(1, len(ok))} chunks instead of {wanted}",
-                    RuntimeWarning, stacklevel=3)
             self._side_streams = ok
         return self._side_streams[: max(1, min(wanted, len(self._side_streams)))]
 
@@ -610,6 +666,7 @@ class Engine:
         return out
 
     # ------------------------------------------------------------------ modexp, int level
+    @_int_args
     def powmod_batch(self, bases: Sequence[int], exp: int, mod: int) -> List[int]:
         """[pow_mod(b, exp, mod) for b in bases] on the GPU (exp >= 0)."""
         if len(bases) == 0:
@@ -620,6 +677,7 @@ class Engine:
         out = self.powmod_shared_t(self.to_device(rows), mod, exp)
         return _limbs.unpack(self.to_host(out))
 
+    @_int_args
     def powmod_batch_multi(
         self, bases: Sequence[Sequence[int]], exps: Sequence[int], mods: Sequence[int]
     ) -> List[List[int]]:
@@ -646,6 +704,7 @@ class Engine:
 
 
     # ------------------------------------------------------------------ modular multiplication / inversion / encryption
+    @_int_args
     def mulmod_t(self, a_t, b_t, mod: int, out_t=None):
         """out[e] = a[e]*b[e] mod `mod`; int32 rows [batch, limbs]; out_t may alias an input."""
         batch, limbs = a_t.shape
@@ -663,6 +722,7 @@ class Engine:
         _lib.check(rc, "mx_mulmod_shared")
         return out_t
 
+    @_int_args
     def mulmod_batch(self, a: Sequence[int], b: Sequence[int], mod: int) -> List[int]:
         if len(a) != len(b):
             raise ValueError("operands must have the same length")
@@ -676,6 +736,7 @@ class Engine:
 
     DIRECT_MODINV_MAX = 4      # elements inverted directly (one wavefront each); longer batches use the product tree
 
+    @_int_args
     def modinv_direct_t(self, x_t, mod: int):
         """Row-wise modular inverse on the device, one wavefront per row (mx_modinv): for the few
         values that need it (the root of the product tree, theta of a key).  Raises ValueError (like
@@ -696,6 +757,7 @@ class Engine:
             raise ValueError("base is not invertible for the given modulus")
         return out_t
 
+    @_int_args
     def modinv_t(self, x_t, mod: int):
         """Row-wise modular inverse by Montgomery's trick as a product tree on the device: 3 modular
         multiplications per element in ~2 log2(batch) launches, and the root inverted on the device too
@@ -723,6 +785,7 @@ class Engine:
             inv = nxt
         return inv
 
+    @_int_args
     def modinv_batch(self, values: Sequence[int], mod: int) -> List[int]:
         """[mod_inv(v, mod) for v in values] (PSK:90 over a batch)."""
         if len(values) == 0:
@@ -732,6 +795,7 @@ class Engine:
         x_t = self.to_device(_limbs.pack_reduced(values, limbs, mod))
         return _limbs.unpack(self.to_host(self.modinv_t(x_t, mod)))
 
+    @_int_args
     def encrypt_batch(self, messages: Sequence[int], randomness: Sequence[int], n: int) -> List[int]:
         """Paillier encryption with g = n + 1:  c = (1 + m n) * r^n mod n^2 for every (m, r)."""
         if len(messages) != len(randomness):
@@ -745,6 +809,7 @@ class Engine:
         g_t = self.to_device(_limbs.pack([(1 + (m % n) * n) % n2 for m in messages], limbs))
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, g_t, n2, out_t=rn_t)))
 
+    @_int_args
     def randomize_batch(self, ciphertexts: Sequence[int], randomness: Sequence[int], n: int) -> List[int]:
         """Re-randomisation of Paillier ciphertexts, c * r^n mod n^2 for every (c, r) — what the
         un-vendored scheme's ``randomize`` does before a ciphertext is sent (README.md:165-171 of the
@@ -761,6 +826,7 @@ class Engine:
         return _limbs.unpack(self.to_host(self.mulmod_t(rn_t, c_t, n2, out_t=rn_t)))
 
     # ------------------------------------------------------------------ Shamir field of the key generation
+    @_int_args
     def shamir_fma_t(self, a_t, b_t, c_t, prime: int, out_t=None):
         """out[e] = (a[e]*b[e] + c[e]) mod prime — this party's share of every candidate modulus
         (`p * q` then `+= zero`, DK:1274-1277); int32 rows [batch, limbs]."""
@@ -780,6 +846,7 @@ class Engine:
         _lib.check(rc, "mx_fma_mod")
         return out_t
 
+    @_int_args
     def shamir_lincomb_t(self, x_t, coeffs: Sequence[int], prime: int, out_t=None):
         """out[e] = sum_t coeffs[t] * x[t][e] mod prime; x_t int32 [terms, batch, limbs].  With the
         Lagrange coefficients at 0 this is `candidate_n.reconstruct()` (DK:1284) for a whole round; the
@@ -801,6 +868,7 @@ class Engine:
         _lib.check(rc, "mx_lincomb_mod")
         return out_t
 
+    @_int_args
     def shamir_fma_batch(self, a: Sequence[int], b: Sequence[int], c: Sequence[int], prime: int) -> List[int]:
         if not (len(a) == len(b) == len(c)):
             raise ValueError("operands must have the same length")
@@ -810,6 +878,7 @@ class Engine:
         ts = [self.to_device(_limbs.pack_reduced(col, limbs, prime)) for col in (a, b, c)]
         return _limbs.unpack(self.to_host(self.shamir_fma_t(ts[0], ts[1], ts[2], prime)))
 
+    @_int_args
     def shamir_lincomb_batch(self, columns: Sequence[Sequence[int]], coeffs: Sequence[int], prime: int) -> List[int]:
         """[sum_t coeffs[t] * columns[t][e] mod prime for e]; one column per term."""
         if len(columns) == 0 or len(columns[0]) == 0:
@@ -820,6 +889,7 @@ class Engine:
         x = np.stack([_limbs.pack_reduced(col, limbs, prime) for col in columns])
         return _limbs.unpack(self.to_host(self.shamir_lincomb_t(self.to_device(x), coeffs, prime)))
 
+    @_int_args
     def shamir_reconstruct_sieve_batch(self, columns: Sequence[Sequence[int]], coeffs: Sequence[int], prime: int,
                                        primes: Sequence[int]) -> Tuple[List[bool], Dict[int, int]]:
         """The candidate moduli of a round and their small-prime verdicts in one device pass
@@ -873,6 +943,7 @@ class Engine:
         _lib.check(rc, "mx_jacobi_dev_range")
         return out_t
 
+    @_int_args
     def jacobi_batch(self, values: Sequence[Sequence[int]], mods: Sequence[int]) -> List[List[int]]:
         """[[jacobi_symbol(v, mods[g]) for v in values[g]] for g]; ragged groups are padded."""
         groups = len(mods)
@@ -934,6 +1005,7 @@ class Engine:
         v_t = self.powmod_multi_t(sel_t, mods_op, exps, keep)
         return v_t, cnt_t
 
+    @_int_args
     def biprime_v_batch(
         self, g_values: Sequence[Sequence[int]], exps: Sequence[int], mods: Sequence[int], keep: int
     ) -> List[List[int]]:
@@ -960,6 +1032,7 @@ class Engine:
         return [vals[g * keep : g * keep + int(counts[g])] for g in range(groups)]
 
     # ------------------------------------------------------------------ sieve
+    @_int_args
     def sieve_t(self, cands_t, primes: Sequence[int], out_t=None):
         """uint8 [batch]: 1 iff some prime divides candidate e (distributed_keygen.py:1197-1209)."""
         batch, limbs = cands_t.shape
@@ -975,6 +1048,7 @@ class Engine:
         _lib.check(rc, "mx_sieve")
         return out_t
 
+    @_int_args
     def sieve_batch(self, candidates: Sequence[int], primes: Sequence[int]) -> List[bool]:
         """[__small_prime_divisors_test(primes, n) for n in candidates]."""
         if len(candidates) == 0:
@@ -989,6 +1063,7 @@ class Engine:
         return [bool(x) for x in out.cpu().numpy()]
 
     # ------------------------------------------------------------------ share recombination
+    @_int_args
     def combine_t(self, partials_t, n: int, theta_inv: int, out_t=None, status_t=None, packed: bool = False):
         """partials_t int32 [n_partials, batch, limbs2] (players 1..degree+1 in order) ->
         (plaintext rows int32 [batch, limbs(N)], status uint8 [batch], 1 = not divisible by N).
@@ -1016,6 +1091,7 @@ class Engine:
         self._small(run)
         return out_t if packed else (out_t, status_t)
 
+    @_int_args
     def combine_batch(
         self, partials: Sequence[Sequence[int]], n: int, theta_inv: int
     ) -> Tuple[List[int], List[bool]]:
@@ -1033,6 +1109,7 @@ class Engine:
         ok = [not bool(x) for x in status_t.cpu().numpy()]
         return _limbs.unpack(self.to_host(out_t)), ok
 
+    @_int_args
     def combine_columns(self, columns: Sequence[Any], n: int, theta_inv: int) -> Tuple[List[int], List[bool]]:
         """Share recombination from one COLUMN per player (players 1..degree+1 in order): a column is the
         device rows kept by ``powmod_nsquare_batch(..., keep_rows=True)`` or a received list of partial
@@ -1087,6 +1164,7 @@ class Engine:
         self._small(run)
         return pass_t
 
+    @_int_args
     def biprime_verdict_batch(self, v: Sequence[Sequence[Sequence[int]]], mods: Sequence[int]) -> List[List[bool]]:
         """v[g][i][k]: share of party i+1 in test slot k of candidate g (all parties, equal slot counts).
         Returns per candidate the per-slot result of `v_1 == +-prod_{i>=2} v_i (mod N)` (DK:1147-1158)."""

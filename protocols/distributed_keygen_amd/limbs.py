@@ -5,6 +5,7 @@ Row e of a ``[batch, limbs]`` array is ``int.to_bytes(4*limbs, "little")`` of el
 
 from __future__ import annotations
 
+import operator
 from typing import Iterable, List, Sequence
 
 import numpy as np
@@ -35,6 +36,22 @@ def _codec():
         except ImportError:
             pass
     return _mxcodec
+
+
+def as_index(value):
+    """int(value) if `value` is an integer scalar (int, gmpy2.mpz, numpy integer ...: anything with __index__ that is
+    not a sequence), else None — how the functions below tell ONE modulus from a sequence of moduli."""
+    if isinstance(value, int):
+        return int(value)
+    if hasattr(value, "__len__") or hasattr(value, "__iter__"):
+        return None
+    try:
+        return int(operator.index(value))
+    except TypeError:
+        try:                                        # gmpy2.mpz before 2.1 has __int__ only
+            return int(value) if type(value).__name__ == "mpz" else None
+        except (TypeError, ValueError):
+            return None
 
 
 def pack_into(values: Sequence[int], limbs: int, out: np.ndarray, row_offset: int = 0) -> None:
@@ -75,7 +92,8 @@ def reduce_rows(rows: np.ndarray, moduli) -> np.ndarray:
     count, limbs = rows.shape
     if count == 0:
         return rows
-    mods = [int(moduli)] if isinstance(moduli, int) else [int(m) for m in moduli]
+    one = as_index(moduli)
+    mods = [one] if one is not None else [int(m) for m in moduli]
     group = count // len(mods)
     view = rows.reshape(len(mods), group, limbs)
     for g, m in enumerate(mods):
@@ -102,8 +120,9 @@ def pack_reduced(values: Sequence[int], limbs: int, moduli) -> np.ndarray:
     try:
         rows = pack(values, limbs)
     except ValueError:
-        if isinstance(moduli, int):
-            return pack([int(v) % moduli for v in values], limbs)
+        one = as_index(moduli)
+        if one is not None:
+            return pack([int(v) % one for v in values], limbs)
         mods = [int(m) for m in moduli]
         group = len(values) // len(mods)
         return pack([int(v) % mods[k // group] for k, v in enumerate(values)], limbs)

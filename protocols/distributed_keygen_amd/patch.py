@@ -112,8 +112,11 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
                         # Shamir prime all are).  The leaf the reference imported is total, so anything else
                         # (an even or tiny modulus: no call site of this package produces one) goes to the
                         # function that was bound here before the patch — the reference's own.
+                        # int-like arguments (gmpy2.mpz when the reference's utils run on gmpy2, numpy integers) are
+                        # coerced once here: the engine's packing takes Python ints.
+                        a = tuple(int(v) for v in a)
                         modulus = a[-1]
-                        if isinstance(modulus, int) and (modulus < 3 or modulus % 2 == 0):
+                        if modulus < 3 or modulus % 2 == 0:
                             return _orig(*a)
                         return _op(*a, engine=engine)
 

@@ -496,3 +496,54 @@ def test_divstep_jacobi_model_matches_sympy():
     for n in (3, 5, 7, 9, 2**64 - 1, 2**64 + 13):
         for x in (0, 1, 2, n - 1, n - 2, (n + 1) // 2):
             assert _posdivsteps_jacobi_model(x % n, n) == sympy.jacobi_symbol(x % n, n)
+
+
+class _IntLike:
+    """an integer scalar that is not an int (what gmpy2.mpz / numpy integers are to isinstance(x, int))"""
+
+    def __init__(self, v):
+        self.v = int(v)
+
+    def __index__(self):
+        return self.v
+
+    def __int__(self):
+        return self.v
+
+
+def test_int_like_moduli_are_one_modulus_not_a_sequence():
+    """reduce_rows / pack_reduced told one modulus from a list with isinstance(moduli, int), so a
+    numpy.int64 or gmpy2.mpz modulus was iterated (TypeError)."""
+    from protocols.distributed_keygen_amd import limbs as L
+
+    m = (1 << 61) - 1
+    vals = [5, m + 3, 2 * m + 1, (1 << 64) + 7]
+    want = L.pack([v % m for v in vals], 3)
+    for mod in (m, np.int64(m), np.uint64(m), _IntLike(m)):
+        assert (L.pack_reduced(vals, 3, mod) == want).all(), type(mod)
+        assert (L.reduce_rows(L.pack(vals, 3), mod) == want).all(), type(mod)
+        assert (L.pack_reduced(vals + [-1], 3, mod)[:4] == want).all(), type(mod)      # the per-element path (negative value)
+    # a sequence of int-like moduli, one per group of consecutive rows
+    mods = [np.int64(m), _IntLike(97)]
+    got = L.pack_reduced([m + 1, m + 2, 100, 200], 3, mods)
+    assert L.unpack(got) == [1, 2, 3, 6]
+
+
+def test_engine_entry_points_coerce_int_like_operands():
+    from protocols.distributed_keygen_amd import engine
+
+    seen = {}
+
+    @engine._int_args
+    def entry(self, bases: Sequence[int], exp: int, mods: Sequence[int], mod: int = 7, other=None):
+        seen.update(exp=exp, mods=mods, mod=mod, bases=bases, other=other)
+
+    entry(None, [_IntLike(3)], np.int64(5), [np.int64(9), _IntLike(11)], mod=_IntLike(13), other=np.int64(1))
+    assert type(seen["exp"]) is int and seen["exp"] == 5
+    assert seen["mods"] == [9, 11] and all(type(x) is int for x in seen["mods"])
+    assert type(seen["mod"]) is int and seen["mod"] == 13
+    assert isinstance(seen["other"], np.int64) and isinstance(seen["bases"][0], _IntLike)      # untouched
+    # every int-level entry point of the Engine is wrapped
+    for name in ("powmod_batch", "powmod_batch_multi", "powmod_nsquare_batch", "modinv_batch", "combine_batch", "sieve_batch",
+                 "jacobi_batch", "biprime_v_batch", "biprime_verdict_batch", "shamir_lincomb_batch", "encrypt_batch"):
+        assert hasattr(getattr(engine.Engine, name), "__wrapped__"), name
