@@ -153,7 +153,7 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
     int64_t rr = r;
     if (g_knob_n2_timeslice > 16) {               // developer: this many per CU
       if (r != 1) break;
-      rr = std::min<int64_t>(fit, g_knob_n2_timeslice - 16);
+      rr = std::min<int64_t>(std::min<int64_t>(fit, 2), g_knob_n2_timeslice - 16);     // the time-sliced instances are built for two workgroups per CU
     }
     const int64_t pairs = rr * cus * mx::N2_SPLIT_PAIRS;
     if (p.groups <= pairs && !forced) continue;

@@ -372,6 +372,13 @@ struct Mont {
     (limb_step<F, Is>(t, a, c, bb, dd, qr, blk, emit), ...);
   }
 
+  template <int F, int I0, int... Is>
+  __device__ __forceinline__ void block_steps_from(u64 (&t)[L], const u32 (&a)[L], const u32 (&c)[L], const u32 (&bb)[L],
+                                                   const u32 (&dd)[L], u32 (&qr)[L], int blk,
+                                                   u32* emit, std::integer_sequence<int, Is...>) const {
+    (limb_step<F, I0 + Is>(t, a, c, bb, dd, qr, blk, emit), ...);
+  }
+
   // ------------------------------------------------------------------ Montgomery product
   // r = (a*b [+ c*d] [+ init]) / R mod N   (lazy: r < 2N for operands < 4N, R >= 16 N); r may alias
   // any operand.  With F_PLAIN: r = high part of a*b [+ c*d] [+ init], low limbs in `emit`.
@@ -418,6 +425,7 @@ struct Mont {
     // before block blk is worked on.  The large-L instances hide the latency behind their own work and keep
     // the registers.
     constexpr bool PREFETCH = L <= 4;
+    constexpr bool HALVES = L >= 16 && (F & F_TWO) != 0;
     u32 nb[L], nd[L];
     if constexpr (PREFETCH) {
 #pragma unroll
@@ -448,6 +456,19 @@ struct Mont {
         for (int j = 0; j < L; ++j) { bb[j] = nb[j]; dd[j] = nd[j]; }
 #pragma unroll
         for (int j = 0; j < L; ++j) { nb[j] = lds[nx * L + j]; nd[j] = (F & F_TWO) ? lds[LDS_D + nx * L + j] : 0u; }
+      } else if constexpr (HALVES) {
+        // two product rows at 18 limbs per lane: the 2 L multiplier limbs of a block are fetched in two halves, each in
+        // front of the steps that use it — with all 36 in registers at once the pass did not fit its 256 registers
+        // (round 3: 28 spilled registers, 116 B of scratch per lane)
+        constexpr int H = L / 2;
+#pragma unroll
+        for (int j = 0; j < H; ++j) { bb[j] = lds[blk * L + j]; dd[j] = lds[LDS_D + blk * L + j]; }
+        block_steps_from<F, 0>(t, a, c, bb, dd, qr, blk, emit, std::make_integer_sequence<int, H>{});
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int j = H; j < L; ++j) { bb[j] = lds[blk * L + j]; dd[j] = lds[LDS_D + blk * L + j]; }
+        block_steps_from<F, H>(t, a, c, bb, dd, qr, blk, emit, std::make_integer_sequence<int, L - H>{});
+        return;
       } else {
 #pragma unroll
         for (int j = 0; j < L; ++j) bb[j] = lds[blk * L + j];

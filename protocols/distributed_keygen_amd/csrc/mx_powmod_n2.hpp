@@ -151,6 +151,11 @@ struct PairArithT {
     M.stage_multipliers(y0, y1);
     u32 t0[L], q[L];
     mul_pass1(t0, q, x0);
+    // Z0 is needed only after pass 2, and the compiler would sink pass 1's carry sweep behind pass 2's loop: the
+    // un-carried 64-bit columns of t0 (2 L registers) then stay live through the two-row loop — the 24 spilled
+    // registers of the 18-limb instances (round 3: 116 B of scratch).  Pinned here, Z0 crosses the loop as L words.
+#pragma unroll
+    for (int j = 0; j < L; ++j) asm volatile("" : "+v"(t0[j]));
     mul_pass2(z1, x0, x1, q);
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
@@ -200,10 +205,15 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
   constexpr int GPW = 64 / K;
   const int lane = threadIdx.x;
   const int gw = lane / K;
-  const i64 elem_raw = (i64)blockIdx.x * GPW + gw;
-  const bool valid = elem_raw < A.batch;
-  const i64 elem = valid ? elem_raw : A.batch - 1;
   u32* wide = smem + gw * GROUP_WORDS;            // same words as the Montgomery scratch M.lds
+  // the element of this group of lanes (surplus groups redo the last one and store nothing).  Prologue and epilogue
+  // each derive it from the lane index on their own — the epilogue from an opaque copy — so that nothing of it (the
+  // row pointer, the flag) has to stay in registers, or in scratch, while the tape runs.
+  auto element_of = [&](int ln, bool& valid_out) -> i64 {
+    const i64 raw = (i64)blockIdx.x * GPW + ln / K;
+    valid_out = raw < A.batch;
+    return valid_out ? raw : A.batch - 1;
+  };
 
   M_t M;
   M.init(smem + gw * GROUP_WORDS, A.nblk);
@@ -242,7 +252,8 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
       }
     }
     __syncthreads();
-    const u32* src = A.bases + elem * A.limbs2;
+    bool valid_in;
+    const u32* src = A.bases + element_of(lane, valid_in) * A.limbs2;
     for (int k = p; k < WIDE; k += K) wide[k] = (k < A.limbs2) ? src[k] : 0u;
     __syncthreads();
 #pragma unroll
@@ -354,9 +365,14 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
   for (int j = 0; j < L; ++j) wide[it + p * L + j] = hi[j];
   if (p == 0) { wide[it + S] = 0; wide[it + S + 1] = 0; wide[it + S + 2] = 0; wide[it + S + 3] = 0; }
   __syncthreads();
-  u32* dst = A.out + elem * A.limbs2;
+  // (the lane index again from the wavefront itself: a workgroup is one wavefront, and threadIdx.x would have to be
+  // kept from the first instruction of the kernel)
+  int lane_e = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  asm volatile("" : "+v"(lane_e));
+  bool valid;
+  u32* dst = A.out + element_of(lane_e, valid) * A.limbs2;
   const int nl = it + S;
-  for (int k = p; k < A.limbs2; k += K) {
+  for (int k = lane_e % K; k < A.limbs2; k += K) {
     const int bit = 32 * k;
     const int g = bit / W, off = bit - g * W;
     u32 o = 0;

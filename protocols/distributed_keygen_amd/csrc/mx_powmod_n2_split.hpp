@@ -61,8 +61,12 @@ constexpr size_t powmod_n2_split_lds_bytes(bool friendly = L == 3) {
 
 // Scheduling state of a time-sliced launch in device memory (zeroed by the host before the launch): the work queue
 // described at the unit loop below, 2 + groups x (segments - 1) words.
+// Register budget: three workgroups per CU (168 registers) for the plain 9- and 3-limb instances, two (256) for the
+// 18-limb ones and for every time-sliced instance — a time-sliced launch keeps at most two workgroups per CU resident
+// (mx_capi_n2.hip: n2_estimate), and inside 168 registers its unit loop spilled 59-75 registers to scratch (round 3
+// shipped that; tools/scratch_report.py).  No instance of this kernel has a private segment.
 template <int K, int L, int W, bool PERSISTENT, bool FRIENDLY = (L == 3)>
-__global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
+__global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 || PERSISTENT ? 2 : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true, false>;          // wavefront-level ordering of the group scratch
   constexpr int S = M_t::S;
   constexpr int GROUP_WORDS = M_t::LDS_WORDS;

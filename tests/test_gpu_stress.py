@@ -121,42 +121,45 @@ def test_nsquare_randomized_differential_over_launch_shapes(eng):
         eng.set_wavefronts_per_group(0)
 
 
-def test_nsquare_four_streams_at_once_every_launch_shape(eng):
-    """Four launches in flight on four streams, every launch shape (and the time-sliced form forced on): each stream's
-    rows bit for bit against CPython pow at key_length 2048 with a full-length exponent.  Single-stream parity says
-    nothing about what launches share while they overlap — an experimental kernel of round 3 passed every
-    single-stream test at full size and returned wrong rows here."""
-    import multiprocessing as mp
+def _worker(what: str, rows: int, streams: int = 4, timeout: int = 900) -> None:
+    """tests/four_stream_worker.py as a child process (it configures 16 HIP hardware queues before its first GPU call;
+    this pytest process runs with the runtime's default of 4)."""
+    import subprocess
+    import sys
+    from pathlib import Path
 
-    import torch
+    worker = Path(__file__).resolve().parent / "four_stream_worker.py"
+    r = subprocess.run([sys.executable, str(worker), what, str(rows), str(streams)], capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0 and f"ok {what} rows={rows} streams={streams}" in r.stdout, f"rc={r.returncode}\n{r.stdout[-800:]}\n{r.stderr[-3000:]}"
+    assert "queues_configured_in_time=True" in r.stdout
 
-    from protocols.distributed_keygen_amd import limbs as L, synthetic
 
-    key = synthetic.make_key(2048, 3, 1)
-    own = next(i for i in (1, 2, 3) if key.exponent(i) > 0)
-    exp, n, n2 = key.exponent(own), key.n, key.n_square
-    batch = 1200
-    cts = synthetic.random_ciphertexts(key, batch, seed=23)
-    with mp.Pool(16) as pool:           # the GPU boxes report 256 CPUs and grant 16
-        want = pool.starmap(pow, [(c, exp, n2) for c in cts], chunksize=8)
-    rows = eng.to_device(L.pack(cts, L.limbs_for(n2)))
-    streams = [torch.cuda.Stream() for _ in range(4)]
-    try:
-        for lpl, wpg, sliced in ((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (3, 2, 0)):
-            eng.set_limbs_per_lane(lpl)
-            eng.set_wavefronts_per_group(wpg)
-            eng.debug_knob("n2_timeslice", sliced)
-            for rep in range(2):
-                outs = []
-                for st in streams:
-                    with torch.cuda.stream(st):
-                        outs.append(eng.powmod_nsquare_t(rows, n, exp))
-                torch.cuda.synchronize()
-                for k, out in enumerate(outs):
-                    got = L.unpack(eng.to_host(out))
-                    bad = [i for i in range(batch) if got[i] != want[i]]
-                    assert not bad, (lpl, wpg, sliced, rep, k, len(bad), bad[:8])
-    finally:
-        eng.debug_knob("n2_timeslice", 0)
-        eng.set_limbs_per_lane(0)
-        eng.set_wavefronts_per_group(0)
+@pytest.mark.timeout(1200)
+def test_nsquare_four_streams_at_once_every_launch_shape():
+    """Four launches of 10 000 rows in flight on four streams (4 x 625 wavefronts of the 18-limb shape: the machine is
+    oversubscribed as in bench.py's steady state), every launch shape incl. the time-sliced form, 16 hardware queues:
+    every row of every stream bit for bit against CPython pow at key_length 2048 with a full-length exponent.
+    Single-stream parity says nothing about what launches share while they overlap — an experimental kernel of round 3
+    passed every single-stream test at full size and returned wrong rows here."""
+    _worker("nsquare", 10000)
+
+
+@pytest.mark.timeout(1200)
+def test_four_streams_at_once_key4096_shapes():
+    """The same at key_length 4096 for the shapes whose instances differ from key_length 2048's: groups of 16 lanes on
+    the friendly modulus, plain and time-sliced, and the wide kernels at K = 8."""
+    _worker("k4096", 2500)
+
+
+@pytest.mark.timeout(1200)
+def test_four_streams_at_once_biprime_v():
+    """biprime_v_t (Jacobi filter -> selection -> generic fixed-window modexps, both lane geometries) from four streams
+    at once: 4 x 600 candidates x 40 modexps at key_length 2048."""
+    _worker("biprime", 600)
+
+
+@pytest.mark.timeout(1200)
+def test_four_streams_at_once_jacobi_257_words():
+    """The 257-word Jacobi instance (key_length 8192: the one kernel of the library whose operands do not fit the
+    register file) from four streams at once."""
+    _worker("jacobi8192", 24)

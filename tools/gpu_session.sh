@@ -1,0 +1,69 @@
+#!/bin/bash
+# One GPU session = one gpurun call:   gpurun --timeout S -- 'bash tools/gpu_session.sh <tag> <step> [<step> ...]'
+# Every step writes under gpurun_out/<tag>/ (merged back into the build container); the summaries that are cited are
+# copied to profiles/ by hand.  Steps (tools/README.md has the table):
+#   census        wrong-row census of overlapping launches for the shipped library and the pad variants
+#                 (build/variants/pad*.so, tools/build_variant.py padN -DMX_PRIVATE_PAD_WORDS=N), over hardware queues,
+#                 segments, one stream vs four, and the runtime's scratch knobs
+#   exec_half     tools/ubench/exec_half: issue cost of VALU instructions with half of EXEC disabled
+#   tests         pytest -m gpu (whole suite, log + durations)
+#   stress        only the four-stream tests
+#   bench         bench.py with the driver's flags and with the defaults (+ bench_extras.json)
+#   biprime_small bench.py --workload biprime at the literal sizes of configs[1] and of an 8-GPU shard
+#   profile       tools/profile_round.sh <tag> (calibration, bench lines, rocprofv3 traces and counter passes)
+export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-$(pwd)}
+tag=$1; shift
+O=gpurun_out/$tag; mkdir -p $O
+V=protocols/distributed_keygen_amd/build/variants
+census() { python tools/concurrency_census.py "$@" >> $O/census.txt 2>> $O/census.err; }
+for step in "$@"; do
+  echo "== step $step $(date +%T)"
+  case $step in
+  census)
+    : > $O/census.txt
+    census --queues 16 --label shipped
+    census --queues 16 --label shipped-timesliced --shape 9,2 --timeslice 2
+    for v in pad64 pad256 pad1024; do
+      [ -f $V/$v.so ] || continue
+      MX_LIBRARY=$V/$v.so census --queues 16 --label $v
+      MX_LIBRARY=$V/$v.so census --queues 16 --label $v --segments 1
+      MX_LIBRARY=$V/$v.so census --queues 4 --label $v
+      MX_LIBRARY=$V/$v.so census --queues 16 --label $v --one-stream
+    done
+    for v in pad256 pad1024; do
+      [ -f $V/$v.so ] || continue
+      HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0 MX_LIBRARY=$V/$v.so census --queues 16 --label "$v HSA_ENABLE_SCRATCH_ASYNC_RECLAIM=0"
+      HSA_SCRATCH_SINGLE_LIMIT=4294967296 HSA_SCRATCH_SINGLE_LIMIT_ASYNC=4294967296 MX_LIBRARY=$V/$v.so census --queues 16 --label "$v HSA_SCRATCH_SINGLE_LIMIT=4G"
+      HSA_SCRATCH_SINGLE_LIMIT=1048576 HSA_SCRATCH_SINGLE_LIMIT_ASYNC=1048576 MX_LIBRARY=$V/$v.so census --queues 16 --label "$v HSA_SCRATCH_SINGLE_LIMIT=1M"
+      MX_LIBRARY=$V/$v.so census --queues 16 --streams 2 --label "$v two streams"
+      MX_LIBRARY=$V/$v.so census --queues 16 --rows 4096 --label "$v 4x4096 rows (1024 wavefronts in flight)"
+    done
+    grep -E "^==|WRONG|pad faults [a-z ]*[0-9]*: [1-9]" $O/census.txt | tail -60
+    ;;
+  exec_half)
+    tools/ubench/exec_half > $O/exec_half.txt 2>&1; tail -40 $O/exec_half.txt
+    ;;
+  tests)
+    ( time python -m pytest tests -m gpu -x -q --durations=15 ) > $O/pytest.log 2>&1; tail -25 $O/pytest.log
+    ;;
+  stress)
+    ( time python -m pytest tests/test_gpu_stress.py -m gpu -x -q -k "four_streams" --durations=8 ) > $O/pytest_stress.log 2>&1; tail -15 $O/pytest_stress.log
+    ;;
+  bench)
+    python bench.py --steps 20 --warmup 5 > $O/bench_driver_flags.json 2> $O/bench_driver_flags.err; cp bench_extras.json $O/bench_driver_flags_extras.json
+    tail -c 2500 $O/bench_driver_flags.json; wc -c $O/bench_driver_flags.json
+    ;;
+  biprime_small)
+    for spec in "1024 256" "2048 512" "2048 100" "2048 25"; do set -- $spec
+      python bench.py --workload biprime --key-length $1 --batch $2 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_biprime_k$1_c$2.json 2>/dev/null
+      python -c "import json,sys; d=json.loads(open('$O/bench_biprime_k$1_c$2.json').read().strip().splitlines()[-1]); print('biprime k$1 c$2', round(d['value']), 'modexps/s', round(d['ms_per_step'],2), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'))"
+    done
+    ;;
+  profile)
+    bash tools/profile_round.sh $tag
+    ;;
+  *) echo "unknown step $step";;
+  esac
+done
+echo "== done $(date +%T)"
