@@ -96,6 +96,8 @@ def parse() -> argparse.Namespace:
                          "-1 = slices when the launches in flight fit the chip side by side at one wavefront per SIMD")
     ap.add_argument("--segments", type=int, default=0,
                     help="c3/c5: launches per exponentiation (mx_powmod_nsquare_run), 0 = the library's choice")
+    ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
+                    help="developer override of the library for A/B runs (Engine.debug_knob), e.g. n2_friendly_1w=1")
     ap.add_argument("--generic-modulus", action="store_true",
                     help="c3/c5: time mx_powmod_shared on the modulus N^2 instead of the N-adic pair kernel")
     return ap.parse_args()
@@ -1162,6 +1164,9 @@ def main() -> None:
     from protocols.distributed_keygen_amd import Engine
 
     eng = Engine(local_rank)
+    for kv in args.knob:
+        name, _, value = kv.partition("=")
+        eng.debug_knob(name, int(value))
     extras = world == 1 and not args.no_extras and not args.generic_modulus
     if args.workload in ("c3", "c5"):
         key_length = args.key_length or (2048 if args.workload == "c3" else 4096)

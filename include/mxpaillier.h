@@ -282,10 +282,12 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
  * so that its fallback kernel has to finish the symbols (test knob for the safety net).  MX_KNOB_N2_TIMESLICE: the
  * time-sliced form of two-wavefront launches (resident workgroups that share the groups of elements segment by
  * segment): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
- * workgroups per CU (r = 1..3).  Process-wide; returns MX_OK / MX_ERR_ARG. */
+ * workgroups per CU (r = 1..2).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
+ * friendly-modulus instances (A/B runs against the plain ones).  Process-wide; returns MX_OK / MX_ERR_ARG. */
 #define MX_KNOB_N2_SEGMENTS 1
 #define MX_KNOB_JACOBI_MAX_BATCHES 2
 #define MX_KNOB_N2_TIMESLICE 3
+#define MX_KNOB_N2_FRIENDLY_1W 4
 int mx_debug_knob(int knob, int value);
 /* Enqueues a kernel of ONE wavefront that idles for `microseconds` (0..1 000 000) on `stream` and touches no
  * memory.  A concurrency probe: two streams that the HIP runtime has mapped to the same hardware queue run

@@ -18,6 +18,7 @@ thread_local hipError_t g_last_hip = hipSuccess;
 int g_limbs_per_lane = 0;
 int g_knob_n2_segments = 0;
 int g_knob_n2_timeslice = 0;
+int g_knob_n2_friendly_1w = 0;
 int g_knob_jacobi_max_batches = 0;
 }
 MxProfile g_mx_profile;
@@ -273,6 +274,7 @@ int mx_debug_knob(int knob, int value) {
     case MX_KNOB_N2_SEGMENTS: if (value > 64) return MX_ERR_ARG; g_knob_n2_segments = value; return MX_OK;
     case MX_KNOB_N2_TIMESLICE: if (value > 2 && (value < 17 || value > 19)) return MX_ERR_ARG; g_knob_n2_timeslice = value; return MX_OK;
     case MX_KNOB_JACOBI_MAX_BATCHES: g_knob_jacobi_max_batches = value; return MX_OK;
+    case MX_KNOB_N2_FRIENDLY_1W: if (value > 1) return MX_ERR_ARG; g_knob_n2_friendly_1w = value; return MX_OK;
   }
   return MX_ERR_ARG;
 }

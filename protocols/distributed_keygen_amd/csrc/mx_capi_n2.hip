@@ -437,11 +437,24 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
     return launch_n2(a, p, ch.wpg, s, wgs);
   }
   a.sched = nullptr; a.sched_groups = a.sched_segments = a.sched_n_sqr = 0;
+  // The friendly-modulus instances of the one-wavefront wide kernel (mx_capi_n2w.hip: groups of 4 and 8 lanes) run the
+  // tape up to, not including, its last product (N2_MULC, tape position n_sqr + 1); that product and the epilogue run as
+  // one more segment on the plain instance (mx_powmod_n2.hpp).
+  const bool fr_tape = ch.wpg == 1 && p.geo.L == LIMBS_PER_LANE_WIDE && (p.geo.K == 4 || p.geo.K == 8) && a.friendly &&
+                       g_knob_n2_friendly_1w != 1;
+  const int friendly = a.friendly;
   for (int sg = 0; sg < nseg; ++sg) {
+    const bool final_sg = sg == nseg - 1;
     a.first = sg == 0;
-    a.last = sg == nseg - 1;
+    a.last = final_sg && !fr_tape;
     a.pos_begin = (int)((int64_t)plan->n_sqr * sg / nseg);
-    a.pos_end = a.last ? 0x7FFFFFFF : (int)((int64_t)plan->n_sqr * (sg + 1) / nseg);
+    a.pos_end = final_sg ? (fr_tape ? plan->n_sqr + 1 : 0x7FFFFFFF) : (int)((int64_t)plan->n_sqr * (sg + 1) / nseg);
+    a.friendly = fr_tape ? 1 : (ch.wpg == 1 && p.geo.L == LIMBS_PER_LANE_WIDE ? 0 : friendly);
+    MX_TRY(launch_n2(a, p, ch.wpg, s));
+  }
+  if (fr_tape) {
+    a.first = 0; a.last = 1; a.friendly = 0;
+    a.pos_begin = plan->n_sqr + 1; a.pos_end = 0x7FFFFFFF;
     MX_TRY(launch_n2(a, p, ch.wpg, s));
   }
   return MX_OK;

@@ -3,12 +3,21 @@
 #include "mx_powmod_n2.hpp"
 
 namespace mxw {
-template <int K>
-static int launch(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
-  size_t lds = mx::powmod_n2_lds_bytes<K, LIMBS_PER_LANE_WIDE>();
-  hipLaunchKernelGGL((mx::powmod_n2_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+template <int K, bool FR>
+static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  size_t lds = mx::powmod_n2_lds_bytes<K, LIMBS_PER_LANE_WIDE>(FR);
+  hipLaunchKernelGGL((mx::powmod_n2_kernel<K, LIMBS_PER_LANE_WIDE, LIMB_BITS, FR>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
+}
+// friendly-modulus instances (mx_powmod_n2.hpp) for groups of 4 and 8 lanes — key_length 2048 and 4096, the launches
+// that fill the machine — where the host found LIMB_BITS + 6 bits of room in R (a.friendly)
+template <int K>
+static int launch(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
+  if constexpr (K == 4 || K == 8) {
+    if (a.friendly) return launch_form<K, true>(a, nblocks, s);
+  }
+  return launch_form<K, false>(a, nblocks, s);
 }
 
 int launch_n2_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {

@@ -200,6 +200,7 @@ inline std::vector<u32> pack_sliding_ops(const std::vector<SlidingOp>& ops) {
 extern int g_limbs_per_lane;
 extern int g_knob_n2_segments;        // MX_KNOB_N2_SEGMENTS: 0 = automatic
 extern int g_knob_n2_timeslice;       // MX_KNOB_N2_TIMESLICE: 0 = automatic, 1 = never, 2 = always (two-wavefront launches)
+extern int g_knob_n2_friendly_1w;     // MX_KNOB_N2_FRIENDLY_1W: 0 = friendly-modulus instances of the one-wavefront wide kernel where they exist, 1 = never
 extern int g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
 inline int override_limbs_per_lane() {
   if (g_limbs_per_lane == LIMBS_PER_LANE || g_limbs_per_lane == LIMBS_PER_LANE_WIDE) return g_limbs_per_lane;

@@ -47,7 +47,7 @@ constexpr int N2_SLOT_CARRY = N2_SLOT_HI;
 // the output limbs reuse), plus ONE copy of C' for all groups.  Small enough that the register
 // file, not LDS, bounds occupancy: 10 KB per wavefront for <4,18>, 5 KB for <8,9>.
 template <int K, int L>
-constexpr size_t powmod_n2_lds_bytes() { return ((size_t)(64 / K) * (2 * K * L + 8) + (size_t)K * L) * 4; }
+constexpr size_t powmod_n2_lds_bytes(bool friendly = false) { return ((size_t)(64 / K) * (2 * K * L + 8) + (size_t)(friendly ? 2 : 1) * K * L) * 4; }
 
 struct PowmodN2Args {
   const u32* bases;   // [batch][limbs2] device
@@ -108,8 +108,9 @@ struct PairArithT {
   // first digits of the operands, the second only reads Q.  One wavefront runs both in turn (mul / sqr
   // below); the split kernel gives each pass its own wavefront (mx_powmod_n2_split.hpp).
   //   multiplication, multipliers staged in LDS by M.stage_multipliers(y0, y1) (pass 1 reads y0 only)
+  template <bool FR = false>
   __device__ __forceinline__ void mul_pass1(u32 (&t0)[L], u32 (&q)[L], u32 (&x0)[L]) {
-    M.template mulx<M_t::F_RECORD_Q | M_t::F_STAGED>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
+    M.template mulx<M_t::F_RECORD_Q | M_t::F_STAGED | (FR ? FRF : 0)>(t0, x0, x0, x0, x0, x0, q, nullptr, M.nblk);
   }
   //   pass 1 on its own (stages y0 itself; the split kernel's first wavefront has no use for y1)
   template <bool FR = false>
@@ -145,27 +146,29 @@ struct PairArithT {
   }
 
   // (z0, z1) = (x0, x1) * (y0, y1); outputs may alias inputs
+  template <bool FR = false>
   __device__ __forceinline__ void mul(u32 (&z0)[L], u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L],
                                       const u32 (&y0)[L], const u32 (&y1)[L]) {
     // both multipliers go to LDS once: pass 1 reads y0, pass 2 reads y0 (row X1*Y0) and y1 (row X0*Y1)
     M.stage_multipliers(y0, y1);
     u32 t0[L], q[L];
-    mul_pass1(t0, q, x0);
+    mul_pass1<FR>(t0, q, x0);
     // Z0 is needed only after pass 2, and the compiler would sink pass 1's carry sweep behind pass 2's loop: the
     // un-carried 64-bit columns of t0 (2 L registers) then stay live through the two-row loop — the 24 spilled
     // registers of the 18-limb instances (round 3: 116 B of scratch).  Pinned here, Z0 crosses the loop as L words.
 #pragma unroll
     for (int j = 0; j < L; ++j) asm volatile("" : "+v"(t0[j]));
-    mul_pass2(z1, x0, x1, q);
+    mul_pass2<FR>(z1, x0, x1, q);
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
 
   // (z0, z1) = (x0, x1)^2
+  template <bool FR = false>
   __device__ __forceinline__ void sqr(u32 (&z0)[L], u32 (&z1)[L], u32 (&x0)[L], u32 (&x1)[L]) {
     u32 t0[L], q[L];
-    sqr_pass1(t0, q, x0);
-    sqr_pass2(z1, x0, x1, q);
+    sqr_pass1<FR>(t0, q, x0);
+    sqr_pass2<FR>(z1, x0, x1, q);
 #pragma unroll
     for (int j = 0; j < L; ++j) z0[j] = t0[j];
   }
@@ -194,7 +197,15 @@ __device__ __forceinline__ u32 pad_word(u32 tag, u32 block, u32 lane, u32 i) {
 }
 #endif
 
-template <int K, int L, int W>
+// FR: the passes of the tape reduce modulo the friendly multiple of N (see PairArithT above) — one multiply-class
+// instruction less per limb step.  Needs W + 6 bits of room in R beyond what N needs (the host checks: A.friendly) and
+// two more constant rows (N~ + 1 in registers INSTEAD of N, C2' in LDS).  The last product of an exponentiation
+// (N2_MULC: by (1, 0), plain passes) and the epilogue need N itself and digits below 2N: a friendly instance never runs
+// them — the host enqueues them as one more segment of the exponentiation on the plain instance of the same geometry
+// (the accumulator travels through the scratch slot as between any two segments; N2_MULC has a tape position of its
+// own for that), so that this kernel carries neither N nor the code of the plain passes (the 18-limb instances have no
+// register to spare: with both in one kernel they spilled 49-55 registers).
+template <int K, int L, int W, bool FR = false>
 __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true>;
   constexpr int S = M_t::S;
@@ -230,7 +241,19 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
     }
     __syncthreads();
   }
-  PairArith<K, L, W> P(M, cp_lds);
+  u32* cp2_lds = cp_lds + K * L;
+  if constexpr (FR) {
+    M.load(M.nf, A.consts + 8 * A.limbsn, A.limbsn + 1);          // N~ + 1
+    M.setup_friendly();
+    u32 v[L];
+    M.load(v, A.consts + 8 * A.limbsn + (A.limbsn + 1), A.limbsn + 1);      // C2'
+    if (gw == 0) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) cp2_lds[p * L + j] = v[j];
+    }
+    __syncthreads();
+  }
+  PairArith<K, L, W> P(M, cp_lds, FR ? cp2_lds : nullptr);
   const i64 nlanes = (i64)gridDim.x * 64;
   u32* slots = A.slots + ((i64)blockIdx.x * 64 + lane);
   auto slot_at = [&](int slot, int half, int j) -> u32& { return slots[(((i64)slot * 2 + half) * L + j) * nlanes]; };
@@ -291,10 +314,11 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
     const u32 word = A.tape[k];
     const u32 op = word >> 28;
     const int arg = (int)(word & 0x0FFFFFFFu);
+    if (op == N2_MULC) pos += 1;                       // the last product: a position (and possibly a segment) of its own
     if (op == N2_SQR) {
       const int lo = pos > A.pos_begin ? pos : A.pos_begin;
       const int hi = pos + arg < A.pos_end ? pos + arg : A.pos_end;
-      for (int s = lo; s < hi; ++s) P.sqr(acc0, acc1, acc0, acc1);
+      for (int s = lo; s < hi; ++s) P.template sqr<FR>(acc0, acc1, acc0, acc1);
       pos += arg;
       continue;
     }
@@ -307,7 +331,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
 #pragma unroll
       for (int j = 0; j < L; ++j) { f0[j] = slot_at(arg, 0, j); f1[j] = slot_at(arg, 1, j); }
       if (op == N2_MUL || op == N2_MULC) {
-        P.mul(acc0, acc1, acc0, acc1, f0, f1);
+        P.template mul<FR>(acc0, acc1, acc0, acc1, f0, f1);
       } else if (op == N2_ADD) {
         M.add(acc0, acc0, f0);
         M.add(acc1, acc1, f1);
@@ -328,7 +352,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
     }
   }
 #endif
-  if (!A.last) {
+  if (FR || !A.last) {
 #pragma unroll
     for (int j = 0; j < L; ++j) { slot_at(N2_SLOT_CARRY, 0, j) = acc0[j]; slot_at(N2_SLOT_CARRY, 1, j) = acc1[j]; }
     return;

@@ -263,6 +263,7 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 || PERSISTENT 
       const u32 word = A.tape[k];
       const u32 op = word >> 28;
       const int arg = (int)(word & 0x0FFFFFFFu);
+      if (op == N2_MULC) pos += 1;                       // the last product has a tape position of its own (mx_powmod_n2.hpp)
       if (op == N2_SQR) {
         const int lo = pos > pos_begin ? pos : pos_begin;
         const int hi = pos + arg < pos_end ? pos + arg : pos_end;

@@ -29,6 +29,7 @@ ap.add_argument("--reps", type=int, default=2)
 ap.add_argument("--label", default="")
 ap.add_argument("--cache", default="/tmp/census_want")
 ap.add_argument("--timeslice", type=int, default=0)
+ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE", help="Engine.debug_knob overrides, e.g. n2_friendly_1w=1")
 args = ap.parse_args()
 if args.queues:
     os.environ["GPU_MAX_HW_QUEUES"] = str(args.queues)
@@ -71,6 +72,8 @@ eng.set_limbs_per_lane(lpl)
 eng.set_wavefronts_per_group(wpg)
 if args.timeslice:
     eng.debug_knob("n2_timeslice", args.timeslice)
+for kv in args.knob:
+    eng.debug_knob(kv.partition("=")[0], int(kv.partition("=")[2]))
 seg = None if args.segments < 0 else args.segments
 c_t = eng.to_device(L.pack(cts, limbs2))
 want_t = eng.to_device(want_rows)

@@ -41,6 +41,29 @@ for step in "$@"; do
     done
     grep -E "^==|WRONG|pad faults [a-z ]*[0-9]*: [1-9]" $O/census.txt | tail -60
     ;;
+  census_fr)
+    # the friendly-modulus instances of the one-wavefront wide kernel (round 3's dropped variant, rebuilt): four streams,
+    # segments 4 / 1 / 7, against the plain instances (knob) — and the time-sliced launches' first overlapping round
+    : > $O/census.txt
+    census --queues 16 --label "friendly 1w"
+    census --queues 16 --label "friendly 1w" --segments 1
+    census --queues 16 --label "friendly 1w" --segments 7
+    census --queues 4 --label "friendly 1w"
+    census --queues 16 --label "plain 1w (knob)" --knob n2_friendly_1w=1
+    census --queues 16 --label "time-sliced" --shape 9,2 --timeslice 2 --reps 4
+    census --queues 16 --label "time-sliced, 2 streams" --shape 9,2 --timeslice 2 --reps 3 --streams 2
+    [ -f $V/r03.so ] && MX_LIBRARY=$V/r03.so census --queues 16 --label "round-3 library time-sliced" --shape 9,2 --timeslice 2 --reps 4
+    [ -f $V/r03.so ] && MX_LIBRARY=$V/r03.so census --queues 16 --label "round-3 library 18x1w"
+    grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
+    ;;
+  bench_ab)
+    for rep in 1 2; do
+      for kn in "" "--knob n2_friendly_1w=1"; do
+        python bench.py --no-extras --no-cpu-baseline --steps 20 --warmup 5 $kn 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c3 driver flags [$kn]', round(d['value']), 'modexps/s', round(d['ms_per_step'],3), 'ms/step kernel_ms', round(d['roofline']['kernel_ms'],2), 'clock', d['roofline'].get('shader_clock_mhz_measured'))"
+        python bench.py --workload c5 --batch 16384 --streams 2 --steps 4 --warmup 2 --no-extras --no-cpu-baseline $kn 2>/dev/null | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('c5 16384 x 2 in flight [$kn]', round(d['value']), 'modexps/s', round(d['ms_per_step'],2), 'ms/step')"
+      done
+    done | tee $O/bench_ab.txt
+    ;;
   exec_half)
     tools/ubench/exec_half > $O/exec_half.txt 2>&1; tail -40 $O/exec_half.txt
     ;;
