@@ -282,7 +282,7 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
  * so that its fallback kernel has to finish the symbols (test knob for the safety net).  MX_KNOB_N2_TIMESLICE: the
  * time-sliced form of two-wavefront launches (resident workgroups that share the groups of elements segment by
  * segment): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
- * workgroups per CU (r = 1..2).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
+ * workgroups per CU (r = 1..3).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
  * friendly-modulus instances (A/B runs against the plain ones).  Process-wide; returns MX_OK / MX_ERR_ARG. */
 #define MX_KNOB_N2_SEGMENTS 1
 #define MX_KNOB_JACOBI_MAX_BATCHES 2
@@ -342,6 +342,14 @@ int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_lane, int w
  * *units_per_group the segments each group is cut into when run is called with segments = 0. */
 int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                                  int* resident_per_cu, int* units_per_group);
+/* The kernel INSTANCE behind that launch, for tests that must see every instance: geometry and wavefronts per group as
+ * mx_nsquare_launch_shape reports them, *friendly = 1 if the tape runs modulo the friendly multiple of N (a different
+ * template instance: every 3-limb one, the 9-limb two-wavefront ones for groups of 8 / 16 lanes and the 18-limb
+ * one-wavefront ones for groups of 4 / 8 lanes where the modulus leaves the room), *timesliced = 1 for the time-sliced
+ * form.  A friendly one-wavefront launch also runs the plain instance of the same geometry (last product, epilogue). */
+int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
+                               int* lanes_per_element, int* limbs_per_lane_out, int* wavefronts_per_group_out,
+                               int* friendly, int* timesliced);
 int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* lanes_per_element,
                            int* limbs_per_lane_out, int* limb_bits, int* blocks);
 

@@ -246,7 +246,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 301; }
+int mx_version(void) { return 302; }
 
 const char* mx_error_string(int code) {
   switch (code) {

@@ -84,6 +84,17 @@ int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t 
   return MX_ERR_SIZE;
 }
 
+// Which instances run their tape modulo the friendly multiple of N (mx_powmod_n2.hpp): every 3-limb instance (its
+// geometry reserves the room), the 9-limb two-wavefront instances for groups of 8 and 16 lanes and the 18-limb
+// one-wavefront instances for groups of 4 and 8 lanes (key_length 2048 and 4096) where the modulus leaves LIMB_BITS + 6
+// bits of room in R.  One place decides; the launchers of the other translation units obey PowmodN2Args::friendly.
+inline bool n2_friendly_instance(const Geometry& g, int wpg, int n_bits) {
+  if (g.L == LIMBS_PER_LANE_LAT) return true;
+  if (n_bits + 4 + LIMB_BITS + 2 > g.W * g.L * g.nblk) return false;
+  if (wpg == 2) return g.L == LIMBS_PER_LANE && (g.K == 8 || g.K == 16);
+  return g.L == LIMBS_PER_LANE_WIDE && (g.K == 4 || g.K == 8) && g_knob_n2_friendly_1w != 1;
+}
+
 // Launch shape of the pair kernel when the caller leaves the choice (limbs per lane and/or wavefronts per
 // group) to the library: the candidate with the lowest estimated duration for ONE launch of this batch on an
 // otherwise idle GPU.  The estimate is a cycle count per pair operation for the wavefront that bounds the launch,
@@ -153,7 +164,7 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
     int64_t rr = r;
     if (g_knob_n2_timeslice > 16) {               // developer: this many per CU
       if (r != 1) break;
-      rr = std::min<int64_t>(std::min<int64_t>(fit, 2), g_knob_n2_timeslice - 16);     // the time-sliced instances are built for two workgroups per CU
+      rr = std::min<int64_t>(fit, g_knob_n2_timeslice - 16);
     }
     const int64_t pairs = rr * cus * mx::N2_SPLIT_PAIRS;
     if (p.groups <= pairs && !forced) continue;
@@ -270,6 +281,20 @@ extern "C" int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs
   if (!shape_n2(n_bits, 1, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
   *resident_per_cu = ch.resident;
   *units_per_group = ch.resident ? n2_timeslice_segments(ch.resident) : 0;
+  return MX_OK;
+}
+
+extern "C" int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
+                                          int* k, int* l, int* wavefronts, int* friendly, int* timesliced) {
+  if (!k || !l || !wavefronts || !friendly || !timesliced || batch <= 0) return MX_ERR_ARG;
+  if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
+  const N2Choice ch = n2_auto_shape(n_bits, batch, limbs_per_lane, wavefronts_per_group);
+  N2Shape p;
+  if (!shape_n2(n_bits, 1, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
+  *k = p.geo.K; *l = p.geo.L; *wavefronts = ch.wpg;
+  *friendly = n2_friendly_instance(p.geo, ch.wpg, n_bits) ? 1 : 0;
+  *timesliced = ch.resident > 0 ? 1 : 0;
   return MX_OK;
 }
 
@@ -411,9 +436,7 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   a.ntape = plan->ntape;
   a.slots = (u32*)d_ws;
   a.batch = batch; a.limbsn = plan->limbs_n; a.limbs2 = limbs2; a.nblk = p.geo.nblk; a.ksplit = bits - 1;
-  // the passes modulo the friendly multiple of N need LIMB_BITS + 2 more bits of room in R than the plain ones (the
-  // 3-limb geometries always have them, choose_geometry; the 9-limb two-wavefront kernels come in both forms)
-  a.friendly = bits + 4 + LIMB_BITS + 2 <= p.geo.W * p.geo.L * p.geo.nblk;
+  a.friendly = n2_friendly_instance(p.geo, ch.wpg, bits);
   hipStream_t s = (hipStream_t)stream;
   // segments: consecutive launches that each execute a stretch of the tape (mx_powmod_n2.hpp); positions
   // are counted in squarings, the accumulator travels through a scratch slot of the workspace
@@ -440,16 +463,13 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   // The friendly-modulus instances of the one-wavefront wide kernel (mx_capi_n2w.hip: groups of 4 and 8 lanes) run the
   // tape up to, not including, its last product (N2_MULC, tape position n_sqr + 1); that product and the epilogue run as
   // one more segment on the plain instance (mx_powmod_n2.hpp).
-  const bool fr_tape = ch.wpg == 1 && p.geo.L == LIMBS_PER_LANE_WIDE && (p.geo.K == 4 || p.geo.K == 8) && a.friendly &&
-                       g_knob_n2_friendly_1w != 1;
-  const int friendly = a.friendly;
+  const bool fr_tape = ch.wpg == 1 && a.friendly;
   for (int sg = 0; sg < nseg; ++sg) {
     const bool final_sg = sg == nseg - 1;
     a.first = sg == 0;
     a.last = final_sg && !fr_tape;
     a.pos_begin = (int)((int64_t)plan->n_sqr * sg / nseg);
     a.pos_end = final_sg ? (fr_tape ? plan->n_sqr + 1 : 0x7FFFFFFF) : (int)((int64_t)plan->n_sqr * (sg + 1) / nseg);
-    a.friendly = fr_tape ? 1 : (ch.wpg == 1 && p.geo.L == LIMBS_PER_LANE_WIDE ? 0 : friendly);
     MX_TRY(launch_n2(a, p, ch.wpg, s));
   }
   if (fr_tape) {

@@ -61,12 +61,17 @@ constexpr size_t powmod_n2_split_lds_bytes(bool friendly = L == 3) {
 
 // Scheduling state of a time-sliced launch in device memory (zeroed by the host before the launch): the work queue
 // described at the unit loop below, 2 + groups x (segments - 1) words.
-// Register budget: three workgroups per CU (168 registers) for the plain 9- and 3-limb instances, two (256) for the
-// 18-limb ones and for every time-sliced instance — a time-sliced launch keeps at most two workgroups per CU resident
-// (mx_capi_n2.hip: n2_estimate), and inside 168 registers its unit loop spilled 59-75 registers to scratch (round 3
-// shipped that; tools/scratch_report.py).  No instance of this kernel has a private segment.
+// Register budget: three workgroups per CU (168 registers) for the 9- and 3-limb instances, plain and time-sliced, two
+// (256) for the 18-limb ones.  No instance has a private segment (tools/scratch_report.py, tests/test_instances.py).
+// The time-sliced instances must NOT be given the whole register file: with 256 registers a launch of 2 x CUs resident
+// workgroups leaves no slot for anybody else, and four such launches started a few milliseconds apart took 4-38 SECONDS
+// for their first round (three of the four stalled until the scheduler's time slice came round; measured in round 4,
+// profiles/r04_timesliced_first_round.txt) — and were no faster than the plain launch (53 vs 47 ms for 10 000).
+#ifndef MX_TS_MIN_WAVES          // developer builds: tools/build_variant.py <name> -DMX_TS_MIN_WAVES=2 / -DMX_TS_NO_A_FENCE
+#define MX_TS_MIN_WAVES 3
+#endif
 template <int K, int L, int W, bool PERSISTENT, bool FRIENDLY = (L == 3)>
-__global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 || PERSISTENT ? 2 : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
+__global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTENT ? MX_TS_MIN_WAVES : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true, false>;          // wavefront-level ordering of the group scratch
   constexpr int S = M_t::S;
   constexpr int GROUP_WORDS = M_t::LDS_WORDS;
@@ -100,7 +105,7 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 || PERSISTENT 
   M.init(wide, A.nblk);
   M.load(M.n, A.consts, A.limbsn);
   M.setup_modulus();
-  const int p = M.p;
+  const int p0 = M.p;
   if constexpr (FR) {
     M.load(M.nf, A.consts + 8 * A.limbsn, A.limbsn + 1);          // N~ + 1
     M.setup_friendly();
@@ -110,13 +115,13 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 || PERSISTENT 
     M.load(v, A.consts + 7 * A.limbsn, A.limbsn);
     if (gw == 0 && pair == 0) {
 #pragma unroll
-      for (int j = 0; j < L; ++j) cp_lds[p * L + j] = v[j];
+      for (int j = 0; j < L; ++j) cp_lds[p0 * L + j] = v[j];
     }
     if constexpr (FR) {
       M.load(v, A.consts + 8 * A.limbsn + (A.limbsn + 1), A.limbsn + 1);      // C2'
       if (gw == 0 && pair == 0) {
 #pragma unroll
-        for (int j = 0; j < L; ++j) cp2_lds[p * L + j] = v[j];
+        for (int j = 0; j < L; ++j) cp2_lds[p0 * L + j] = v[j];
       }
     }
   }
@@ -165,6 +170,13 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 || PERSISTENT 
   u32* const q_tail = A.sched + 1;       // entries pushed so far (beyond the implicit ones)
   u32* const q_ring = A.sched + 2;       // entry i - groups for index i >= groups: unit + 1, 0 = not yet pushed
   for (;;) {
+    // Time-sliced form: everything the prologue and the epilogue of a unit derive from the lane position (bit offsets,
+    // masks and LDS addresses of the limb conversions: some fifty values) is invariant across units, and the compiler
+    // would hoist it out of this loop and keep it — in scratch memory, the register budget being what it is (round 3
+    // shipped these instances with 59-75 spilled registers).  An opaque lane position per unit keeps those values
+    // inside the unit, where they are computed, used and dropped.
+    if constexpr (PERSISTENT) asm volatile("" : "+v"(M.p));
+    const int p = M.p;
     i64 slot, nlanes;
     int first, last, pos_begin, pos_end;
     u32 g = 0, sg = 0;
@@ -397,7 +409,9 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 || PERSISTENT 
       // workgroup-scope LDS release that neither waits for A's global stores (carry slot, table slots) nor writes
       // them back from this XCD's L2 — so A releases them at agent scope itself, before the token that lets B push.
       if (half == 0) {
+#ifndef MX_TS_NO_A_FENCE
         if (!last) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+#endif
         send_token();
       } else {
         receive_token();

@@ -7,11 +7,15 @@ mx_powmod_multi_dev: per-group exponents, fixed window).  ``tests/test_instances
 library's own geometry queries over the whole supported range and fails if an instance it can
 return has no case below; ``tests/test_gpu_instances.py`` runs the cases bit-exactly against pow().
 
-Each case: (kind, modulus-root bits, limbs_per_lane argument, batch, exponent bits[, wavefronts per group]).
-kind "n2": modulus is N^2 for an N of that many bits; "shared" / "multi": modulus of that many bits.
+Each case: (kind, modulus-root bits, limbs_per_lane argument, batch, exponent bits[, wavefronts per group[, time-slice knob]]).
+kind "n2": modulus is N^2 for an N of exactly that many bits; "shared" / "multi": modulus of that many bits.
 The pair kernel exists in two forms — ``powmod_n2_kernel`` (one wavefront per group of elements) and
 ``powmod_n2_split_kernel`` (two: mx_powmod_n2_split.hpp) — selected by the sixth field (1 | 2; 0 = the
-library's choice for this batch).
+library's choice for this batch); both have friendly-modulus instances that the library takes when the modulus leaves
+the room (so the bit length of a case decides the instance), and the two-wavefront kernel has time-sliced instances
+(seventh field 2: forced through the developer knob, as the automatic choice only takes them for batches of several
+thousand).  An instance is the tuple ``mx_nsquare_launch_instance`` reports:
+("n2", K, L, wavefronts per group, friendly, time-sliced).
 """
 
 from __future__ import annotations
@@ -35,6 +39,13 @@ N2_CASES = [
     # two wavefronts per group, L = 9, K = 8 and 16 with a modulus that leaves NO room for the friendly-modulus passes
     # (the cases at 2051 and 4099 bits above run the friendly instances, these the plain ones of the same geometry)
     ("n2", 2075, 9, 19, 200, 2), ("n2", 4160, 9, 9, 96, 2),
+    # one wavefront per group, wide geometry, K = 4 and 8 with a modulus that leaves NO room for the friendly-modulus passes
+    # (the cases at 2051 / 3075 / 4099 bits above run the friendly instances of round 4 — whose last segment is the plain
+    # instance —, these the plain ones alone)
+    ("n2", 2075, 18, 20, 200, 1), ("n2", 4160, 18, 12, 96, 1),
+    # time-sliced instances of the two-wavefront kernel (L = 9, K = 1 .. 16; friendly and plain for K = 8 and 16)
+    ("n2", 200, 9, 300, 130, 2, 2), ("n2", 400, 9, 67, 130, 2, 2), ("n2", 900, 9, 70, 130, 2, 2),
+    ("n2", 2051, 9, 35, 200, 2, 2), ("n2", 2075, 9, 35, 200, 2, 2), ("n2", 4099, 9, 19, 96, 2, 2), ("n2", 4160, 9, 19, 96, 2, 2),
     # the library's choice: a handful of elements -> the latency geometry on two wavefronts
     ("n2", 2051, 0, 7, 64, 0),
 ]
@@ -64,20 +75,26 @@ def _geom(fn, *args):
     return (k.value, l.value) if rc == 0 else None
 
 
-def _shape(lib, bits, batch, lpl, wpg):
+def _instance(lib, bits, batch, lpl, wpg, ts_knob=0):
     import ctypes
 
-    k, l, w, b, wv = (ctypes.c_int() for _ in range(5))
-    rc = lib.mx_nsquare_launch_shape(bits, batch, lpl, wpg, k, l, w, b, wv)
-    return (k.value, l.value, wv.value) if rc == 0 else None
+    k, l, wv, fr, ts = (ctypes.c_int() for _ in range(5))
+    if ts_knob:
+        assert lib.mx_debug_knob(3, ts_knob) == 0
+    try:
+        rc = lib.mx_nsquare_launch_instance(bits, batch, lpl, wpg, k, l, wv, fr, ts)
+    finally:
+        if ts_knob:
+            lib.mx_debug_knob(3, 0)
+    return (k.value, l.value, wv.value, fr.value, ts.value) if rc == 0 else None
 
 
 def case_instance(lib, case):
-    """The template instance a case runs: ("n2", K, L, wavefronts per group) or
+    """The template instance a case runs: ("n2", K, L, wavefronts per group, friendly, time-sliced) or
     ("generic-sliding" | "generic-fixed", K, L)."""
     kind, bits, lpl, batch = case[:4]
     if kind == "n2":
-        g = _shape(lib, bits, batch, lpl, case[5])
+        g = _instance(lib, bits, batch, lpl, case[5], case[6] if len(case) > 6 else 0)
         return None if g is None else ("n2",) + g
     groups = 1 if kind == "shared" else 3
     g = _geom(lib.mx_powmod_geometry_for, bits, batch * groups, groups, lpl)
@@ -85,17 +102,22 @@ def case_instance(lib, case):
 
 
 def reachable_instances(lib):
-    """Every instance the launchers can return, probed through the library's geometry queries over the
-    supported modulus range, a spread of batch sizes and all limbs_per_lane / wavefronts_per_group arguments."""
+    """Every instance the launchers can return, probed through the library's own queries over the supported modulus
+    range, a spread of batch sizes (among them the sizes just above a capacity step, where the time-sliced form is
+    chosen) and all limbs_per_lane / wavefronts_per_group arguments."""
     out = set()
     bit_points = sorted(set(list(range(2, 600)) + list(range(600, 17000, 7)) + [16700, 16701, 8348, 8349, 4172, 4173]))
-    for batch in (1, 64, 5000, 20000, 200000, 2000000):
-        for bits in bit_points:
+    batches = (1, 64, 2304, 4608, 5000, 5120, 9216, 10000, 18432, 20000, 36864, 40000, 73728, 80000, 147456, 160000, 200000, 2000000)
+    for batch in batches:
+        coarse = batch not in (1, 64, 5000, 20000, 200000, 2000000)
+        for bits in (bit_points[::5] if coarse else bit_points):
             for lpl in (0, 3, 9, 18):
                 for wpg in (0, 1, 2):
-                    g = _shape(lib, bits, batch, lpl, wpg)
+                    g = _instance(lib, bits, batch, lpl, wpg)
                     if g is not None:
                         out.add(("n2",) + g)
+            if coarse:
+                continue
             for lpl in (0, 9, 18):
                 for groups, name in ((1, "generic-sliding"), (max(2, batch // 40), "generic-fixed")):
                     g = _geom(lib.mx_powmod_geometry_for, bits, max(batch, groups), groups, lpl)

@@ -30,7 +30,7 @@ def _modulus(rng, bits):
     return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
 
 
-@pytest.mark.parametrize("case", ic.ALL_CASES, ids=lambda c: f"{c[0]}-{c[1]}b-L{c[2]}-x{c[3]}" + (f"-w{c[5]}" if len(c) > 5 else ""))
+@pytest.mark.parametrize("case", ic.ALL_CASES, ids=lambda c: f"{c[0]}-{c[1]}b-L{c[2]}-x{c[3]}" + (f"-w{c[5]}" if len(c) > 5 else "") + ("-ts" if len(c) > 6 else ""))
 def test_instance_parity(eng, case):
     from protocols.distributed_keygen_amd import _lib
 
@@ -43,12 +43,18 @@ def test_instance_parity(eng, case):
     if kind == "n2":
         n = _modulus(rng, bits)
         n2 = n * n
-        shape = eng.nsquare_launch_shape(bits, batch)
-        assert (shape[0], shape[1], shape[4]) == inst[1:]
-        bases = [0, 1, n2 - 1, n, n + 1, n2 - n][: max(1, batch - 1)] + [rng.randrange(n2) for _ in range(batch)]
-        bases = bases[:batch]
-        for e in (rng.getrandbits(ebits) | (1 << (ebits - 1)) | 1, 2):
-            assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (case, e.bit_length())
+        ts_knob = case[6] if len(case) > 6 else 0
+        eng.debug_knob("n2_timeslice", ts_knob)
+        try:
+            shape = eng.nsquare_launch_shape(bits, batch)
+            assert (shape[0], shape[1], shape[4]) == inst[1:4]
+            assert bool(eng.nsquare_launch_timesliced(bits, batch)[0]) == bool(inst[5]) == bool(ts_knob)
+            bases = [0, 1, n2 - 1, n, n + 1, n2 - n][: max(1, batch - 1)] + [rng.randrange(n2) for _ in range(batch)]
+            bases = bases[:batch]
+            for e in (rng.getrandbits(ebits) | (1 << (ebits - 1)) | 1, 2):
+                assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (case, e.bit_length())
+        finally:
+            eng.debug_knob("n2_timeslice", 0)
     elif kind == "shared":
         mod = _modulus(rng, bits)
         assert eng.geometry(bits, batch, 1)[:2] == inst[1:]
@@ -115,20 +121,23 @@ def test_golden_key4096_partial_decryptions_every_launch_shape(eng, golden_decry
     eng.set_wavefronts_per_group(0)
 
 
-def test_c5_sweep_point_batch4096_auto_geometry(eng):
-    """configs[4] at a batch size of its sweep: 4096 ciphertexts at key_length 4096 through the
-    product path with the library's own choice of launch shape — the wide <8,18> instance on two wavefronts per group —
-    96 samples bit-exact against pow() on the host cores, and the full threshold decryption
-    round trip decrypt(encrypt(m)) == m on all 4096."""
+@pytest.mark.parametrize("batch,shape", [(1024, (64, 3, 2)), (4096, (8, 18, 2)), (16384, (8, 18, 1))])
+def test_c5_sweep_points_auto_geometry(eng, batch, shape):
+    """configs[4] at the three batch sizes of its sweep (1024 / 4096 / 16 384 ciphertexts at key_length 4096) through the
+    product path with the library's own choice of launch shape — a different instance at every size: the latency
+    geometry on two wavefronts, the wide <8,18> instance on two wavefronts, the wide one-wavefront instance (on the
+    friendly modulus) —: 64-96 samples bit-exact against pow() on the host cores, and the full threshold decryption round
+    trip decrypt(encrypt(m)) == m on every ciphertext."""
     from protocols.distributed_keygen_amd import synthetic
 
     key = synthetic.make_key(4096, 3, 1)
     n, n2 = key.n, key.n_square
-    batch = 4096
     eng.set_limbs_per_lane(0)
     eng.set_wavefronts_per_group(0)
-    assert eng.nsquare_launch_shape(n.bit_length(), batch)[:2] + eng.nsquare_launch_shape(n.bit_length(), batch)[4:] == (8, 18, 2)
-    rng = random.Random(40960)
+    got_shape = eng.nsquare_launch_shape(n.bit_length(), batch)
+    assert got_shape[:2] + got_shape[4:] == shape
+    assert eng.nsquare_launch_timesliced(n.bit_length(), batch) == (0, 0)
+    rng = random.Random(40960 + batch)
     msgs = [rng.randrange(n) for _ in range(batch)]
     msgs[:3] = [0, 1, n - 1]
     rs = [rng.randrange(1, n) for _ in range(batch)]
@@ -142,15 +151,22 @@ def test_c5_sweep_point_batch4096_auto_geometry(eng):
     got, ok = eng.combine_batch([[partials[i][k] for i in range(key.degree + 1)] for k in range(batch)], n, key.theta_inv)
     assert all(ok) and got == msgs
     i_pos = next(i for i in (1, 2, 3) if key.exponent(i) >= 0)
-    idx = [0, 1, 2, batch - 1] + [(k * 7919) % batch for k in range(1, 93)]
-    with mp.Pool() as pool:
+    idx = [0, 1, 2, batch - 1] + [(k * 7919) % batch for k in range(1, 93 if batch == 4096 else 61)]
+    with mp.Pool(16) as pool:
         want = pool.starmap(pow, [(cts[k], key.exponent(i_pos), n2) for k in idx], chunksize=1)
     assert [partials[i_pos - 1][k] for k in idx] == want
-    # the one-wavefront narrow and wide instances on the same inputs agree on every ciphertext
-    for lpl, want in ((9, (16, 9)), (18, (8, 18))):
-        eng.set_limbs_per_lane(lpl)
-        eng.set_wavefronts_per_group(1)
-        assert eng.nsquare_geometry(n.bit_length(), batch)[:2] == want
-        assert eng.powmod_nsquare_batch(cts, key.exponent(i_pos), n) == partials[i_pos - 1]
+    if batch == 4096:
+        # the one-wavefront narrow and wide instances on the same inputs agree on every ciphertext
+        for lpl, want_geo in ((9, (16, 9)), (18, (8, 18))):
+            eng.set_limbs_per_lane(lpl)
+            eng.set_wavefronts_per_group(1)
+            assert eng.nsquare_geometry(n.bit_length(), batch)[:2] == want_geo
+            assert eng.powmod_nsquare_batch(cts, key.exponent(i_pos), n) == partials[i_pos - 1]
+        # and the plain one-wavefront wide instance (friendly-modulus passes switched off) agrees with the friendly one
+        eng.debug_knob("n2_friendly_1w", 1)
+        try:
+            assert eng.powmod_nsquare_batch(cts, key.exponent(i_pos), n) == partials[i_pos - 1]
+        finally:
+            eng.debug_knob("n2_friendly_1w", 0)
     eng.set_limbs_per_lane(0)
     eng.set_wavefronts_per_group(0)

@@ -29,8 +29,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     assert declared == set(_lib.SYMBOLS), declared ^ set(_lib.SYMBOLS)
     for name in declared:
         assert hasattr(lib, name)
-    # ABI 3.0: mx_powmod_nsquare_run gained wavefronts_per_group, mx_nsquare_plan.geometries; 3.1: mx_nsquare_launch_timesliced
-    assert lib.mx_version() == 301
+    # ABI 3.0: mx_powmod_nsquare_run gained wavefronts_per_group, mx_nsquare_plan.geometries; 3.1: mx_nsquare_launch_timesliced;
+    # 3.2: mx_nsquare_launch_instance, MX_KNOB_N2_FRIENDLY_1W
+    assert lib.mx_version() == 302
     assert lib.mx_error_string(-3).decode().startswith("modulus")
 
 

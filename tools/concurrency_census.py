@@ -123,14 +123,25 @@ pad_faults("after the single launch")
 streams = [torch.cuda.Stream() for _ in range(args.streams)]
 total = 0
 for rep in range(args.reps):
-    outs = []
+    outs, evs = [], []
+    base = torch.cuda.Event(enable_timing=True)
+    base.record()
     t0 = time.perf_counter()
     for st in streams:
-        with torch.cuda.stream(streams[0] if args.one_stream else st):
+        use = streams[0] if args.one_stream else st
+        use.wait_event(base)
+        with torch.cuda.stream(use):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
             outs.append(eng.powmod_nsquare_t(c_t, n, exp, segments=seg))
+            e1.record()
+            evs.append((e0, e1))
+    t_enq = time.perf_counter() - t0
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"  rep {rep}: {args.streams} launches {'on ONE stream' if args.one_stream else 'on ' + str(args.streams) + ' streams'} in {dt * 1e3:.1f} ms", flush=True)
+    spans = ", ".join(f"{base.elapsed_time(a):.1f}-{base.elapsed_time(b):.1f}" for a, b in evs)
+    print(f"  rep {rep}: {args.streams} launches {'on ONE stream' if args.one_stream else 'on ' + str(args.streams) + ' streams'} in {dt * 1e3:.1f} ms"
+          f" (enqueued in {t_enq * 1e3:.1f} ms; start-end of each launch, ms: {spans})", flush=True)
     for k, o in enumerate(outs):
         total += census(o, f"launch {k}")
     pad_faults(f"after rep {rep}")

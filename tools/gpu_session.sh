@@ -56,6 +56,26 @@ for step in "$@"; do
     [ -f $V/r03.so ] && MX_LIBRARY=$V/r03.so census --queues 16 --label "round-3 library 18x1w"
     grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
     ;;
+  ts_first)
+    # why the FIRST round of four overlapping time-sliced launches took seconds (r04a/r04b): per-launch start/end times for
+    # the shipped library and for builds with three workgroups per CU (round 3's register budget) / without wavefront A's
+    # agent-scope release
+    : > $O/census.txt
+    census --queues 16 --label "shipped time-sliced" --shape 9,2 --timeslice 2 --reps 3
+    for v in ts_regs3 ts_nofence; do
+      [ -f $V/$v.so ] && MX_LIBRARY=$V/$v.so census --queues 16 --label "$v time-sliced" --shape 9,2 --timeslice 2 --reps 3
+    done
+    census --queues 16 --label "shipped time-sliced 3 streams" --shape 9,2 --timeslice 2 --reps 2 --streams 3
+    census --queues 16 --label "shipped time-sliced 8192 rows" --shape 9,2 --timeslice 2 --reps 2 --rows 8192
+    census --queues 16 --label "shipped time-sliced, second process" --shape 9,2 --timeslice 2 --reps 2
+    grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
+    ;;
+  counters_avail)
+    ( cd /tmp && rocprofv3 --list-avail 2>&1 ) > $O/counters_avail.txt; grep -c . $O/counters_avail.txt; grep -oE "\bSQ_[A-Z0-9_]+" $O/counters_avail.txt | sort -u | tr '\n' ' ' | head -c 6000; echo
+    ;;
+  instances)
+    ( time python -m pytest tests/test_gpu_instances.py -m gpu -x -q --durations=5 ) > $O/pytest_instances.log 2>&1; tail -12 $O/pytest_instances.log
+    ;;
   bench_ab)
     for rep in 1 2; do
       for kn in "" "--knob n2_friendly_1w=1"; do
