@@ -864,10 +864,10 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
 # ---------------------------------------------------------------------------------------------------
 def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 5, t: int = 2,
                      batch_sizes=(1024, 16384, 65536)) -> dict:
-    """What patch.compute_modulus does per round, timed from Python ints to Python verdicts for `batch_size`
-    candidates: every party's Shamir shares of the candidate moduli -> reconstruct + sieve (one device pass,
-    shamir.reconstruct_and_sieve_batch) -> survivors' v values (biprime_test_v_calculation_batch: Jacobi filter,
-    selection, 40 modexps each) -> verdicts (biprime_test_with_v_i_batch).  The exchange rounds in between (shares,
+    """What patch.compute_modulus does per round (biprime.BiprimeRound), timed from Python ints to Python verdicts for
+    `batch_size` candidates: every party's Shamir shares of the candidate moduli -> reconstruct + sieve (one device
+    pass; the survivors' moduli stay on the device) -> survivors' v values (Jacobi filter, selection, 40 modexps each;
+    this party's rows stay on the device) -> verdicts (the peers' columns packed with one codec call per party).  The exchange rounds in between (shares,
     jointly random generators, the other parties' v values) are network traffic in the reference and are prepared
     untimed.  Beside it: the same four steps as the reference computes them (oracle/cpu_keygen_round.py, one core —
     the reference runs a round sequentially on its asyncio thread), timed on a sample and scaled to the round."""
@@ -903,7 +903,9 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
         for rep in range(2):                                                 # the first pass warms allocations
             torch.cuda.synchronize()
             t0 = time.perf_counter()
-            has_div, surviving = shamir.reconstruct_and_sieve_batch(by_party, prime, degree, prime_list, eng, points=points)
+            rnd = biprime.BiprimeRound(eng)                                      # what patch.compute_modulus runs per round
+            surviving = rnd.reconstruct_and_sieve(by_party, prime, degree, prime_list, points=points)
+            has_div = rnd.has_divisor
             t1 = time.perf_counter()
             surv = sorted(surviving)
             moduli = [surviving[k] for k in surv]
@@ -911,8 +913,7 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
             g_rng = random.Random(B)
             g_values = [[g_rng.getrandbits(key_length + 64) % m for _ in range(160)] for m in moduli]      # untimed: a communication round
             t2 = time.perf_counter()
-            v1 = biprime.biprime_test_v_calculation_batch(g_values, 1, moduli, [shares[k][0][0] for k in surv],
-                                                          [shares[k][1][0] for k in surv], 40, eng)
+            v1 = rnd.v_calculation(g_values, 1, [shares[k][0][0] for k in surv], [shares[k][1][0] for k in surv], 40)
             t3 = time.perf_counter()
             v_by = [{1: v} for v in v1]                                          # untimed: the other parties' v values arrive
             for i in range(2, n_parties + 1):
@@ -921,7 +922,7 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
                 for d, v in zip(v_by, vi):
                     d[i] = v
             t4 = time.perf_counter()
-            verdicts = biprime.biprime_test_with_v_i_batch(v_by, moduli, 40, eng, errors="return")
+            verdicts = rnd.verdicts(v_by, 40, errors="return")
             t5 = time.perf_counter()
             cur = {"reconstruct_sieve_s": t1 - t0, "v_calculation_s": t3 - t2, "verdict_s": t5 - t4}
             cur["total_s"] = sum(cur.values())

@@ -101,12 +101,30 @@ def biprime_test_v_calculation(
 
 
 # ------------------------------------------------------------------ DK:1110-1175
+def _party_column(v_by_party: Sequence[Dict[int, Sequence[int]]], party: int, nslots: int) -> List[int]:
+    """All candidates' first `nslots` values of one party as one flat list, short lists padded with zeros (a missing
+    slot is never consulted unless the test reaches it, and then it raises)."""
+    from itertools import chain
+
+    if all(len(vc[party]) == nslots for vc in v_by_party):
+        return list(chain.from_iterable(vc[party] for vc in v_by_party))
+    flat: List[int] = []
+    for vc in v_by_party:
+        vals = vc[party]
+        flat.extend(vals[:nslots])
+        if len(vals) < nslots:
+            flat.extend([0] * (nslots - len(vals)))
+    return flat
+
+
 def biprime_test_with_v_i_batch(
     v_by_party: Sequence[Dict[int, Sequence[int]]],
     moduli: Sequence[int],
     correct_param_biprime: int,
     engine: Any = None,
     errors: str = "raise",
+    mods_rows: Any = None,
+    own: Any = None,
 ) -> List[Any]:
     """Verdict per candidate; ``v_by_party[c][i]`` is the v list of party i for candidate c.
     With ``errors="return"`` a candidate whose test would raise gets the exception object in its
@@ -114,7 +132,8 @@ def biprime_test_with_v_i_batch(
 
     Reference semantics: slots are tested in order, False at the first failing slot
     (DK:1160-1164), True after correct_param_biprime passing slots (DK:1168-1172); reaching a
-    slot for which a party has no value raises KeyError (utils.py:368-377)."""
+    slot for which a party has no value raises KeyError (utils.py:368-377).
+    `mods_rows` / `own`: device-resident operands of the same round (BiprimeRound below)."""
     if len(v_by_party) != len(moduli):
         raise ValueError("one v dictionary per candidate modulus expected")
     if len(moduli) == 0:
@@ -131,9 +150,16 @@ def biprime_test_with_v_i_batch(
         if errors == "raise":
             raise KeyError(order[0])
         return [KeyError(order[0]) for _ in moduli]
-    # pad short candidates with zeros: their missing slots are never consulted unless reached
-    v = [[[int(x) for x in vc[i][:nslots]] + [0] * (nslots - min(nslots, len(vc[i]))) for i in order] for vc in v_by_party]
-    slot_pass = _engine(engine).biprime_verdict_batch(v, list(moduli))
+    eng = _engine(engine)
+    if hasattr(eng, "biprime_verdict_columns"):
+        # one flat column per party (candidate-major), packed with one codec call each; `own` = (party index, handle of
+        # that party's values still on the device): taken from there instead of being packed again
+        columns = [own[1] if own is not None and own[0] == i else _party_column(v_by_party, i, nslots) for i in order]
+        slot_pass = eng.biprime_verdict_columns(columns, list(moduli), nslots, mods_rows=mods_rows)
+    else:
+        # pad short candidates with zeros: their missing slots are never consulted unless reached
+        v = [[[int(x) for x in vc[i][:nslots]] + [0] * (nslots - min(nslots, len(vc[i]))) for i in order] for vc in v_by_party]
+        slot_pass = eng.biprime_verdict_batch(v, list(moduli))
     out: List[bool] = []
     for c, passes in enumerate(slot_pass):
         verdict: Any = None
@@ -158,3 +184,74 @@ def biprime_test_with_v_i(
     v_by_party: Dict[int, Sequence[int]], modulus: int, correct_param_biprime: int, engine: Any = None
 ) -> bool:
     return biprime_test_with_v_i_batch([v_by_party], [modulus], correct_param_biprime, engine)[0]
+
+
+# ------------------------------------------------------------------ one round of DK:1284-1360 with its state on the device
+class BiprimeRound:
+    """The compute steps of one key-generation round — reconstruction + sieve (DK:1284-1292), this party's v values
+    (DK:1313-1329), the verdicts (DK:1339-1360) — with what the later steps need of the earlier ones kept on the device:
+    the survivors' moduli (rows straight out of the reconstruction) and this party's v rows.  Between the steps lie the
+    reference's communication rounds (generator generation, exchange of the v values), which take and deliver Python
+    ints; every value that crosses them is returned / accepted as such, and a value is only taken from the device when
+    the caller's copy equals what was computed.  Engines without the device-resident forms (the CPU test double) run
+    the same steps through the list-level functions above."""
+
+    def __init__(self, engine: Any = None) -> None:
+        self.engine = _engine(engine)
+        self.has_divisor: List[bool] = []
+        self.survivors: List[int] = []        # candidate indices that passed the sieve, ascending
+        self.moduli: List[int] = []           # their moduli, same order
+        self._mods_rows: Any = None
+        self._own: Any = None                 # (party index, v lists as returned, device handle)
+
+    def reconstruct_and_sieve(self, shares_by_party: Dict[int, Sequence[int]], prime: int, degree: int,
+                              prime_list: Sequence[int], points: Any = None) -> Dict[int, int]:
+        """DK:1284 + DK:1288-1292 for the whole round; returns {candidate index: modulus} of the survivors."""
+        from . import shamir
+
+        eng = self.engine
+        pts = shamir._points(shares_by_party, degree, points)
+        count = len(shares_by_party[pts[0]])
+        if any(len(shares_by_party[i]) != count for i in pts):
+            raise ValueError("every party needs one share per candidate")
+        self._mods_rows = self._own = None
+        if count == 0:
+            self.has_divisor, self.survivors, self.moduli = [], [], []
+            return {}
+        coeffs = shamir.lagrange_coefficients_at_zero(pts, prime, eng)
+        columns = [shares_by_party[i] for i in pts]
+        try:
+            self.has_divisor, surviving, self._mods_rows = eng.shamir_reconstruct_sieve_batch(
+                columns, coeffs, prime, list(prime_list), keep_rows=True)
+        except TypeError:                     # an engine without the device-resident form
+            self.has_divisor, surviving = eng.shamir_reconstruct_sieve_batch(columns, coeffs, prime, list(prime_list))
+        self.survivors = sorted(surviving)
+        self.moduli = [surviving[k] for k in self.survivors]
+        return surviving
+
+    def v_calculation(self, g_values: Sequence[Sequence[int]], index: int, p_shares: Sequence[int], q_shares: Sequence[int],
+                      correct_param_biprime: int) -> List[List[int]]:
+        """DK:1313-1329 for the survivors (one g list, p share and q share per survivor, in order)."""
+        moduli = self.moduli
+        if not (len(g_values) == len(moduli) == len(p_shares) == len(q_shares)):
+            raise ValueError("one g list, p share and q share per surviving candidate expected")
+        if not moduli:
+            return []
+        eng = self.engine
+        if self._mods_rows is None or not hasattr(eng, "biprime_verdict_columns"):
+            return biprime_test_v_calculation_batch(g_values, index, moduli, p_shares, q_shares, correct_param_biprime, eng)
+        exps = [biprime_exponent(index, n, p, q) for n, p, q in zip(moduli, p_shares, q_shares)]
+        lists, rows = eng.biprime_v_batch(g_values, exps, moduli, correct_param_biprime, mods_rows=self._mods_rows, keep_rows=True)
+        self._own = (index, lists, rows)
+        return lists
+
+    def verdicts(self, v_by_party: Sequence[Dict[int, Sequence[int]]], correct_param_biprime: int, errors: str = "raise") -> List[Any]:
+        """DK:1339-1360 for the survivors: one verdict (or, with errors="return", exception object) per survivor."""
+        own = None
+        if self._own is not None and self._own[2] is not None and len(v_by_party) == len(self._own[1]):
+            index, lists, rows = self._own
+            # the device copy stands in for this party's column only if the exchanged values are the computed ones
+            if all(index in vc and (vc[index] is mine or list(vc[index]) == mine) for vc, mine in zip(v_by_party, lists)):
+                own = (index, rows)
+        return biprime_test_with_v_i_batch(v_by_party, self.moduli, correct_param_biprime, self.engine, errors=errors,
+                                           mods_rows=self._mods_rows if hasattr(self.engine, "biprime_verdict_columns") else None, own=own)

@@ -41,7 +41,7 @@ def build_codec(verbose: bool = False) -> Path:
     cc = shutil.which("gcc") or shutil.which("cc")
     if cc is None:
         raise RuntimeError("gcc not found")
-    cmd = [cc, "-O2", "-shared", "-fPIC", "-I" + sysconfig.get_paths()["include"], str(CODEC_SRC), "-o", str(CODEC)]
+    cmd = [cc, "-O2", "-shared", "-fPIC", "-pthread", "-I" + sysconfig.get_paths()["include"], str(CODEC_SRC), "-o", str(CODEC)]
     if verbose:
         print(" ".join(cmd))
     subprocess.run(cmd, check=True)

@@ -1,17 +1,242 @@
 /* Python int  <->  little-endian uint32 limb rows, in bulk (CPython extension, host side only).
  *
  * The C ABI's number format is `int.to_bytes(4*limbs, "little")` per element (include/mxpaillier.h).
- * Converting 10 000 ciphertexts of 4100 bits with a Python-level loop costs 12 ms in and 12 ms out —
- * a fifth of the GPU time of the whole batch; this module does the same conversion in one C loop per
- * batch (the reference's values are Python ints: PaillierCiphertext.get_value(), PSK:69; the results
- * go back as Python ints, PSK:92 / PSK:125).  No arithmetic happens here.
+ * The reference's values are Python ints (PaillierCiphertext.get_value(), PSK:69; the shares, generators and v values
+ * of a key-generation round, DK:1284-1360) and its results go back as Python ints (PSK:92 / PSK:125), so every
+ * int-level call of the engine converts whole batches: 10 000 ciphertexts of 4100 bits, or the 230 000 generators
+ * and 290 000 v values of a 65 536-candidate round — two thirds of such a round's time in round 3, when this module
+ * called _PyLong_AsByteArray per element.  No arithmetic happens here.
  *
  *   pack_into(values, limbs, buffer, row_offset) -> None   buffer: writable, C-contiguous, rows of 4*limbs bytes
  *   unpack(buffer, limbs) -> list[int]
+ *   set_threads(n) -> previous setting                     0 = automatic (usable cores, at most 16)
+ *
+ * Both directions read / write the digits of the int objects directly (CPython's 30-bit digits) and do the bit
+ * shuffling on several threads WITHOUT the interpreter lock: a Python int is immutable and the list the caller passed
+ * keeps every element alive for the duration of the call, so its digits can be read from any thread; new ints are
+ * allocated under the lock (sizes computed first, in parallel) and filled in parallel before anybody else can see them.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
+#include <pthread.h>
+#include <sched.h>
+#include <stdint.h>
 #include <string.h>
+#include <unistd.h>
+
+#if PYLONG_BITS_IN_DIGIT == 30 && PY_VERSION_HEX < 0x030C0000
+#define MX_DIRECT_DIGITS 1
+#else
+#define MX_DIRECT_DIGITS 0
+#endif
+
+static int g_threads = 0; /* 0 = automatic */
+
+static int usable_threads(Py_ssize_t n, Py_ssize_t per_thread_min) {
+  int t = g_threads;
+  if (t <= 0) {
+    cpu_set_t set;
+    t = (sched_getaffinity(0, sizeof(set), &set) == 0) ? CPU_COUNT(&set) : (int)sysconf(_SC_NPROCESSORS_ONLN);
+    if (t > 16) t = 16; /* the GPU boxes report 256 CPUs and grant 16 */
+  }
+  if (t < 1) t = 1;
+  if ((Py_ssize_t)t > n / per_thread_min) t = (int)(n / per_thread_min);
+  return t < 1 ? 1 : t;
+}
+
+#if MX_DIRECT_DIGITS
+/* ---------------------------------------------------------------------------------------------- pack */
+typedef struct { PyObject** items; uint32_t* dst; Py_ssize_t limbs, lo, hi; Py_ssize_t bad; int bad_kind; } PackJob;
+
+static void digits_to_words(const digit* d, Py_ssize_t nd, uint32_t* out, Py_ssize_t limbs) {
+  uint64_t acc = 0;
+  int bits = 0;
+  Py_ssize_t w = 0;
+  for (Py_ssize_t i = 0; i < nd; ++i) {
+    acc |= (uint64_t)d[i] << bits;
+    bits += 30;
+    if (bits >= 32) {
+      if (w < limbs) out[w] = (uint32_t)acc;
+      ++w;
+      acc >>= 32;
+      bits -= 32;
+    }
+  }
+  if (w < limbs) out[w++] = (uint32_t)acc;
+  for (; w < limbs; ++w) out[w] = 0;
+}
+
+/* Everything about an element happens here, on the worker's core (the object header and its digits share cache
+ * lines: touching them first on the calling thread would only move the misses there): type, sign, size, conversion.
+ * Only immutable fields of live objects are read; a failure is recorded (first one of the slice) and raised by the
+ * caller under the lock. */
+static void* pack_worker(void* arg) {
+  PackJob* j = (PackJob*)arg;
+  const Py_ssize_t room = 32 * j->limbs;
+  for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
+    PyObject* v = j->items[i];
+    if (!PyLong_Check(v)) { j->bad = i; j->bad_kind = 1; return NULL; }
+    const Py_ssize_t nd = Py_SIZE(v);
+    const digit* d = ((PyLongObject*)v)->ob_digit;
+    int fits = nd >= 0;
+    if (fits && nd > 0) {
+      Py_ssize_t bits = (nd - 1) * 30 + (32 - __builtin_clz((unsigned)d[nd - 1]));
+      fits = bits <= room;
+    }
+    if (!fits) { j->bad = i; j->bad_kind = 2; return NULL; }
+    digits_to_words(d, nd, j->dst + i * j->limbs, j->limbs);
+  }
+  return NULL;
+}
+
+static PyObject* pack_into(PyObject* self, PyObject* args) {
+  PyObject* seq;
+  Py_ssize_t limbs, row_offset;
+  Py_buffer out;
+  if (!PyArg_ParseTuple(args, "Onw*n", &seq, &limbs, &out, &row_offset)) return NULL;
+  PyObject* fast = PySequence_Fast(seq, "values must be a sequence of ints");
+  if (!fast) { PyBuffer_Release(&out); return NULL; }
+  const Py_ssize_t n = PySequence_Fast_GET_SIZE(fast);
+  const Py_ssize_t nbytes = 4 * limbs;
+  if (limbs <= 0 || row_offset < 0 || (row_offset + n) * nbytes > out.len) {
+    PyErr_SetString(PyExc_ValueError, "buffer too small for the rows");
+    goto fail;
+  }
+  {
+    uint32_t* dst = (uint32_t*)((unsigned char*)out.buf + row_offset * nbytes);
+    const int nt = usable_threads(n, 1024);
+    PackJob jobs[16];
+    pthread_t tid[16];
+    int started[16] = {0};
+    Py_BEGIN_ALLOW_THREADS
+    for (int t = 0; t < nt; ++t) {
+      jobs[t].items = PySequence_Fast_ITEMS(fast); jobs[t].dst = dst; jobs[t].limbs = limbs;
+      jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt; jobs[t].bad = -1; jobs[t].bad_kind = 0;
+      if (t > 0) started[t] = pthread_create(&tid[t], NULL, pack_worker, &jobs[t]) == 0;
+    }
+    pack_worker(&jobs[0]);
+    for (int t = 1; t < nt; ++t) {
+      if (started[t]) pthread_join(tid[t], NULL);
+      else pack_worker(&jobs[t]); /* thread creation failed: this thread does the slice */
+    }
+    Py_END_ALLOW_THREADS
+    for (int t = 0; t < nt; ++t) {
+      if (jobs[t].bad_kind == 1) { PyErr_SetString(PyExc_TypeError, "values must be ints"); goto fail; }
+      if (jobs[t].bad_kind == 2) {
+        PyErr_Format(PyExc_ValueError, "value does not fit in %zd uint32 limbs (or is negative)", limbs);
+        goto fail;
+      }
+    }
+  }
+  Py_DECREF(fast);
+  PyBuffer_Release(&out);
+  Py_RETURN_NONE;
+fail:
+  Py_DECREF(fast);
+  PyBuffer_Release(&out);
+  return NULL;
+}
+
+/* -------------------------------------------------------------------------------------------- unpack */
+typedef struct { const uint32_t* rows; Py_ssize_t limbs, lo, hi; Py_ssize_t* nd; PyObject** objs; int fill; } UnpackJob;
+
+static void* unpack_worker(void* arg) {
+  UnpackJob* j = (UnpackJob*)arg;
+  for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
+    const uint32_t* w = j->rows + i * j->limbs;
+    if (!j->fill) { /* pass 1: digits needed */
+      Py_ssize_t top = j->limbs;
+      while (top > 0 && w[top - 1] == 0) --top;
+      Py_ssize_t bits = 0;
+      if (top > 0) {
+        bits = 32 * (top - 1);
+        uint32_t x = w[top - 1];
+        while (x) { ++bits; x >>= 1; }
+      }
+      j->nd[i] = (bits + 29) / 30;
+    } else if (j->nd[i] > 0) { /* pass 2: words -> 30-bit digits of the freshly allocated int */
+      digit* d = ((PyLongObject*)j->objs[i])->ob_digit;
+      const Py_ssize_t nd = j->nd[i];
+      uint64_t acc = 0;
+      int bits = 0;
+      Py_ssize_t k = 0, wi = 0;
+      while (k < nd) {
+        if (bits < 30) {                       /* at most 29 + 32 bits in the accumulator */
+          if (wi < j->limbs) acc |= (uint64_t)w[wi++] << bits;
+          bits += 32;
+        }
+        d[k++] = (digit)(acc & 0x3FFFFFFFu);
+        acc >>= 30;
+        bits -= 30;
+      }
+    }
+  }
+  return NULL;
+}
+
+static void run_unpack(UnpackJob* proto, Py_ssize_t n, int nt) {
+  UnpackJob jobs[16];
+  pthread_t tid[16];
+  int started[16] = {0};
+  for (int t = 0; t < nt; ++t) {
+    jobs[t] = *proto;
+    jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt;
+    if (t > 0) started[t] = pthread_create(&tid[t], NULL, unpack_worker, &jobs[t]) == 0;
+  }
+  unpack_worker(&jobs[0]);
+  for (int t = 1; t < nt; ++t) {
+    if (started[t]) pthread_join(tid[t], NULL);
+    else unpack_worker(&jobs[t]);
+  }
+}
+
+static PyObject* unpack(PyObject* self, PyObject* args) {
+  Py_buffer in;
+  Py_ssize_t limbs;
+  if (!PyArg_ParseTuple(args, "y*n", &in, &limbs)) return NULL;
+  const Py_ssize_t nbytes = 4 * limbs;
+  if (limbs <= 0 || in.len % nbytes != 0) {
+    PyBuffer_Release(&in);
+    PyErr_SetString(PyExc_ValueError, "buffer is not a whole number of rows");
+    return NULL;
+  }
+  const Py_ssize_t n = in.len / nbytes;
+  PyObject* list = PyList_New(n);
+  Py_ssize_t* nd = (Py_ssize_t*)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(Py_ssize_t));
+  PyObject** objs = (PyObject**)PyMem_Calloc((size_t)(n ? n : 1), sizeof(PyObject*));
+  if (!list || !nd || !objs || ((uintptr_t)in.buf & 3)) {
+    if (list && nd && objs) PyErr_SetString(PyExc_ValueError, "rows must be 4-byte aligned");
+    else PyErr_NoMemory();
+    goto fail;
+  }
+  const int nt = usable_threads(n, 2048);
+  UnpackJob job = {(const uint32_t*)in.buf, limbs, 0, 0, nd, objs, 0};
+  Py_BEGIN_ALLOW_THREADS
+  run_unpack(&job, n, nt);
+  Py_END_ALLOW_THREADS
+  for (Py_ssize_t i = 0; i < n; ++i) {
+    objs[i] = nd[i] == 0 ? PyLong_FromLong(0) : (PyObject*)_PyLong_New(nd[i]);
+    if (!objs[i]) goto fail;
+  }
+  job.fill = 1;
+  Py_BEGIN_ALLOW_THREADS
+  run_unpack(&job, n, nt);
+  Py_END_ALLOW_THREADS
+  for (Py_ssize_t i = 0; i < n; ++i) PyList_SET_ITEM(list, i, objs[i]);
+  PyMem_Free(nd);
+  PyMem_Free(objs);
+  PyBuffer_Release(&in);
+  return list;
+fail:
+  if (objs) for (Py_ssize_t i = 0; i < n; ++i) Py_XDECREF(objs[i]);
+  PyMem_Free(nd);
+  PyMem_Free(objs);
+  Py_XDECREF(list);
+  PyBuffer_Release(&in);
+  return NULL;
+}
+
+#else /* ---- interpreters with another digit width or int layout: the per-element library routines */
 
 static PyObject* pack_into(PyObject* self, PyObject* args) {
   PyObject* seq;
@@ -34,7 +259,6 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
       PyErr_SetString(PyExc_TypeError, "values must be ints");
       goto fail;
     }
-    /* unsigned, little endian; fails (OverflowError) for negative values and values that do not fit */
     if (_PyLong_AsByteArray((PyLongObject*)v, dst, (size_t)nbytes, 1, 0) < 0) {
       PyErr_Clear();
       PyErr_Format(PyExc_ValueError, "value does not fit in %zd uint32 limbs (or is negative)", limbs);
@@ -72,12 +296,30 @@ static PyObject* unpack(PyObject* self, PyObject* args) {
   PyBuffer_Release(&in);
   return list;
 }
+#endif
+
+static PyObject* set_threads(PyObject* self, PyObject* args) {
+  int n;
+  if (!PyArg_ParseTuple(args, "i", &n)) return NULL;
+  if (n < 0 || n > 16) {
+    PyErr_SetString(PyExc_ValueError, "threads must be 0 (automatic) .. 16");
+    return NULL;
+  }
+  const int prev = g_threads;
+  g_threads = n;
+  return PyLong_FromLong(prev);
+}
 
 static PyMethodDef methods[] = {
     {"pack_into", pack_into, METH_VARARGS, "pack_into(values, limbs, buffer, row_offset): ints -> uint32 rows"},
     {"unpack", unpack, METH_VARARGS, "unpack(buffer, limbs) -> list of ints"},
+    {"set_threads", set_threads, METH_VARARGS, "set_threads(n) -> previous; 0 = automatic (usable cores, at most 16)"},
     {NULL, NULL, 0, NULL}};
 
 static struct PyModuleDef moduledef = {PyModuleDef_HEAD_INIT, "_mxcodec", "bulk Python int <-> limb rows", -1, methods};
 
-PyMODINIT_FUNC PyInit__mxcodec(void) { return PyModule_Create(&moduledef); }
+PyMODINIT_FUNC PyInit__mxcodec(void) {
+  PyObject* m = PyModule_Create(&moduledef);
+  if (m) PyModule_AddIntConstant(m, "DIRECT_DIGITS", MX_DIRECT_DIGITS);
+  return m;
+}

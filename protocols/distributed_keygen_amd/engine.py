@@ -64,6 +64,44 @@ class _Plan:
         self.desc, self.block, self.stream_ptr, self.ready = desc, block, stream_ptr, ready
 
 
+class _ModulusRows:
+    """Moduli of a key-generation round kept on the device between its steps (survivors of the sieve, in order):
+    device rows of the width they were produced in, and the largest bit length."""
+
+    __slots__ = ("rows", "bits")
+
+    def __init__(self, rows, bits: int) -> None:
+        self.rows, self.bits = rows, int(bits)
+
+    def operand(self, eng, groups: int, limbs: int):
+        """The (rows, bits) operand the tensor-level entry points take, `limbs` words wide."""
+        if self.rows.shape[0] != groups:
+            raise ValueError("the kept moduli rows do not belong to these candidates")
+        if self.bits > 32 * limbs:
+            raise ValueError("modulus wider than the limb rows")
+        rows = self.rows
+        if rows.shape[1] > limbs:
+            rows = rows[:, :limbs].contiguous()         # produced in the Shamir field's width: the upper words are zero
+        elif rows.shape[1] < limbs:
+            rows = eng.torch.nn.functional.pad(rows, (0, limbs - rows.shape[1]))
+        return rows, self.bits
+
+
+class _VRows:
+    """A party's v values of a round kept on the device: rows [groups * keep, limbs] as biprime_v_t produced them
+    (rows beyond a candidate's count hold the modexp of a zero row: 0 or 1) and the counts."""
+
+    __slots__ = ("rows", "counts", "keep")
+
+    def __init__(self, rows, counts, keep: int) -> None:
+        self.rows, self.counts, self.keep = rows, counts, int(keep)
+
+    def slots(self, eng, groups: int, n_slots: int, limbs: int):
+        if self.rows.shape[0] != groups * self.keep or n_slots > self.keep or self.rows.shape[1] != limbs:
+            raise ValueError("the kept v rows do not belong to these candidates")
+        return self.rows.view(groups, self.keep, limbs)[:, :n_slots, :]
+
+
 class Engine:
     """One engine per process/GPU.  Calls enqueue on ``torch.cuda.current_stream()``; every stream gets
     its own workspace, so one Engine may be driven from several streams (one launch in flight per
@@ -891,13 +929,16 @@ class Engine:
 
     @_int_args
     def shamir_reconstruct_sieve_batch(self, columns: Sequence[Sequence[int]], coeffs: Sequence[int], prime: int,
-                                       primes: Sequence[int]) -> Tuple[List[bool], Dict[int, int]]:
+                                       primes: Sequence[int], keep_rows: bool = False):
         """The candidate moduli of a round and their small-prime verdicts in one device pass
         (DK:1284 + DK:1288-1292): reconstruction rows go straight into the sieve; only the verdict bytes
         and the moduli of the SURVIVORS (~2 % of a round) come back to the host.
-        Returns (has_small_divisor per candidate, {candidate index: modulus} for the survivors)."""
+        Returns (has_small_divisor per candidate, {candidate index: modulus} for the survivors); with
+        ``keep_rows`` a third value: the survivors' moduli as device rows (in index order, an opaque
+        handle for ``biprime_v_batch`` / ``biprime_verdict_columns``: the round's later steps take their moduli
+        from it instead of packing them again), None if nothing survived."""
         if len(columns) == 0 or len(columns[0]) == 0:
-            return [], {}
+            return ([], {}, None) if keep_rows else ([], {})
         limbs = _limbs.limbs_for(prime)
         x = np.stack([_limbs.pack_reduced(col, limbs, prime) for col in columns])
         mods_t = self.shamir_lincomb_t(self.to_device(x), coeffs, prime)
@@ -908,11 +949,15 @@ class Engine:
             bad = self.sieve_t(mods_t, primes).cpu().numpy()
         keep = np.nonzero(bad == 0)[0]
         survivors: Dict[int, int] = {}
+        rows = None
         if len(keep):
             idx = self.torch.from_numpy(keep.astype(np.int64)).to(self.device)
-            vals = _limbs.unpack(self.to_host(mods_t.index_select(0, idx)))
+            rows_t = mods_t.index_select(0, idx)
+            vals = _limbs.unpack(self.to_host(rows_t))
             survivors = {int(k): v for k, v in zip(keep, vals)}
-        return [bool(b) for b in bad], survivors
+            rows = _ModulusRows(rows_t, _limbs.max_bits(vals))
+        flags = bad.astype(bool).tolist()
+        return (flags, survivors, rows) if keep_rows else (flags, survivors)
 
     # ------------------------------------------------------------------ Jacobi symbol
     def jacobi_t(self, values_t, mods, group_size: int, out_t=None, first: int = 0, count: Optional[int] = None,
@@ -1007,29 +1052,41 @@ class Engine:
 
     @_int_args
     def biprime_v_batch(
-        self, g_values: Sequence[Sequence[int]], exps: Sequence[int], mods: Sequence[int], keep: int
-    ) -> List[List[int]]:
+        self, g_values: Sequence[Sequence[int]], exps: Sequence[int], mods: Sequence[int], keep: int,
+        mods_rows: Any = None, keep_rows: bool = False,
+    ):
         """The whole v-calculation of DK:1084-1099 for many candidates on the device: Jacobi symbols of
         all generators, selection of the first `keep` with symbol 1, v = g^exp mod N for those.
-        Returns per candidate the list of v values (shorter than `keep` if fewer symbols were 1)."""
+        Returns per candidate the list of v values (shorter than `keep` if fewer symbols were 1).
+        `mods_rows`: the handle ``shamir_reconstruct_sieve_batch(..., keep_rows=True)`` returned for exactly these
+        moduli — they are then not packed and uploaded again.  With ``keep_rows`` the result is
+        ``(lists, rows)`` where ``rows`` keeps this party's v values on the device for ``biprime_verdict_columns``."""
         groups = len(mods)
         if groups == 0:
-            return []
-        for m in mods:
-            _check_modulus(m)
+            return ([], None) if keep_rows else []
+        if mods_rows is None:
+            for m in mods:
+                _check_modulus(m)
         gsize = max(len(g) for g in g_values)
         if gsize == 0 or keep == 0:
-            return [[] for _ in mods]
+            return ([[] for _ in mods], None) if keep_rows else [[] for _ in mods]
         limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
-        flat = []
-        for gs in g_values:
-            flat.extend(gs)
-            flat.extend([0] * (gsize - len(gs)))          # padding: symbol (0/N) = 0, never selected
-        g_t = self.to_device(_limbs.pack_reduced(flat, limbs, list(mods)))
-        v_t, cnt_t = self.biprime_v_t(g_t, list(mods), list(exps), gsize, keep)
+        if all(len(gs) == gsize for gs in g_values):
+            from itertools import chain
+
+            flat = list(chain.from_iterable(g_values))
+        else:
+            flat = []
+            for gs in g_values:
+                flat.extend(gs)
+                flat.extend([0] * (gsize - len(gs)))      # padding: symbol (0/N) = 0, never selected
+        g_t = self.to_device(_limbs.pack_reduced(flat, limbs, mods))
+        mods_op = mods_rows.operand(self, groups, limbs) if mods_rows is not None else mods
+        v_t, cnt_t = self.biprime_v_t(g_t, mods_op, exps, gsize, keep)
         counts = cnt_t.cpu().numpy()
         vals = _limbs.unpack(self.to_host(v_t))
-        return [vals[g * keep : g * keep + int(counts[g])] for g in range(groups)]
+        lists = [vals[g * keep : g * keep + int(counts[g])] for g in range(groups)]
+        return (lists, _VRows(v_t, counts, keep)) if keep_rows else lists
 
     # ------------------------------------------------------------------ sieve
     @_int_args
@@ -1163,6 +1220,35 @@ class Engine:
 
         self._small(run)
         return pass_t
+
+    @_int_args
+    def biprime_verdict_columns(self, columns: Sequence[Any], mods: Sequence[int], n_slots: int, mods_rows: Any = None) -> List[List[bool]]:
+        """The slot tests DK:1147-1158 of many candidates from ONE COLUMN PER PARTY (party 1 first): a column is a flat
+        list of groups * n_slots values (candidate-major; short candidates padded by the caller) — packed with one
+        codec call — or the handle ``biprime_v_batch(..., keep_rows=True)`` returned for this party's own values,
+        which are then taken from the device as they are.  `mods_rows` as in ``biprime_v_batch``.
+        Returns per candidate the per-slot verdicts, like ``biprime_verdict_batch``."""
+        groups = len(mods)
+        if groups == 0:
+            return []
+        if n_slots == 0:
+            return [[] for _ in mods]
+        if mods_rows is None:
+            for m in mods:
+                _check_modulus(m)
+        limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
+        torch = self.torch
+        parts = []
+        for col in columns:
+            if isinstance(col, _VRows):
+                parts.append(col.slots(self, groups, n_slots, limbs))
+            else:
+                if len(col) != groups * n_slots:
+                    raise ValueError("a party's column needs groups * n_slots values")
+                parts.append(self.to_device(_limbs.pack_reduced(col, limbs, mods)).view(groups, n_slots, limbs))
+        mods_op = mods_rows.operand(self, groups, limbs) if mods_rows is not None else mods
+        pass_t = self.biprime_verdict_t(torch.stack(parts, dim=0), mods_op)
+        return pass_t.cpu().numpy().astype(bool).tolist()
 
     @_int_args
     def biprime_verdict_batch(self, v: Sequence[Sequence[Sequence[int]]], mods: Sequence[int]) -> List[List[bool]]:

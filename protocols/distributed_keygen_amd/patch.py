@@ -199,11 +199,14 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
     def _v_lists(batched_v_i: Any, party_indices: Dict[str, int]) -> Dict[int, List[int]]:
         out: Dict[int, List[int]] = {i: [] for i in party_indices.values()}
         for i in out:
-            for var in batched_v_i.variables:
-                try:
-                    out[i].append(var.get_share(i))
-                except KeyError:
-                    break
+            try:
+                out[i] = [var.get_share(i) for var in batched_v_i.variables]      # every slot set: the usual case
+            except KeyError:
+                for var in batched_v_i.variables:
+                    try:
+                        out[i].append(var.get_share(i))
+                    except KeyError:
+                        break
         return out
 
     def small_prime_divisors_test(cls: Any, prime_list: List[int], modulus: int) -> bool:
@@ -255,10 +258,14 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
             by_party = {i: [tbl[i] for tbl in share_table] for i in share_table[0]}
             # the interpolation points in the order ShamirShares.reconstruct_secret would take them: the first
             # degree+1 entries of the shares dictionary in insertion order
-            has_divisor, surviving = shamir.reconstruct_and_sieve_batch(
-                by_party, scheme_n.modulus, scheme_n.polynomial_degree, prime_list, engine,
+            # (biprime.BiprimeRound: the survivors' moduli and, later, this party's v rows stay on the device between the
+            # steps of the round; every value that crosses a communication round does so as a Python int, as in the reference)
+            this_round = biprime.BiprimeRound(engine)
+            surviving = this_round.reconstruct_and_sieve(
+                by_party, scheme_n.modulus, scheme_n.polynomial_degree, prime_list,
                 points=list(share_table[0])[: scheme_n.polynomial_degree + 1])
-            survivors = sorted(surviving)
+            has_divisor = this_round.has_divisor
+            survivors = this_round.survivors
             moduli = surviving                                          # candidate index -> modulus, survivors only
             sieved_out += len(has_divisor) - len(survivors)
             if not survivors:
@@ -268,19 +275,14 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
                 f"{sid}_biprime_test_g_{rounds}",
             )
             # DK:1313-1329 as one launch
-            v_lists = biprime.biprime_test_v_calculation_batch(
-                g_values, index, [moduli[k] for k in survivors], [p_add[k] for k in survivors],
-                [q_add[k] for k in survivors], correct_param_biprime, engine,
-            )
+            v_lists = this_round.v_calculation(
+                g_values, index, [p_add[k] for k in survivors], [q_add[k] for k in survivors], correct_param_biprime)
             to_exchange = [
                 _to_batched(v, index, moduli[k], correct_param_biprime) for v, k in zip(v_lists, survivors)
             ]
             await exchange_reconstruct(to_exchange, index, pool, party_indices, msg_id=f"{sid}_biprime_test_v_{rounds}_v")
             # DK:1339-1360: slot tests of all survivors as one launch; first passing candidate wins
-            verdicts = biprime.biprime_test_with_v_i_batch(
-                [_v_lists(b, party_indices) for b in to_exchange], [moduli[k] for k in survivors],
-                correct_param_biprime, engine, errors="return",
-            )
+            verdicts = this_round.verdicts([_v_lists(b, party_indices) for b in to_exchange], correct_param_biprime, errors="return")
             for verdict, k in zip(verdicts, survivors):
                 shares.p = Shares.P(p_add[k], q_sh[k].get_shares())  # as DK:1344-1345 (sic)
                 shares.q = Shares.Q(q_add[k], q_sh[k].get_shares())

@@ -106,3 +106,66 @@ def test_three_party_keygen_hot_path_finds_a_biprime():
     cts = eng.encrypt_batch(msgs, [rng.randrange(1, n) for _ in msgs], n)
     parts = {i: k.partial_decrypt_batch([PlainCiphertext(c, n) for c in cts]) for i, k in keys.items()}
     assert keys[2].decrypt_batch([{i: parts[i][e] for i in keys} for e in range(len(cts))]) == msgs
+
+
+def test_biprime_round_with_state_on_the_device_equals_the_list_level_steps():
+    """biprime.BiprimeRound (what patch.compute_modulus runs per round: the survivors' moduli and this party's v rows
+    stay on the device between reconstruct + sieve, v-calculation and verdicts) against the list-level functions and the
+    oracle, at key_length 1024 with 5 parties: same sieve verdicts, same v values, same verdicts with planted biprimes;
+    a tampered copy of this party's values must NOT be answered from the device rows; short v lists keep the
+    reference's KeyError."""
+    import sympy
+
+    from protocols.distributed_keygen_amd import Engine, biprime, shamir, synthetic
+
+    eng = Engine()
+    rng = random.Random(2024)
+    n_parties, t, key_length, nbip, batch = 5, 2, 1024, 40, 1500
+    half = key_length // 2
+    primes = oracle.small_prime_list(2000)
+    field = int(sympy.nextprime(1 << (2 * (half + 4) + 44)))
+    shares = [synthetic.candidate_shares(rng, n_parties, half) for _ in range(batch)]
+    planted = synthetic.biprime_candidate_shares(rng, n_parties, half) if hasattr(synthetic, "biprime_candidate_shares") else None
+    if planted is not None:
+        shares[7] = planted
+    moduli = [sum(p) * sum(q) for p, q in shares]
+    points = list(range(1, n_parties + 1))
+    by_party = {i: [] for i in points}
+    for m in moduli:
+        coeffs = [m] + [rng.randrange(field) for _ in range(2 * t)]
+        for i in points:
+            by_party[i].append(sum(c * pow(i, e, field) for e, c in enumerate(coeffs)) % field)
+    rnd = biprime.BiprimeRound(eng)
+    surviving = rnd.reconstruct_and_sieve(by_party, field, 2 * t, primes, points=points)
+    bad, surviving_ref = shamir.reconstruct_and_sieve_batch(by_party, field, 2 * t, primes, eng, points=points)
+    assert rnd.has_divisor == bad == [oracle.small_prime_divisors_test(primes, m) for m in moduli]
+    assert surviving == surviving_ref == {k: moduli[k] for k in range(batch) if not bad[k]}
+    surv = rnd.survivors
+    assert len(surv) >= 5 and rnd.moduli == [moduli[k] for k in surv]
+    mods = rnd.moduli
+    g_values = [[rng.randrange(m) for _ in range(4 * nbip)] for m in mods]
+    g_values[1] = g_values[1][:9]                                   # a candidate that runs out of generators
+    ps = {i: [shares[k][0][i - 1] for k in surv] for i in points}
+    qs = {i: [shares[k][1][i - 1] for k in surv] for i in points}
+    v = {i: biprime.biprime_test_v_calculation_batch(g_values, i, mods, ps[i], qs[i], nbip, eng) for i in points}
+    for index in (1, 3):
+        own = rnd.v_calculation(g_values, index, ps[index], qs[index], nbip)
+        assert own == v[index]
+        e0 = biprime.biprime_exponent(index, mods[0], ps[index][0], qs[index][0])
+        keep = [g for g in g_values[0] if oracle.jacobi_symbol(g, mods[0]) == 1][:nbip]
+        assert own[0] == [pow(g, e0, mods[0]) for g in keep]
+        v_by = [{i: list(v[i][c]) for i in points} for c in range(len(mods))]
+        want = biprime.biprime_test_with_v_i_batch(v_by, mods, nbip, eng, errors="return")
+        got = rnd.verdicts(v_by, nbip, errors="return")
+        assert [type(x) for x in got] == [type(x) for x in want]
+        assert [x for x in got if not isinstance(x, Exception)] == [x for x in want if not isinstance(x, Exception)]
+        assert isinstance(got[1], KeyError)                         # the short candidate: the reference's KeyError
+        for c in (0, 2, len(mods) - 1):
+            if not isinstance(got[c], Exception):
+                assert got[c] == oracle.biprime_test_with_v_i(v_by[c], mods[c], nbip)
+        # a tampered copy of this party's values: the verdicts follow the values handed in, not the device rows
+        v_bad = [{i: list(vals) for i, vals in vc.items()} for vc in v_by]
+        v_bad[0][index][0] = (v_bad[0][index][0] + 1) % mods[0]
+        got_bad = rnd.verdicts(v_bad, nbip, errors="return")
+        assert got_bad[0] == oracle.biprime_test_with_v_i(v_bad[0], mods[0], nbip)
+        assert got_bad[2:] == got[2:]
