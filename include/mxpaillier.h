@@ -69,7 +69,10 @@ int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_
                     int64_t group_size, void* d_workspace, int64_t workspace_bytes, void* stream);
 
 /* mx_powmod_shared with the lane geometry as an argument: limbs_per_lane 9 (narrow: more lanes per
- * element), 18 (wide: fewer, busier lanes) or 0 (automatic from the batch size). */
+ * element), 18 (wide: fewer, busier lanes), 3 (latency: many lanes per element, the exponentiation's products modulo
+ * the friendly multiple of N — for launches that leave SIMDs idle, moduli up to 5533 bits) or 0 = automatic from the
+ * batch size: 3 while the launch brings at most two such wavefronts per SIMD, else 9 or 18 by instruction count.
+ * The same argument of mx_powmod_multi_dev and mx_powmod_geometry_for. */
 int mx_powmod_shared_lpl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
                          int limbs, int exp_limbs, int64_t batch, int limbs_per_lane, void* d_workspace,
                          int64_t workspace_bytes, void* stream);
@@ -283,11 +286,13 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
  * time-sliced form of two-wavefront launches (resident workgroups that share the groups of elements segment by
  * segment): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
  * workgroups per CU (r = 1..3).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
- * friendly-modulus instances (A/B runs against the plain ones).  Process-wide; returns MX_OK / MX_ERR_ARG. */
+ * friendly-modulus instances (A/B runs against the plain ones).  MX_KNOB_GENERIC_LATENCY: 1 = the automatic geometry of
+ * the generic-modulus modexp never takes the 3-limb latency instances.  Process-wide; returns MX_OK / MX_ERR_ARG. */
 #define MX_KNOB_N2_SEGMENTS 1
 #define MX_KNOB_JACOBI_MAX_BATCHES 2
 #define MX_KNOB_N2_TIMESLICE 3
 #define MX_KNOB_N2_FRIENDLY_1W 4
+#define MX_KNOB_GENERIC_LATENCY 5
 int mx_debug_knob(int knob, int value);
 /* Enqueues a kernel of ONE wavefront that idles for `microseconds` (0..1 000 000) on `stream` and touches no
  * memory.  A concurrency probe: two streams that the HIP runtime has mapped to the same hardware queue run

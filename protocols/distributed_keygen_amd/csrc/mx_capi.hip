@@ -19,6 +19,7 @@ int g_limbs_per_lane = 0;
 int g_knob_n2_segments = 0;
 int g_knob_n2_timeslice = 0;
 int g_knob_n2_friendly_1w = 0;
+int g_knob_generic_latency = 0;
 int g_knob_jacobi_max_batches = 0;
 }
 MxProfile g_mx_profile;
@@ -34,14 +35,31 @@ struct PowmodPlan {
   int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_ops = 0, off_table = 0, total = 0;
 };
 
-// Geometry when the caller leaves the choice to the library.  Per-group exponents (biprimality test,
+}  // namespace
+// latency instances (3 limbs per lane) live in mx_capi_lat.hip
+namespace mxl {
+int launch_powmod_lat(int K, const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s);
+int launch_rmodn_lat(int K, const mx::RmodnArgs& a, hipStream_t s);
+}
+namespace {
+inline bool generic_lpl_ok(int lpl) { return lpl == 0 || lpl == LIMBS_PER_LANE || lpl == LIMBS_PER_LANE_WIDE || lpl == LIMBS_PER_LANE_LAT; }
+
+// Geometry when the caller leaves the choice to the library.  A launch whose wavefronts at 3 limbs per lane number at
+// most two per SIMD runs the latency instances: the launch then lasts as long as ONE wavefront's dependent chain, which
+// is 0.57 of the 9-limb one (16 instead of 28 instructions per limb step) alone on its SIMD and still shorter with a
+// second wavefront beside it; beyond that the instruction count decides (tools/sweep_generic.py,
+// profiles/r04_sweep_generic.txt).  Per-group exponents (biprimality test,
 // fixed-window kernel): the wide geometry issues 30 % fewer instructions but runs 2 wavefronts per
 // SIMD (216 VGPRs) with twice the elements each, so it only wins when the launch spans several
 // rounds of the 2048 wavefront slots (tools/ab_biprime.sh: key_length 2048, 4096 candidates x 40:
 // 1.31 M vs 1.13 M modexps/s; 1024 candidates: 1.02 M vs 1.08 M) and the narrow geometry needs at
 // least 8 lanes per element.  One shared exponent: wide once every SIMD gets two wavefronts.
 int auto_limbs_per_lane(int mod_bits, int64_t batch, int64_t groups) {
-  Geometry narrow, wide;
+  Geometry narrow, wide, lat;
+  if (g_knob_generic_latency != 1 && choose_geometry(mod_bits, lat, LIMBS_PER_LANE_LAT)) {
+    const int64_t waves = (batch * lat.K + 63) / 64;
+    if (waves <= (int64_t)2 * 4 * mx_device_cus()) return LIMBS_PER_LANE_LAT;
+  }
   if (!choose_geometry(mod_bits, narrow, LIMBS_PER_LANE) || !choose_geometry(mod_bits, wide, LIMBS_PER_LANE_WIDE))
     return LIMBS_PER_LANE;
   const int64_t waves = (batch * wide.K + 63) / 64;
@@ -82,6 +100,7 @@ int launch_powmod_kl(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
 
 template <int K>
 int launch_powmod_k(const mx::PowmodArgs& a, int64_t nblocks, int limbs_per_lane, hipStream_t s) {
+  if (limbs_per_lane == LIMBS_PER_LANE_LAT) return mxl::launch_powmod_lat(K, a, nblocks, s);
   if (limbs_per_lane == LIMBS_PER_LANE_WIDE) {
     // the largest supported modulus (MAX_MOD_BITS) needs 32 wide lanes: no <64, 18> instance
     if constexpr (K <= 32) return launch_powmod_kl<K, LIMBS_PER_LANE_WIDE>(a, nblocks, s);
@@ -106,6 +125,7 @@ int launch_rmodn_kl(const mx::RmodnArgs& a, hipStream_t s) {
 int launch_rmodn(const Geometry& g, const u32* d_mods, u32* d_rmodn, int limbs, int64_t groups, hipStream_t s) {
   mx::RmodnArgs a;
   a.mods = d_mods; a.rmodn = d_rmodn; a.groups = groups; a.limbs = limbs; a.nblk = g.nblk;
+  if (g.L == LIMBS_PER_LANE_LAT) return mxl::launch_rmodn_lat(g.K, a, s);
   const bool wide = g.L == LIMBS_PER_LANE_WIDE;
   switch (g.K) {
 #define MX_CASE(KK) case KK: return wide ? launch_rmodn_kl<KK, LIMBS_PER_LANE_WIDE>(a, s) : launch_rmodn_kl<KK, LIMBS_PER_LANE>(a, s);
@@ -275,6 +295,7 @@ int mx_debug_knob(int knob, int value) {
     case MX_KNOB_N2_TIMESLICE: if (value > 2 && (value < 17 || value > 19)) return MX_ERR_ARG; g_knob_n2_timeslice = value; return MX_OK;
     case MX_KNOB_JACOBI_MAX_BATCHES: g_knob_jacobi_max_batches = value; return MX_OK;
     case MX_KNOB_N2_FRIENDLY_1W: if (value > 1) return MX_ERR_ARG; g_knob_n2_friendly_1w = value; return MX_OK;
+    case MX_KNOB_GENERIC_LATENCY: if (value > 1) return MX_ERR_ARG; g_knob_generic_latency = value; return MX_OK;
   }
   return MX_ERR_ARG;
 }
@@ -322,9 +343,13 @@ int64_t mx_powmod_workspace_bytes(int limbs, int exp_limbs, int64_t batch, int64
   if (limbs <= 0 || exp_limbs <= 0 || batch <= 0 || groups <= 0) return MX_ERR_ARG;
   PowmodPlan p, q;
   if (!plan_powmod(sizing_bits(limbs), limbs, exp_limbs, batch, groups, p, LIMBS_PER_LANE)) return MX_ERR_SIZE;
-  if (plan_powmod(sizing_bits(limbs), limbs, exp_limbs, batch, groups, q, LIMBS_PER_LANE_WIDE) && q.total > p.total)
-    return q.total;
-  return p.total;
+  int64_t most = p.total;
+  if (plan_powmod(sizing_bits(limbs), limbs, exp_limbs, batch, groups, q, LIMBS_PER_LANE_WIDE) && q.total > most) most = q.total;
+  // (the latency geometry only exists up to 64 x 3 limbs: rows that could hold a wider modulus are sized with the
+  // widest one it takes)
+  const int lat_bits = std::min(sizing_bits(limbs), LIMB_BITS * LIMBS_PER_LANE_LAT * 64 - 4 - LIMB_BITS - 2);
+  if (plan_powmod(lat_bits, limbs, exp_limbs, batch, groups, q, LIMBS_PER_LANE_LAT) && q.total > most) most = q.total;
+  return most;
 }
 
 int mx_powmod_shared(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
@@ -337,7 +362,7 @@ int mx_powmod_shared(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h
 int mx_powmod_shared_lpl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
                          int limbs, int exp_limbs, int64_t batch, int limbs_per_lane, void* d_workspace,
                          int64_t workspace_bytes, void* stream) {
-  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  if (!generic_lpl_ok(limbs_per_lane)) return MX_ERR_ARG;
   return powmod_impl(d_bases, d_out, h_mod, h_exp, limbs, exp_limbs, 1, batch, limbs_per_lane, d_workspace,
                      workspace_bytes, stream);
 }
@@ -355,7 +380,7 @@ int mx_powmod_multi_dev(const uint32_t* d_bases, uint32_t* d_out, const uint32_t
   if (!d_bases || !d_out || !d_mods || !d_exps || !d_workspace) return MX_ERR_ARG;
   if (limbs <= 0 || exp_limbs <= 0 || groups <= 0 || group_size <= 0) return MX_ERR_ARG;
   if (mod_bits < 2 || mod_bits > 32 * limbs || exp_bits < 0 || exp_bits > 32 * exp_limbs) return MX_ERR_ARG;
-  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  if (!generic_lpl_ok(limbs_per_lane)) return MX_ERR_ARG;
   PowmodPlan p;
   if (!plan_powmod(mod_bits, limbs, exp_limbs, groups * group_size, groups, p, limbs_per_lane)) return MX_ERR_SIZE;
   if (p.total > workspace_bytes) return MX_ERR_WORKSPACE;
@@ -366,7 +391,7 @@ int mx_powmod_multi_dev(const uint32_t* d_bases, uint32_t* d_out, const uint32_t
 int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* k, int* l, int* w,
                            int* blocks) {
   if (!k || !l || !w || !blocks || batch <= 0 || groups <= 0) return MX_ERR_ARG;
-  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
+  if (!generic_lpl_ok(limbs_per_lane)) return MX_ERR_ARG;
   Geometry g;
   if (!choose_geometry(mod_bits, g, limbs_per_lane ? limbs_per_lane : auto_limbs_per_lane(mod_bits, batch, groups)))
     return MX_ERR_SIZE;

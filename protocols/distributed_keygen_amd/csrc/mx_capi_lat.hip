@@ -1,0 +1,45 @@
+// Latency instances of the generic-modulus modexp (mx_powmod.hpp) and of its per-group setup kernel (mx_setup.hpp):
+// 3 limbs per lane, the products of the exponentiation modulo the friendly multiple of N.  For launches that leave
+// SIMDs idle — the biprimality-test modexps of a key-generation round at the reference's batch sizes leave 2-25
+// survivors, i.e. a few hundred to a thousand modexps (distributed_keygen.py:1084-1099 looped at :1313-1329): the
+// time of such a launch is the dependent chain of ONE wavefront, and fewer limbs per lane shorten it.
+// Translation unit of its own, built in parallel with the others.
+#include "mx_upload.hpp"
+#include "mx_powmod.hpp"
+#include "mx_setup.hpp"
+
+namespace mxl {
+template <int K>
+static int launch_powmod(const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE_LAT, LIMB_BITS, true>;
+  const size_t lds = (size_t)(64 / K) * M_t::LDS_WORDS * 4;
+  MxKernelTimer timer(s);
+  if (a.nops > 0)
+    hipLaunchKernelGGL((mx::powmod_kernel<K, LIMBS_PER_LANE_LAT, LIMB_BITS, true, true>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  else
+    hipLaunchKernelGGL((mx::powmod_kernel<K, LIMBS_PER_LANE_LAT, LIMB_BITS, false, true>), dim3((unsigned)nblocks), dim3(64), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+template <int K>
+static int launch_rmodn(const mx::RmodnArgs& a, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE_LAT, LIMB_BITS, true>;
+  const int gpw = 64 / K;
+  const int64_t nblocks = (a.groups + gpw - 1) / gpw;
+  hipLaunchKernelGGL((mx::rmodn_kernel<K, LIMBS_PER_LANE_LAT, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), (size_t)gpw * M_t::LDS_WORDS * 4, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+
+#define MX_LAT_CASES(FN, ...) \
+  switch (K) {                \
+    case 1: return FN<1>(__VA_ARGS__); case 2: return FN<2>(__VA_ARGS__); case 4: return FN<4>(__VA_ARGS__);     \
+    case 8: return FN<8>(__VA_ARGS__); case 16: return FN<16>(__VA_ARGS__); case 32: return FN<32>(__VA_ARGS__); \
+    case 64: return FN<64>(__VA_ARGS__);                                                                         \
+  }                                                                                                              \
+  return MX_ERR_SIZE;
+
+int launch_powmod_lat(int K, const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) { MX_LAT_CASES(launch_powmod, a, nblocks, s) }
+int launch_rmodn_lat(int K, const mx::RmodnArgs& a, hipStream_t s) { MX_LAT_CASES(launch_rmodn, a, s) }
+}  // namespace mxl

@@ -19,7 +19,6 @@ struct N2Shape {
 // elements), 3 — the latency geometry — only in the two-wavefront form (mx_powmod_n2_split.hpp).  (2 limbs per
 // lane were tried too: fewer instructions per limb step, but the quotient digit then travels through an SGPR
 // (v_readfirstlane for 64-lane groups) and the dependent chain got longer, 18.5 vs 16.8 ms for one ciphertext.)
-constexpr int LIMBS_PER_LANE_LAT = 3;
 constexpr int N2_GEOS = 3;                      // constant sets of a plan, in geo_index order
 constexpr int N2_LPLS[N2_GEOS] = {LIMBS_PER_LANE, LIMBS_PER_LANE_WIDE, LIMBS_PER_LANE_LAT};
 inline int geo_index(int lpl) {

@@ -142,6 +142,16 @@ struct Mont {
 
   // F_FRIENDLY: nf[] must hold this lane's limbs of N~ + 1 (loaded by the caller from the host's constants)
   __device__ __forceinline__ void setup_friendly() { uf = n0inv; }
+  // ... or computed here from the modulus alone (per-candidate moduli have no host constants): N~ + 1 = u N + 1 with
+  // u = -N^-1 mod 2^W — one multiply-add per limb and a carry sweep; the geometry leaves the W bits of room.
+  __device__ __forceinline__ void compute_friendly() {
+    uf = n0inv;
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = (u64)n[j] * uf;
+    if (p == 0) t[0] += 1;
+    normalize_full(nf, t);
+  }
 
   // ------------------------------------------------------------------ carry handling
   // 64-bit columns -> almost-normalised limbs (limb 1 may exceed 2^W by < 2^7).  One local carry
@@ -502,6 +512,15 @@ struct Mont {
 
   // r = a^2 / R mod N (lazy), with the symmetric product
   __device__ __forceinline__ void sqr(u32 (&r)[L], const u32 (&a)[L]) { mul<false, true>(r, a, a); }
+
+  // the same two modulo the friendly multiple of N (F_FRIENDLY: results below 2 N~; nf / uf must be set)
+  template <bool SQUARE = false>
+  __device__ __forceinline__ void mul_friendly(u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L]) {
+    u32 av[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) av[j] = a[j];
+    mulx<F_FRIENDLY | (SQUARE ? F_SQUARE : 0)>(r, av, b, av, b, b, nullptr, nullptr, nblk);
+  }
 
   // ------------------------------------------------------------------ constants
   // one: the integer 1 (limb 0 of the group's lane 0)

@@ -37,7 +37,11 @@ struct PowmodArgs {
 
 // SLIDING = the shared-exponent schedule (A.ops), otherwise the fixed window with per-group digits;
 // two kernels rather than one branch so that neither carries the other's register pressure.
-template <int K, int L, int W, bool SLIDING>
+// FR (the 3-limb latency instances): the products of the exponentiation reduce modulo the friendly multiple of N
+// (mx_mont.hpp: F_FRIENDLY — no multiplication on the quotient digit's dependent chain); N~ + 1 is derived from each
+// group's modulus in the kernel, and the conversion out of the Montgomery domain runs the plain passes, which bring
+// the result below N + 1 whatever multiple of N it carried (x < 2 N~ < R).
+template <int K, int L, int W, bool SLIDING, bool FR = false>
 __global__ void __launch_bounds__(64, (L > 9 ? 2 : 1)) powmod_kernel(PowmodArgs A) {
   using M_t = Mont<K, L, W, true>;
   extern __shared__ u32 smem[];
@@ -61,18 +65,25 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 1)) powmod_kernel(PowmodArgs 
   M.compute_r2(r2, one_m);
   M.load(x, A.bases + elem * A.limbs, A.limbs);
   M.mul(x, x, r2);                                   // x = base * R mod N (lazy)
+  if constexpr (FR) M.compute_friendly();
+  auto MUL = [&](u32 (&r)[L], const u32 (&a)[L], const u32 (&b)[L]) {
+    if constexpr (FR) M.template mul_friendly<false>(r, a, b); else M.mul(r, a, b);
+  };
+  auto SQR = [&](u32 (&r)[L], const u32 (&a)[L]) {
+    if constexpr (FR) M.template mul_friendly<true>(r, a, a); else M.sqr(r, a);
+  };
 
   u32* tbl = A.table + gl;
   if constexpr (SLIDING) {
     // ---- sliding window over a shared exponent: odd powers only, multiplications only where
     // the exponent has a window (the schedule is the same for every lane: uniform control flow)
     u32 x2[L], y[L];
-    M.sqr(x2, x);
+    SQR(x2, x);
 #pragma unroll
     for (int j = 0; j < L; ++j) { y[j] = x[j]; tbl[(i64)j * nlanes] = x[j]; }
     const int nodd = 1 << (A.win - 1);
     for (int k = 1; k < nodd; ++k) {
-      M.mul(y, y, x2);
+      MUL(y, y, x2);
 #pragma unroll
       for (int j = 0; j < L; ++j) tbl[((i64)k * L + j) * nlanes] = y[j];
     }
@@ -94,12 +105,12 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 1)) powmod_kernel(PowmodArgs 
 #pragma unroll
         for (int j = 0; j < L; ++j) f[j] = tbl[((i64)(idx1 - 1) * L + j) * nlanes];
       }
-      for (int s = 0; s < nsq; ++s) M.sqr(acc, acc);
+      for (int s = 0; s < nsq; ++s) SQR(acc, acc);
       if (L > 9 && idx1) {
 #pragma unroll
         for (int j = 0; j < L; ++j) f[j] = tbl[((i64)(idx1 - 1) * L + j) * nlanes];
       }
-      if (idx1) M.mul(acc, acc, f);
+      if (idx1) MUL(acc, acc, f);
     }
     u32 res[L];
     M.from_mont_canonical(res, acc);
@@ -116,7 +127,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 1)) powmod_kernel(PowmodArgs 
 #pragma unroll
     for (int j = 0; j < L; ++j) y[j] = x[j];
     for (int k = 2; k < nent; ++k) {
-      M.mul(y, y, x);
+      MUL(y, y, x);
 #pragma unroll
       for (int j = 0; j < L; ++j) tbl[((i64)k * L + j) * nlanes] = y[j];
     }
@@ -142,8 +153,8 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 1)) powmod_kernel(PowmodArgs 
     u32 y[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) y[j] = tbl[((i64)dg * L + j) * nlanes];   // issued early, used after the squarings
-    for (int s = 0; s < A.win; ++s) M.sqr(acc, acc);
-    M.mul(acc, acc, y);
+    for (int s = 0; s < A.win; ++s) SQR(acc, acc);
+    MUL(acc, acc, y);
   }
 
   u32 res[L];

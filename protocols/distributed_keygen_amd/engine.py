@@ -192,7 +192,7 @@ class Engine:
         self._wpg = int(wavefronts)
 
     def _lpl_generic(self) -> int:
-        return self._lpl if self._lpl in (9, 18) else 0
+        return self._lpl if self._lpl in (3, 9, 18) else 0
 
     def set_segments(self, segments: int) -> None:
         """Launches one mx_powmod_nsquare_run exponentiation is cut into (0 = automatic, 1..64)."""
@@ -243,7 +243,7 @@ class Engine:
     def debug_knob(self, knob: str, value: int) -> None:
         """Developer overrides of the library (include/mxpaillier.h: mx_debug_knob; process-wide, 0 restores
         the default): "n2_segments", "jacobi_max_batches", "n2_timeslice" (1 never, 2 always), "n2_friendly_1w" (1 never)."""
-        ids = {"n2_segments": 1, "jacobi_max_batches": 2, "n2_timeslice": 3, "n2_friendly_1w": 4}
+        ids = {"n2_segments": 1, "jacobi_max_batches": 2, "n2_timeslice": 3, "n2_friendly_1w": 4, "generic_latency": 5}
         _lib.check(self.lib.mx_debug_knob(ids[knob], int(value)), "mx_debug_knob")
 
     def cu_slice_streams(self, n: int) -> List[Any]:

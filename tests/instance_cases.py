@@ -64,6 +64,10 @@ GENERIC_CASES = [
     ("multi", 4100, 18, 10, 96), ("multi", 8200, 18, 6, 64), ("multi", 16400, 18, 3, 40),
 ]
 
+# the latency instances of the generic kernel (3 limbs per lane, friendly-modulus products): K = 1 .. 64
+GENERIC_CASES += [(kind, bits, 3, batch, ebits) for kind in ("shared", "multi") for bits, batch, ebits in
+                  ((50, 70, 40), (130, 67, 100), (300, 35, 130), (600, 19, 130), (1027, 9, 130), (2051, 5, 130), (4100, 3, 96))]
+
 ALL_CASES = N2_CASES + GENERIC_CASES
 
 
@@ -118,7 +122,7 @@ def reachable_instances(lib):
                         out.add(("n2",) + g)
             if coarse:
                 continue
-            for lpl in (0, 9, 18):
+            for lpl in (0, 3, 9, 18):
                 for groups, name in ((1, "generic-sliding"), (max(2, batch // 40), "generic-fixed")):
                     g = _geom(lib.mx_powmod_geometry_for, bits, max(batch, groups), groups, lpl)
                     if g is not None:

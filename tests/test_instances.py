@@ -37,6 +37,7 @@ def test_every_reachable_instance_has_a_parity_case():
     for kind in ("generic-sliding", "generic-fixed"):
         assert {k for kd, k, l, *w in reachable if kd == kind and l == 9} == {1, 2, 4, 8, 16, 32, 64}
         assert {k for kd, k, l, *w in reachable if kd == kind and l == 18} == {1, 2, 4, 8, 16, 32}
+        assert {k for kd, k, l, *w in reachable if kd == kind and l == 3} == {1, 2, 4, 8, 16, 32, 64}       # latency instances
 
 
 def test_auto_launch_shapes_match_the_measured_crossovers():
@@ -110,7 +111,7 @@ def test_no_modexp_kernel_has_a_private_segment():
     assert len(rows) > 100, "kernel metadata of the library not found"
     modexp = [r for r in rows if "powmod" in names[r[0]]]
     assert len(modexp) >= 60, len(modexp)
-    for tmpl in ("mx::powmod_n2_kernel<4, 18, 29, true>", "mx::powmod_n2_kernel<4, 18, 29, false>", "mx::powmod_n2_split_kernel<8, 9, 29, true, true>", "mx::powmod_kernel<8, 9, 29, false>",
+    for tmpl in ("mx::powmod_n2_kernel<4, 18, 29, true>", "mx::powmod_n2_kernel<4, 18, 29, false>", "mx::powmod_n2_split_kernel<8, 9, 29, true, true>", "mx::powmod_kernel<8, 9, 29, false, false>", "mx::powmod_kernel<32, 3, 29, false, true>",
                  "mx::powmod_n2_split_kernel<32, 3, 29, false, true>"):
         assert any(tmpl in names[r[0]] for r in modexp), tmpl
     offenders = [(names[r[0]], r[1], r[2]) for r in rows if (r[1] or r[2]) and "jacobi" not in names[r[0]]]

@@ -70,6 +70,12 @@ for step in "$@"; do
     census --queues 16 --label "shipped time-sliced, second process" --shape 9,2 --timeslice 2 --reps 2
     grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
     ;;
+  sweep_generic)
+    python tools/sweep_generic.py 1024 2048 > $O/sweep_generic.txt 2>&1; cat $O/sweep_generic.txt | tail -80
+    ;;
+  keygen)
+    ( time python -m pytest tests/test_gpu_keygen_flow.py tests/test_gpu_standin.py -m gpu -x -q ) > $O/pytest_keygen.log 2>&1; tail -5 $O/pytest_keygen.log
+    ;;
   counters_avail)
     ( cd /tmp && rocprofv3 --list-avail 2>&1 ) > $O/counters_avail.txt; grep -c . $O/counters_avail.txt; grep -oE "\bSQ_[A-Z0-9_]+" $O/counters_avail.txt | sort -u | tr '\n' ' ' | head -c 6000; echo
     ;;
