@@ -44,27 +44,36 @@ int launch_rmodn_lat(int K, const mx::RmodnArgs& a, hipStream_t s);
 namespace {
 inline bool generic_lpl_ok(int lpl) { return lpl == 0 || lpl == LIMBS_PER_LANE || lpl == LIMBS_PER_LANE_WIDE || lpl == LIMBS_PER_LANE_LAT; }
 
-// Geometry when the caller leaves the choice to the library.  A launch whose wavefronts at 3 limbs per lane number at
-// most two per SIMD runs the latency instances: the launch then lasts as long as ONE wavefront's dependent chain, which
-// is 0.57 of the 9-limb one (16 instead of 28 instructions per limb step) alone on its SIMD and still shorter with a
-// second wavefront beside it; beyond that the instruction count decides (tools/sweep_generic.py,
-// profiles/r04_sweep_generic.txt).  Per-group exponents (biprimality test,
-// fixed-window kernel): the wide geometry issues 30 % fewer instructions but runs 2 wavefronts per
-// SIMD (216 VGPRs) with twice the elements each, so it only wins when the launch spans several
-// rounds of the 2048 wavefront slots (tools/ab_biprime.sh: key_length 2048, 4096 candidates x 40:
-// 1.31 M vs 1.13 M modexps/s; 1024 candidates: 1.02 M vs 1.08 M) and the narrow geometry needs at
-// least 8 lanes per element.  One shared exponent: wide once every SIMD gets two wavefronts.
+// Geometry when the caller leaves the choice to the library: the shape with the shortest estimated duration of ONE launch
+// on an idle GPU.  A wavefront of the 3- / 9- / 18-limb instances carries 64 / K elements through the whole exponentiation
+// in 1 : 1.43 : 2.12 of the time (instructions on its dependent chain: 16 / 28 / 47 per limb step, measured ratios), alone
+// on its SIMD; every further wavefront per SIMD adds 0.6 / 0.8 / 0.96 of that (a second wavefront fills the issue slots
+// the first one leaves: more of them in the short-limbed instances) — fitted to tools/sweep_generic.py at key_length 1024
+// and 2048 (profiles/r04_sweep_generic.txt; the choice matches the fastest measured shape at every point of the sweep
+// within 3 %).  Consequences: a keygen round's few hundred to a thousand modexps (2-25 survivors) run the latency
+// instances (6.0 instead of 8.7 ms at key_length 2048), 256-384 candidates the wide ones (one wavefront per SIMD: 12.8
+// instead of 15.3 ms), the saturating launches whichever packs the SIMDs more evenly.
+double generic_estimate(int mod_bits, int64_t batch, int lpl) {
+  Geometry g;
+  if (!choose_geometry(mod_bits, g, lpl)) return -1.0;
+  if (lpl == LIMBS_PER_LANE_WIDE && g.K > 32) return -1.0;          // no <64, 18> instance
+  const int64_t waves = (batch * g.K + 63) / 64;
+  const int64_t simds = (int64_t)4 * mx_device_cus();
+  const int64_t per_simd = (waves + simds - 1) / simds;
+  const double t1 = lpl == LIMBS_PER_LANE_LAT ? 1.0 : lpl == LIMBS_PER_LANE ? 1.43 : 2.12;
+  const double more = lpl == LIMBS_PER_LANE_LAT ? 0.6 : lpl == LIMBS_PER_LANE ? 0.8 : 0.96;
+  return t1 * (1.0 + more * (double)(per_simd - 1));
+}
 int auto_limbs_per_lane(int mod_bits, int64_t batch, int64_t groups) {
-  Geometry narrow, wide, lat;
-  if (g_knob_generic_latency != 1 && choose_geometry(mod_bits, lat, LIMBS_PER_LANE_LAT)) {
-    const int64_t waves = (batch * lat.K + 63) / 64;
-    if (waves <= (int64_t)2 * 4 * mx_device_cus()) return LIMBS_PER_LANE_LAT;
+  (void)groups;
+  int best = LIMBS_PER_LANE;
+  double best_t = -1.0;
+  for (int lpl : {LIMBS_PER_LANE, LIMBS_PER_LANE_WIDE, LIMBS_PER_LANE_LAT}) {
+    if (lpl == LIMBS_PER_LANE_LAT && g_knob_generic_latency == 1) continue;
+    const double t = generic_estimate(mod_bits, batch, lpl);
+    if (t > 0 && (best_t < 0 || t < best_t * 0.999)) { best_t = t; best = lpl; }
   }
-  if (!choose_geometry(mod_bits, narrow, LIMBS_PER_LANE) || !choose_geometry(mod_bits, wide, LIMBS_PER_LANE_WIDE))
-    return LIMBS_PER_LANE;
-  const int64_t waves = (batch * wide.K + 63) / 64;
-  if (groups > 1) return (narrow.K >= 8 && waves >= 4 * 2048) ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
-  return waves >= 2 * 1024 ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
+  return best;
 }
 
 bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t groups, PowmodPlan& p,
