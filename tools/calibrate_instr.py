@@ -18,7 +18,7 @@ for every (L, nblk):
         — matches the dispatches to the configs in launch order, solves the 3x3 system from the first
           three exponents and reports the residual of the held-out fourth (a check of the linear model)
 
-The model is committed as profiles/r03_instr_model.json together with a digest of the kernel sources it was
+The model is committed as profiles/r04_instr_model.json together with a digest of the kernel sources it was
 fitted to; bench.py reads it and refuses it (roofline fraction null, with the reason) when the digest no longer
 matches the sources of the library it runs.  Kinds: "n2" (pair kernel, one wavefront per group), "n2split" (two
 wavefronts per group: the constants are per PAIR of wavefronts), "generic" (fixed-window kernel).
@@ -93,14 +93,17 @@ def run(cfg_path: str) -> None:
     rng = random.Random(20260201)
     configs = []
     for kind in ("n2", "n2split", "generic"):
-        for L in ((3, 9, 18) if kind == "n2split" else (9, 18)):
-            max_nblk = {("n2", 9): 32, ("n2", 18): 16, ("generic", 9): 64, ("generic", 18): 32,
+        for L in ((9, 18) if kind == "n2" else (3, 9, 18)):
+            max_nblk = {("n2", 9): 32, ("n2", 18): 16, ("generic", 3): 64, ("generic", 9): 64, ("generic", 18): 32,
                         ("n2split", 3): 64, ("n2split", 9): 32, ("n2split", 18): 16}[(kind, L)]
             eng.set_wavefronts_per_group(2 if kind == "n2split" else 1)
             for nblk in range(1, max_nblk + 1):
                 bits = W * L * nblk - (4 if L != 3 else 4 + W + 2)          # the head room of mx_host.hpp: choose_geometry
                 if kind == "n2split" and L == 9 and 4 < nblk <= 16:
                     bits = W * L * nblk - (4 + W + 2)      # groups of 8 / 16 lanes: the friendly instances (what key_length 2048 / 4096 run)
+                friendly_1w = kind == "n2" and L == 18 and 2 < nblk <= 8
+                if friendly_1w:
+                    bits = W * L * nblk - (4 + W + 2)      # groups of 4 / 8 lanes: the friendly one-wavefront instances (round 4)
                 if bits < 8:
                     continue
                 k = 1
@@ -115,8 +118,10 @@ def run(cfg_path: str) -> None:
                         n2 = n * n
                         rows = eng.to_device(Lm.pack([rng.randrange(n2) for _ in range(batch)], Lm.limbs_for(n2)))
                         plan = eng.nsquare_plan(n, e)
-                        eng.powmod_nsquare_t(rows, n, e)
-                        configs.append({"kind": kind, "L": L, "nblk": nblk, "K": k, "waves": WAVES,
+                        eng.powmod_nsquare_t(rows, n, e, segments=1)
+                        # a friendly one-wavefront exponentiation is two dispatches of powmod_n2_kernel: the tape on the
+                        # friendly instance, its last product and the epilogue on the plain one
+                        configs.append({"kind": kind, "L": L, "nblk": nblk, "K": k, "waves": WAVES, "dispatches": 2 if friendly_1w else 1,
                                         "n_sqr": int(plan.desc.n_sqr), "n_mul": int(plan.desc.n_mul)})
                     else:
                         assert eng.geometry(bits, batch * 2, 2) == (k, L, W, nblk)
@@ -158,17 +163,22 @@ def fit(cfg_path: str, pmc_dir: str, model_path: str) -> None:
                     else "generic" if "mx::powmod_kernel" in name else None)
             if kind:
                 disp[kind].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), name))
-    model = {"n2": {"9": {}, "18": {}}, "n2split": {"3": {}, "9": {}, "18": {}}, "generic": {"9": {}, "18": {}}, "max_residual": 0.0,
+    model = {"n2": {"9": {}, "18": {}}, "n2split": {"3": {}, "9": {}, "18": {}}, "generic": {"3": {}, "9": {}, "18": {}}, "max_residual": 0.0,
              "kernel_sources_sha256": kernel_sources_digest(), "kernel_sources": KERNEL_SOURCES,
              "source": "tools/calibrate_instr.py: SQ_INSTS_VALU of 4 exponents per (kernel, L, nblk); wave-instructions "
                        "per wavefront (n2split: per pair of wavefronts) = n_sqr*I_sqr + n_mul*I_mul + F"}
     for kind in ("n2", "n2split", "generic"):
         d = sorted(disp[kind])
         cfgs = [c for c in configs if c["kind"] == kind]
-        assert len(d) == len(cfgs), (kind, len(d), len(cfgs))
+        assert len(d) == sum(c.get("dispatches", 1) for c in cfgs), (kind, len(d), len(cfgs))
+        totals, pos = [], 0
+        for c in cfgs:                                    # the dispatches of one exponentiation, summed
+            nd = c.get("dispatches", 1)
+            totals.append(sum(x[1] for x in d[pos : pos + nd]))
+            pos += nd
         for i in range(0, len(cfgs), 4):
             grp = cfgs[i : i + 4]
-            per_wave = [d[i + j][1] / grp[j]["waves"] for j in range(4)]
+            per_wave = [totals[i + j] / grp[j]["waves"] for j in range(4)]
             fit_rows, held = (0, 1, 2), 3
             sol = solve3([[grp[j]["n_sqr"], grp[j]["n_mul"], 1] for j in fit_rows], [per_wave[j] for j in fit_rows])
             pred = sol[0] * grp[held]["n_sqr"] + sol[1] * grp[held]["n_mul"] + sol[2]

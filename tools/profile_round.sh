@@ -2,7 +2,7 @@
 # Runs the bench lines and rocprofv3 passes whose summaries are copied into profiles/ (tools/prof_summary.py,
 # tools/hbm_traffic.py, tools/calibrate_instr.py, tools/sweep_shapes.py).  The library reads no environment; the
 # bench opts into 16 HIP hardware queues itself (protocols.distributed_keygen_amd.configure_hw_queues).
-tag=${1:-r03}
+tag=${1:-r04}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=gpurun_out/prof_$tag; mkdir -p $O
@@ -41,6 +41,12 @@ S="python3 $R/bench.py --no-cpu-baseline --no-extras --streams 1 --limbs-per-lan
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/pmc_c3_sq -- $S > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_c3_fetch -- $S > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_c3_write -- $S > /dev/null 2>&1
+# ---- where the issue slots of a SATURATED launch go (32 768 ciphertexts = two wavefronts per SIMD of the headline kernel):
+# instruction-issue and wait counters in two passes
+SAT="python3 $R/bench.py --no-cpu-baseline --no-extras --streams 1 --limbs-per-lane 18 --wavefronts-per-group 1 --segments 1 --batch 32768 --steps 3 --warmup 1"
+rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY --kernel-trace --output-format csv -d $R/$O/pmc_sat_a -- $SAT > /dev/null 2>&1
+rocprofv3 --pmc SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_INSTS_SALU SQ_INST_CYCLES_SALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_LDS_BANK_CONFLICT --kernel-trace --output-format csv -d $R/$O/pmc_sat_b -- $SAT > /dev/null 2>&1
+rocprofv3 --pmc SQ_THREAD_CYCLES_VALU SQ_IFETCH SQ_INSTS_VMEM SQ_ACTIVE_INST_VMEM SQ_INSTS_BRANCH SQ_BUSY_CU_CYCLES GRBM_GUI_ACTIVE SQ_INSTS_VALU_INT64 --kernel-trace --output-format csv -d $R/$O/pmc_sat_c -- $SAT > /dev/null 2>&1
 S2="python3 $R/bench.py --no-cpu-baseline --no-extras --streams 1 --segments 1 --steps 6 --warmup 2"
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_LDS SQ_INSTS_SALU SQ_WAIT_INST_ANY GRBM_GUI_ACTIVE --kernel-trace --output-format csv -d $R/$O/pmc_split_sq -- $S2 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_split_fetch -- $S2 > /dev/null 2>&1
@@ -54,17 +60,18 @@ rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $R/
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_c5_fetch -- $C5 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_c5_write -- $C5 > /dev/null 2>&1
 cd $R
-python tools/hbm_traffic.py n2_k2048_b10000_L18 "powmod_n2_kernel" $O/pmc_c3_fetch $O/pmc_c3_write 6 > /dev/null
+python tools/hbm_traffic.py n2_k2048_b10000_L18 "powmod_n2_kernel" $O/pmc_c3_fetch $O/pmc_c3_write 6 2 > /dev/null
 python tools/hbm_traffic.py n2_k2048_b10000_L9 "powmod_n2_split_kernel" $O/pmc_split_fetch $O/pmc_split_write 6 > /dev/null
 python tools/hbm_traffic.py biprime_b2053_c4096_L18 "mx::powmod_kernel" $O/pmc_biprime_fetch $O/pmc_biprime_write 3 > /dev/null
-python tools/hbm_traffic.py n2_k4096_b4096_L18 "powmod_n2_kernel" $O/pmc_c5_fetch $O/pmc_c5_write 3 > /dev/null
+python tools/hbm_traffic.py n2_k4096_b4096_L18 "powmod_n2_kernel" $O/pmc_c5_fetch $O/pmc_c5_write 3 2 > /dev/null
 cp profiles/${tag}_hbm_traffic.json $O/
 python tools/prof_summary.py $O/summary_driver_flags.txt $O/trace_driver_flags > /dev/null
 python tools/prof_summary.py $O/summary_single_batch.txt $O/trace_single_batch $O/pmc_split_sq $O/pmc_split_fetch $O/pmc_split_write > /dev/null
 python tools/prof_summary.py $O/summary_biprime.txt $O/trace_biprime $O/pmc_biprime_sq $O/pmc_biprime_fetch $O/pmc_biprime_write > /dev/null
 python tools/prof_summary.py $O/summary_c5.txt $O/trace_c5 $O/pmc_c5_sq $O/pmc_c5_fetch $O/pmc_c5_write > /dev/null
 python tools/prof_summary.py $O/summary_c3_single_stream_counters.txt $O/pmc_c3_sq $O/pmc_c3_sq $O/pmc_c3_fetch $O/pmc_c3_write > /dev/null
+python tools/prof_summary.py $O/summary_c3_saturated_issue_counters.txt $O/pmc_sat_a $O/pmc_sat_a $O/pmc_sat_b $O/pmc_sat_c > /dev/null
 for f in trace_driver_flags trace_single_batch trace_biprime trace_c5; do cp $(find $O/$f -name "*_kernel_stats.csv" | head -1) $O/${f}_kernel_stats.csv; done
-for f in pmc_c3_sq pmc_split_sq; do g=$(find $O/$f -name "*counter_collection.csv" | head -1); [ -n "$g" ] && gzip -c $g > $O/${f}_raw_counters.csv.gz; done
+for f in pmc_c3_sq pmc_split_sq pmc_sat_a pmc_sat_b pmc_sat_c; do g=$(find $O/$f -name "*counter_collection.csv" | head -1); [ -n "$g" ] && gzip -c $g > $O/${f}_raw_counters.csv.gz; done
 rm -rf $O/trace_*/ $O/pmc_*/
 ls $O | wc -l
