@@ -287,12 +287,14 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
  * segment): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
  * workgroups per CU (r = 1..3).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
  * friendly-modulus instances (A/B runs against the plain ones).  MX_KNOB_GENERIC_LATENCY: 1 = the automatic geometry of
- * the generic-modulus modexp never takes the 3-limb latency instances.  Process-wide; returns MX_OK / MX_ERR_ARG. */
+ * the generic-modulus modexp never takes the 3-limb latency instances.  MX_KNOB_N2_SPLIT: mx_nsquare_launch_split
+ * 1 = never reports a split, 2 = whenever one exists.  Process-wide; returns MX_OK / MX_ERR_ARG. */
 #define MX_KNOB_N2_SEGMENTS 1
 #define MX_KNOB_JACOBI_MAX_BATCHES 2
 #define MX_KNOB_N2_TIMESLICE 3
 #define MX_KNOB_N2_FRIENDLY_1W 4
 #define MX_KNOB_GENERIC_LATENCY 5
+#define MX_KNOB_N2_SPLIT 6
 int mx_debug_knob(int knob, int value);
 /* Enqueues a kernel of ONE wavefront that idles for `microseconds` (0..1 000 000) on `stream` and touches no
  * memory.  A concurrency probe: two streams that the HIP runtime has mapped to the same hardware queue run
@@ -355,6 +357,14 @@ int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs_per_lane, 
 int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                                int* lanes_per_element, int* limbs_per_lane_out, int* wavefronts_per_group_out,
                                int* friendly, int* timesliced);
+/* For callers that own a second stream: whether ONE batch is better run as two launches side by side — the first
+ * *first_rows elements in the shape (*first_lpl, *first_wpg), the rest in (*rest_lpl, *rest_wpg) on another stream at the
+ * same time (each with its own workspace; mx_powmod_nsquare_run with explicit shapes).  *first_rows = 0: no split.
+ * Reported just above the capacity of the wide two-wavefront shape (one workgroup per CU: 8192 ciphertexts at key_length
+ * 2048): 10 000 then take ~40 ms instead of 47-59 in any single launch.  The library itself never uses a stream the
+ * caller did not pass; protocols/distributed_keygen_amd/engine.py follows this hint for lone launches. */
+int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first_rows, int* first_lpl, int* first_wpg,
+                            int* rest_lpl, int* rest_wpg);
 int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* lanes_per_element,
                            int* limbs_per_lane_out, int* limb_bits, int* blocks);
 

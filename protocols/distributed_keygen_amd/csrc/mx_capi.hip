@@ -20,6 +20,7 @@ int g_knob_n2_segments = 0;
 int g_knob_n2_timeslice = 0;
 int g_knob_n2_friendly_1w = 0;
 int g_knob_generic_latency = 0;
+int g_knob_n2_split = 0;
 int g_knob_jacobi_max_batches = 0;
 }
 MxProfile g_mx_profile;
@@ -275,7 +276,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 302; }
+int mx_version(void) { return 303; }
 
 const char* mx_error_string(int code) {
   switch (code) {
@@ -305,6 +306,7 @@ int mx_debug_knob(int knob, int value) {
     case MX_KNOB_JACOBI_MAX_BATCHES: g_knob_jacobi_max_batches = value; return MX_OK;
     case MX_KNOB_N2_FRIENDLY_1W: if (value > 1) return MX_ERR_ARG; g_knob_n2_friendly_1w = value; return MX_OK;
     case MX_KNOB_GENERIC_LATENCY: if (value > 1) return MX_ERR_ARG; g_knob_generic_latency = value; return MX_OK;
+    case MX_KNOB_N2_SPLIT: if (value > 2) return MX_ERR_ARG; g_knob_n2_split = value; return MX_OK;
   }
   return MX_ERR_ARG;
 }

@@ -297,6 +297,33 @@ extern "C" int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_p
   return MX_OK;
 }
 
+// A lone launch just above a capacity step of the wide two-wavefront shape (one workgroup of 2 x 64/K elements per CU:
+// 8192 ciphertexts at key_length 2048) pays for a second workgroup per CU on a few CUs: 59 ms for 10 000 instead of 32
+// for 8192.  A caller that owns a second stream can do better: the first `cap` elements in that shape, the rest at 9 limbs
+// per lane on two wavefronts AT THE SAME TIME — a 9-limb workgroup (168 registers per wavefront) fits beside the 18-limb
+// one (256) on a CU but not beside another 9-limb one, so the dispatcher spreads the remainder one workgroup per CU, and
+// those CUs finish in ~1.25-1.45 of the time of the others (measured: tools/sweep_split.py, profiles/r04_split_launch.txt).
+// Reported when it beats every single-launch shape by the estimate: remainder workgroups <= MX_SPLIT_MAX_SHARE of the CUs.
+constexpr double MX_SPLIT_MAX_SHARE = 0.62;
+extern "C" int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first_rows, int* first_lpl, int* first_wpg,
+                                       int* rest_lpl, int* rest_wpg) {
+  if (!first_rows || !first_lpl || !first_wpg || !rest_lpl || !rest_wpg || batch <= 0) return MX_ERR_ARG;
+  *first_rows = 0; *first_lpl = *first_wpg = *rest_lpl = *rest_wpg = 0;
+  if (g_knob_n2_split == 1) return MX_OK;
+  N2Shape wide, narrow;
+  if (!shape_n2(n_bits, 1, batch, LIMBS_PER_LANE_WIDE, 2, wide) || !shape_n2(n_bits, 1, batch, LIMBS_PER_LANE, 2, narrow)) return MX_OK;
+  const int cus = device_cus();
+  const int64_t per_wg_wide = (int64_t)mx::N2_SPLIT_PAIRS * (64 / wide.geo.K), per_wg_narrow = (int64_t)mx::N2_SPLIT_PAIRS * (64 / narrow.geo.K);
+  const int64_t cap = (int64_t)cus * per_wg_wide;
+  if (batch <= cap || batch >= 2 * cap) return MX_OK;
+  const int64_t rest = batch - cap;
+  const int64_t rest_wgs = (rest + per_wg_narrow - 1) / per_wg_narrow;
+  if ((double)rest_wgs > MX_SPLIT_MAX_SHARE * cus && g_knob_n2_split != 2) return MX_OK;
+  if (rest_wgs > cus) return MX_OK;
+  *first_rows = cap; *first_lpl = LIMBS_PER_LANE_WIDE; *first_wpg = 2; *rest_lpl = LIMBS_PER_LANE; *rest_wpg = 2;
+  return MX_OK;
+}
+
 extern "C" int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_lane, int* k, int* l, int* w,
                                        int* blocks) {
   int waves = 0;

@@ -202,6 +202,7 @@ extern int g_limbs_per_lane;
 extern int g_knob_n2_segments;        // MX_KNOB_N2_SEGMENTS: 0 = automatic
 extern int g_knob_n2_timeslice;       // MX_KNOB_N2_TIMESLICE: 0 = automatic, 1 = never, 2 = always (two-wavefront launches)
 extern int g_knob_n2_friendly_1w;     // MX_KNOB_N2_FRIENDLY_1W: 0 = friendly-modulus instances of the one-wavefront wide kernel where they exist, 1 = never
+extern int g_knob_n2_split;           // MX_KNOB_N2_SPLIT: 0 = mx_nsquare_launch_split reports a split where it pays, 1 = never, 2 = whenever a split exists
 extern int g_knob_generic_latency;    // MX_KNOB_GENERIC_LATENCY: 0 = the automatic choice may take the 3-limb instances of the generic kernel, 1 = never
 extern int g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
 inline int override_limbs_per_lane() {

@@ -130,6 +130,7 @@ class Engine:
         self.last_timing: Optional[Dict[str, Any]] = None   # host/GPU time split of the last int-level modexp batch
         self._priority_aux = False             # small kernels on a high-priority companion stream (set_priority_aux)
         self._aux: Dict[int, Any] = {}         # stream -> its companion
+        self._split_streams: Dict[int, Any] = {}   # stream -> the companion that runs the second part of a split launch
 
     # ------------------------------------------------------------------ plumbing
     def _stream_ptr(self) -> int:
@@ -243,7 +244,7 @@ class Engine:
     def debug_knob(self, knob: str, value: int) -> None:
         """Developer overrides of the library (include/mxpaillier.h: mx_debug_knob; process-wide, 0 restores
         the default): "n2_segments", "jacobi_max_batches", "n2_timeslice" (1 never, 2 always), "n2_friendly_1w" (1 never)."""
-        ids = {"n2_segments": 1, "jacobi_max_batches": 2, "n2_timeslice": 3, "n2_friendly_1w": 4, "generic_latency": 5}
+        ids = {"n2_segments": 1, "jacobi_max_batches": 2, "n2_timeslice": 3, "n2_friendly_1w": 4, "generic_latency": 5, "n2_split": 6}
         _lib.check(self.lib.mx_debug_knob(ids[knob], int(value)), "mx_debug_knob")
 
     def cu_slice_streams(self, n: int) -> List[Any]:
@@ -327,6 +328,19 @@ class Engine:
                 return (18, 1)
         _, l_, _, _, w_ = self.nsquare_launch_shape(n_bits, total)
         return (self._lpl or l_, self._wpg or w_)
+
+    def nsquare_launch_split(self, n_bits: int, batch: int) -> Optional[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
+        """(rows of the first launch, its shape, the shape of the rest) when ONE powmod_nsquare batch of this size is
+        better run as two launches side by side (mx_nsquare_launch_split) and this engine's settings leave the choice to
+        the library; None otherwise."""
+        import ctypes
+
+        if self._lpl or self._wpg:
+            return None
+        first = ctypes.c_int64()
+        a, b, c, d = (ctypes.c_int() for _ in range(4))
+        _lib.check(self.lib.mx_nsquare_launch_split(n_bits, batch, first, a, b, c, d), "mx_nsquare_launch_split")
+        return (int(first.value), (a.value, b.value), (c.value, d.value)) if first.value else None
 
     def nsquare_launch_timesliced(self, n_bits: int, batch: int) -> Tuple[int, int]:
         """(resident workgroups per CU, units per group) when a powmod_nsquare launch of `batch` elements with this
@@ -492,6 +506,23 @@ class Engine:
         plan = self.nsquare_plan(n, exp)
         if out_t is None:
             out_t = self.torch.empty_like(bases_t)
+        split = self.nsquare_launch_split(n.bit_length(), batch) if shape is None and bases_t.is_contiguous() and out_t.is_contiguous() else None
+        if split is not None:
+            # one batch just above a capacity step of the wide two-wavefront shape: the part that fills the CUs once in
+            # that shape on this stream, the rest at 9 limbs per lane on a companion stream at the same time
+            first, shape_a, shape_b = split
+            torch = self.torch
+            cur = torch.cuda.current_stream(self.device)
+            side = self._split_streams.get(int(cur.cuda_stream))
+            if side is None:
+                with torch.cuda.device(self.device):
+                    side = self._split_streams[int(cur.cuda_stream)] = torch.cuda.Stream(device=self.device)
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                self.powmod_nsquare_t(bases_t[first:], n, exp, out_t=out_t[first:], segments=1, shape=shape_b)
+            self.powmod_nsquare_t(bases_t[:first], n, exp, out_t=out_t[:first], segments=1, shape=shape_a)
+            cur.wait_stream(side)
+            return out_t
         with self.torch.cuda.device(self.device):
             self._use_plan(plan)
             ws = self._workspace(self.lib.mx_powmod_nsquare_run_workspace_bytes(plan.desc, batch))

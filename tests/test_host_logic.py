@@ -30,8 +30,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(lib, name)
     # ABI 3.0: mx_powmod_nsquare_run gained wavefronts_per_group, mx_nsquare_plan.geometries; 3.1: mx_nsquare_launch_timesliced;
-    # 3.2: mx_nsquare_launch_instance, MX_KNOB_N2_FRIENDLY_1W
-    assert lib.mx_version() == 302
+    # 3.2: mx_nsquare_launch_instance, MX_KNOB_N2_FRIENDLY_1W; 3.3: limbs_per_lane 3 for the generic kernel,
+    # mx_nsquare_launch_split, MX_KNOB_GENERIC_LATENCY / MX_KNOB_N2_SPLIT
+    assert lib.mx_version() == 303
     assert lib.mx_error_string(-3).decode().startswith("modulus")
 
 

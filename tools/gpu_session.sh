@@ -70,6 +70,9 @@ for step in "$@"; do
     census --queues 16 --label "shipped time-sliced, second process" --shape 9,2 --timeslice 2 --reps 2
     grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
     ;;
+  sweep_split)
+    python tools/sweep_split.py 2048 4096 > $O/sweep_split.txt 2>&1; tail -40 $O/sweep_split.txt
+    ;;
   sweep_generic)
     python tools/sweep_generic.py 1024 2048 > $O/sweep_generic.txt 2>&1; cat $O/sweep_generic.txt | tail -80
     ;;
