@@ -360,8 +360,9 @@ int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, in
 /* For callers that own a second stream: whether ONE batch is better run as two launches side by side — the first
  * *first_rows elements in the shape (*first_lpl, *first_wpg), the rest in (*rest_lpl, *rest_wpg) on another stream at the
  * same time (each with its own workspace; mx_powmod_nsquare_run with explicit shapes).  *first_rows = 0: no split.
- * Reported just above the capacity of the wide two-wavefront shape (one workgroup per CU: 8192 ciphertexts at key_length
- * 2048): 10 000 then take ~40 ms instead of 47-59 in any single launch.  The library itself never uses a stream the
+ * Reported above the capacity of the wide two-wavefront shape (one workgroup per CU: 8192 ciphertexts at key_length
+ * 2048) where no single launch is as fast: 10 752 .. 12 288 ciphertexts (48.5 instead of 51-56 ms; below that the
+ * time-sliced single launch is at least as good).  The library itself never uses a stream the
  * caller did not pass; protocols/distributed_keygen_amd/engine.py follows this hint for lone launches. */
 int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first_rows, int* first_lpl, int* first_wpg,
                             int* rest_lpl, int* rest_wpg);

@@ -693,10 +693,16 @@ namespace {
 template <int NL>
 int launch_jacobi(const mx::JacobiArgs& a, hipStream_t s) {
   int64_t nblocks = a.skip ? (a.count / a.per_group) * ((a.per_group + 63) / 64) : (a.count + 63) / 64;
-  hipLaunchKernelGGL((mx::jacobi_kernel<NL>), dim3((unsigned)nblocks), dim3(64), 0, s, a);
+  // dynamic LDS: 0 except for the 257-word instance, whose top limbs live there (mx_jacobi.hpp)
+  hipLaunchKernelGGL((mx::jacobi_kernel<NL>), dim3((unsigned)nblocks), dim3(64), mx::jacobi_lds_bytes<NL>(), s, a);
   MX_HIP(hipGetLastError());
   // safety net for symbols the divstep kernel did not finish within its batch bound (mx_jacobi.hpp)
-  hipLaunchKernelGGL((mx::jacobi_fallback_kernel<NL>), dim3((unsigned)nblocks), dim3(64), 0, s, a);
+  constexpr size_t lds_fb = mx::jacobi_lds_bytes<NL, true>();
+  if constexpr (lds_fb > 64 * 1024) {
+    static bool allowed[MX_MAX_DEVICES] = {};
+    MX_HIP(mx_allow_dynamic_lds(reinterpret_cast<const void*>(&mx::jacobi_fallback_kernel<NL>), (int)lds_fb, allowed));
+  }
+  hipLaunchKernelGGL((mx::jacobi_fallback_kernel<NL>), dim3((unsigned)nblocks), dim3(64), lds_fb, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
 }
@@ -727,8 +733,8 @@ extern "C" int mx_jacobi_dev_range(const uint32_t* d_values, int8_t* d_out, cons
   if (limbs <= 33) return launch_jacobi<33>(a, s);
   if (limbs <= 65) return launch_jacobi<65>(a, s);
   if (limbs <= 129) return launch_jacobi<129>(a, s);
-  // key_length 8192 (the widest modulus the modexp kernels take for N^2): operands no longer fit the register file
-  // (512 VGPRs + scratch, one wavefront per SIMD) — slower per symbol, still a rounding error beside 8200-bit modexps
+  // key_length 8192 (the widest modulus the modexp kernels take for N^2): operands no longer fit the register file —
+  // the limbs from 192 upwards live in LDS (mx_jacobi.hpp: jacobi_reg_limbs; one wavefront per SIMD, no scratch)
   return launch_jacobi<257>(a, s);
 }
 

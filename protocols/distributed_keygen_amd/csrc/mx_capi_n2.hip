@@ -297,14 +297,17 @@ extern "C" int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_p
   return MX_OK;
 }
 
-// A lone launch just above a capacity step of the wide two-wavefront shape (one workgroup of 2 x 64/K elements per CU:
-// 8192 ciphertexts at key_length 2048) pays for a second workgroup per CU on a few CUs: 59 ms for 10 000 instead of 32
-// for 8192.  A caller that owns a second stream can do better: the first `cap` elements in that shape, the rest at 9 limbs
+// A lone launch above a capacity step of the wide two-wavefront shape (one workgroup of 2 x 64/K elements per CU: 8192
+// ciphertexts at key_length 2048) pays for a second workgroup per CU: 55-59 ms for 10 000-12 288 instead of 33 for 8192.
+// A caller that owns a second stream has one more option: the first `cap` elements in that shape, the rest at 9 limbs
 // per lane on two wavefronts AT THE SAME TIME — a 9-limb workgroup (168 registers per wavefront) fits beside the 18-limb
-// one (256) on a CU but not beside another 9-limb one, so the dispatcher spreads the remainder one workgroup per CU, and
-// those CUs finish in ~1.25-1.45 of the time of the others (measured: tools/sweep_split.py, profiles/r04_split_launch.txt).
-// Reported when it beats every single-launch shape by the estimate: remainder workgroups <= MX_SPLIT_MAX_SHARE of the CUs.
-constexpr double MX_SPLIT_MAX_SHARE = 0.62;
+// one (256) on a CU but not beside another 9-limb one, so the dispatcher spreads the remainder one workgroup per CU.
+// Measured (tools/sweep_split.py, profiles/r04_split_launch.txt): a CU that hosts both takes 48-49 ms whatever the
+// share of such CUs — the two wavefronts of a SIMD add up almost fully (a lone wavefront already issues 83 % of what
+// its SIMD can) — so the split only beats the single launches where those take longer: above the range the time-sliced
+// form covers (44-48 ms up to 10 500), i.e. when the remainder needs more than MX_SPLIT_MIN_SHARE of the CUs: 10 752 ..
+// 12 288 ciphertexts at key_length 2048 (48.5 instead of 51-56 ms), 5376 .. 6144 at 4096 (182 instead of 191-196).
+constexpr double MX_SPLIT_MIN_SHARE = 0.62;
 extern "C" int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first_rows, int* first_lpl, int* first_wpg,
                                        int* rest_lpl, int* rest_wpg) {
   if (!first_rows || !first_lpl || !first_wpg || !rest_lpl || !rest_wpg || batch <= 0) return MX_ERR_ARG;
@@ -318,7 +321,7 @@ extern "C" int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first
   if (batch <= cap || batch >= 2 * cap) return MX_OK;
   const int64_t rest = batch - cap;
   const int64_t rest_wgs = (rest + per_wg_narrow - 1) / per_wg_narrow;
-  if ((double)rest_wgs > MX_SPLIT_MAX_SHARE * cus && g_knob_n2_split != 2) return MX_OK;
+  if ((double)rest_wgs <= MX_SPLIT_MIN_SHARE * cus && g_knob_n2_split != 2) return MX_OK;
   if (rest_wgs > cus) return MX_OK;
   *first_rows = cap; *first_lpl = LIMBS_PER_LANE_WIDE; *first_wpg = 2; *rest_lpl = LIMBS_PER_LANE; *rest_wpg = 2;
   return MX_OK;

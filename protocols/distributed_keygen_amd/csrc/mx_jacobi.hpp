@@ -3,7 +3,7 @@
 //
 // Unlike the Montgomery kernels this is a gcd-type algorithm, so the layout is different: ONE THREAD
 // PER SYMBOL, both operands in registers as NL radix-2^32 limbs (fully unrolled limb loops,
-// compile-time indices only).  The algorithm is the division-step ("divstep") form of the binary
+// compile-time indices only; the top limbs of the 257-word instance in LDS, see jacobi_reg_limbs).  The algorithm is the division-step ("divstep") form of the binary
 // Euclidean algorithm in its all-positive variant, in batches of 30 steps:
 //   * 30 divsteps are decided from the LOW 64 bits of (f, g) alone (f = N, g = the value): strip the
 //     trailing zeros of g; when the step counter eta turns negative swap f and g; add the multiple w
@@ -46,6 +46,14 @@ struct JacobiArgs {
 // Limbs are processed in chunks of JC; chunks above the highest limb that is non-zero in ANY lane of
 // the wavefront (for f or g) are skipped with a wave-uniform branch.  Both operands shrink steadily,
 // so on average about half of the chunks are live; `live` is refreshed every JREFRESH batches.
+// Where the limbs of the two operands live: in registers — except for the 257-word instance (key_length 8192), whose
+// 2 x 257 words per lane exceed the 512 registers of a lane.  Its limbs from JREG upwards live in LDS, one column per
+// lane ([limb][lane]: conflict-free), 33 KB per wavefront; the operands shrink from the top, so after the first quarter
+// of the batches those limbs are no longer touched (`live`).  Round 3 shipped this instance on 204 B / 1848 B of scratch.
+// (The safety-net kernel keeps fewer limbs in registers: its subtract-with-borrow chains need more temporaries.)
+template <int NL, bool FALLBACK = false> constexpr int jacobi_reg_limbs() { return NL <= 129 ? NL : FALLBACK ? 128 : 192; }
+template <int NL, bool FALLBACK = false> constexpr size_t jacobi_lds_bytes() { return (size_t)2 * (NL - jacobi_reg_limbs<NL, FALLBACK>()) * 64 * 4; }
+
 constexpr int JC = 8;
 constexpr int JREFRESH = 4;
 constexpr int JSTEPS = 30;      // divsteps per batch
@@ -72,20 +80,29 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
   }
   const uint32_t* pa = A.a + row * A.limbs;
   const uint32_t* pn = A.mods + grp * A.limbs;
-  uint32_t f[NL], g[NL];
+  constexpr int JREG = jacobi_reg_limbs<NL>();
+  extern __shared__ uint32_t jlds[];
+  uint32_t* const lf = jlds + threadIdx.x;                 // this lane's column of the limbs >= JREG of f, then of g
+  uint32_t* const lg = lf + (NL - JREG) * 64;
+  uint32_t f[JREG], g[JREG];
+  // (the index is a compile-time constant wherever these are used: the limb loops are fully unrolled)
+  auto F = [&](int j) -> uint32_t { return j < JREG ? f[j < JREG ? j : 0] : lf[(j - JREG) * 64]; };
+  auto G = [&](int j) -> uint32_t { return j < JREG ? g[j < JREG ? j : 0] : lg[(j - JREG) * 64]; };
+  auto setF = [&](int j, uint32_t v) { if (j < JREG) f[j < JREG ? j : 0] = v; else lf[(j - JREG) * 64] = v; };
+  auto setG = [&](int j, uint32_t v) { if (j < JREG) g[j < JREG ? j : 0] = v; else lg[(j - JREG) * 64] = v; };
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    g[j] = j < A.limbs ? pa[j] : 0u;
-    f[j] = j < A.limbs ? pn[j] : 0u;
+    setG(j, j < A.limbs ? pa[j] : 0u);
+    setF(j, j < A.limbs ? pn[j] : 0u);
   }
   int result = 0;
   bool done;
   {
     uint32_t gz = 0, fhi = 0;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) gz |= g[j];
+    for (int j = 0; j < NL; ++j) gz |= G(j);
 #pragma unroll
-    for (int j = 1; j < NL; ++j) fhi |= f[j];
+    for (int j = 1; j < NL; ++j) fhi |= F(j);
     const bool f_is_one = fhi == 0 && f[0] == 1u;
     // (x / 1) = 1; (0 / N) = 0 for N > 1; an even "modulus" is not a Jacobi symbol: reported as 0
     done = f_is_one || gz == 0 || !(f[0] & 1u);
@@ -104,7 +121,7 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
     if ((batch % JREFRESH) == 0) {
       int top = 0;           // 1 + index of this lane's highest non-zero limb of f | g
 #pragma unroll
-      for (int j = 0; j < NL; ++j) top = (f[j] | g[j]) ? j + 1 : top;
+      for (int j = 0; j < NL; ++j) top = (F(j) | G(j)) ? j + 1 : top;
       if (done) top = 0;
       for (int off = 32; off > 0; off >>= 1) top = max(top, __shfl_xor(top, off));
       live = __builtin_amdgcn_readfirstlane((top + JC - 1) / JC);
@@ -157,24 +174,25 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
         if (c < live) {
 #pragma unroll
           for (int j = c * JC; j < (c + 1) * JC && j < NL; ++j) {
-            const unsigned long long af = (unsigned long long)u * f[j] + (unsigned long long)v * g[j] + cf;
-            const unsigned long long ag = (unsigned long long)q * f[j] + (unsigned long long)r * g[j] + cg;
-            const uint32_t lf = (uint32_t)af, lg = (uint32_t)ag;
+            const uint32_t fj = F(j), gj = G(j);
+            const unsigned long long af = (unsigned long long)u * fj + (unsigned long long)v * gj + cf;
+            const unsigned long long ag = (unsigned long long)q * fj + (unsigned long long)r * gj + cg;
+            const uint32_t lowf = (uint32_t)af, lowg = (uint32_t)ag;
             cf = af >> 32;
             cg = ag >> 32;
             if (j > 0) {
-              f[j - 1] = __builtin_amdgcn_alignbit(lf, pf, JSTEPS);
-              g[j - 1] = __builtin_amdgcn_alignbit(lg, pg, JSTEPS);
+              setF(j - 1, __builtin_amdgcn_alignbit(lowf, pf, JSTEPS));
+              setG(j - 1, __builtin_amdgcn_alignbit(lowg, pg, JSTEPS));
             }
-            pf = lf;
-            pg = lg;
+            pf = lowf;
+            pg = lowg;
           }
           // the top limb of the last live chunk receives the final carries (everything above is zero in
           // every lane of the wavefront, and f', g' <= max(f, g) fit below it)
           if (c == live - 1) {
             const int jend = ((c + 1) * JC < NL ? (c + 1) * JC : NL) - 1;      // compile-time per chunk
-            f[jend] = __builtin_amdgcn_alignbit((uint32_t)cf, pf, JSTEPS);
-            g[jend] = __builtin_amdgcn_alignbit((uint32_t)cg, pg, JSTEPS);
+            setF(jend, __builtin_amdgcn_alignbit((uint32_t)cf, pf, JSTEPS));
+            setG(jend, __builtin_amdgcn_alignbit((uint32_t)cg, pg, JSTEPS));
           }
         }
       }
@@ -185,8 +203,9 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
         if (c < live) {
 #pragma unroll
           for (int j = c * JC; j < (c + 1) * JC && j < NL; ++j) {
-            if (j > 0) { fhi |= f[j]; ghi |= g[j]; }
-            diff |= f[j] ^ g[j];
+            const uint32_t fj = F(j), gj = G(j);
+            if (j > 0) { fhi |= fj; ghi |= gj; }
+            diff |= fj ^ gj;
           }
         }
       }
@@ -232,54 +251,62 @@ __global__ void __launch_bounds__(64) jacobi_fallback_kernel(JacobiArgs A) {
   if (!__any(todo)) return;
   const uint32_t* pa = A.a + row * A.limbs;
   const uint32_t* pn = A.mods + grp * A.limbs;
-  uint32_t a[NL], n[NL];
+  constexpr int JREG = jacobi_reg_limbs<NL, true>();
+  extern __shared__ uint32_t jlds[];
+  uint32_t* const la = jlds + threadIdx.x;                 // limbs >= JREG of a, then of n (see jacobi_reg_limbs)
+  uint32_t* const ln = la + (NL - JREG) * 64;
+  uint32_t a[JREG], n[JREG];
+  auto AA = [&](int j) -> uint32_t { return j < JREG ? a[j < JREG ? j : 0] : la[(j - JREG) * 64]; };
+  auto NN = [&](int j) -> uint32_t { return j < JREG ? n[j < JREG ? j : 0] : ln[(j - JREG) * 64]; };
+  auto setA = [&](int j, uint32_t v) { if (j < JREG) a[j < JREG ? j : 0] = v; else la[(j - JREG) * 64] = v; };
+  auto setN = [&](int j, uint32_t v) { if (j < JREG) n[j < JREG ? j : 0] = v; else ln[(j - JREG) * 64] = v; };
 #pragma unroll
   for (int j = 0; j < NL; ++j) {
-    a[j] = j < A.limbs ? pa[j] : 0u;
-    n[j] = j < A.limbs ? pn[j] : 0u;
+    setA(j, j < A.limbs ? pa[j] : 0u);
+    setN(j, j < A.limbs ? pn[j] : 0u);
   }
   int t = 1;
   for (int pass = 0; pass < 64 * NL + 2; ++pass) {
     uint32_t nz = 0;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) nz |= a[j];
+    for (int j = 0; j < NL; ++j) nz |= AA(j);
     const bool active = todo && nz != 0;
     if (!__any(active)) break;
     if (!active) continue;
     while (a[0] == 0) {            // a != 0, so this terminates; 32 zero bits: even count, no sign change
 #pragma unroll
-      for (int j = 0; j < NL - 1; ++j) a[j] = a[j + 1];
-      a[NL - 1] = 0;
+      for (int j = 0; j < NL - 1; ++j) setA(j, AA(j + 1));
+      setA(NL - 1, 0);
     }
     const int z = __builtin_ctz(a[0]);
     if (z) {
 #pragma unroll
-      for (int j = 0; j < NL; ++j) a[j] = (j + 1 < NL) ? __builtin_amdgcn_alignbit(a[j + 1], a[j], z) : (a[j] >> z);
+      for (int j = 0; j < NL; ++j) setA(j, (j + 1 < NL) ? __builtin_amdgcn_alignbit(AA(j + 1), AA(j), z) : (AA(j) >> z));
       const uint32_t n8 = n[0] & 7u;
       if ((z & 1) && (n8 == 3u || n8 == 5u)) t = -t;
     }
     unsigned int borrow = 0;
 #pragma unroll
-    for (int j = 0; j < NL; ++j) (void)__builtin_subc(a[j], n[j], borrow, &borrow);
+    for (int j = 0; j < NL; ++j) (void)__builtin_subc(AA(j), NN(j), borrow, &borrow);
     unsigned int b = 0;
     if (borrow) {                  // (a, n) <- (n - a, a), quadratic reciprocity for the swap
       if ((a[0] & 3u) == 3u && (n[0] & 3u) == 3u) t = -t;
 #pragma unroll
       for (int j = 0; j < NL; ++j) {
-        const uint32_t x = a[j];
-        a[j] = __builtin_subc(n[j], x, b, &b);
-        n[j] = x;
+        const uint32_t x = AA(j);
+        setA(j, __builtin_subc(NN(j), x, b, &b));
+        setN(j, x);
       }
     } else {
 #pragma unroll
-      for (int j = 0; j < NL; ++j) a[j] = __builtin_subc(a[j], n[j], b, &b);
+      for (int j = 0; j < NL; ++j) setA(j, __builtin_subc(AA(j), NN(j), b, &b));
     }
   }
   uint32_t hi = 0, az = 0;
 #pragma unroll
-  for (int j = 1; j < NL; ++j) hi |= n[j];
+  for (int j = 1; j < NL; ++j) hi |= NN(j);
 #pragma unroll
-  for (int j = 0; j < NL; ++j) az |= a[j];
+  for (int j = 0; j < NL; ++j) az |= AA(j);
   if (todo) A.out[row] = (signed char)((az == 0 && hi == 0 && n[0] == 1u) ? t : 0);
 }
 

@@ -305,3 +305,41 @@ def test_exponent_with_a_very_long_run_of_zero_bits(eng):
         assert eng.powmod_batch(bases, e, mod) == [pow(b, e, mod) for b in bases], e.bit_length()
         nb = [b % (n * n) for b in bases]
         assert eng.powmod_nsquare_batch(nb, e, n) == [pow(b, e, n * n) for b in nb], e.bit_length()
+
+
+def test_powmod_nsquare_split_launch_is_bit_identical(eng):
+    """One batch above the capacity of the wide two-wavefront shape runs as two launches side by side on the engine's
+    companion stream (mx_nsquare_launch_split): same rows as the single launch and as pow(), for the automatic range and
+    with the split forced on a ragged remainder; explicit shapes never split."""
+    import torch
+
+    from protocols.distributed_keygen_amd import limbs as L, synthetic
+
+    key = synthetic.make_key(2048, 3, 1)
+    n, n2 = key.n, key.n_square
+    e = (1 << 70) + 12345
+    eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
+    try:
+        assert eng.nsquare_launch_split(n.bit_length(), 8192) is None and eng.nsquare_launch_split(n.bit_length(), 10000) is None
+        assert eng.nsquare_launch_split(n.bit_length(), 11264) == (8192, (18, 2), (9, 2))
+        for batch, knob in ((11264, 0), (8192 + 333, 2)):
+            cts = synthetic.random_ciphertexts(key, batch, seed=batch)
+            rows = eng.to_device(L.pack(cts, L.limbs_for(n2)))
+            eng.debug_knob("n2_split", knob)
+            assert eng.nsquare_launch_split(n.bit_length(), batch) is not None
+            got = eng.powmod_nsquare_t(rows, n, e)
+            eng.debug_knob("n2_split", 1)
+            assert eng.nsquare_launch_split(n.bit_length(), batch) is None
+            single = eng.powmod_nsquare_t(rows, n, e)
+            torch.cuda.synchronize()
+            assert torch.equal(got, single)
+            idx = [0, 1, 8191, 8192, 8193, batch - 1]
+            assert L.unpack(eng.to_host(got[idx])) == [pow(cts[k], e, n2) for k in idx]
+        eng.debug_knob("n2_split", 2)
+        eng.set_limbs_per_lane(9)
+        assert eng.nsquare_launch_split(n.bit_length(), 11264) is None          # an explicit shape is the caller's choice
+    finally:
+        eng.debug_knob("n2_split", 0)
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
