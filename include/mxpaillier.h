@@ -284,7 +284,7 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
  * segments = 0 (1..64).  MX_KNOB_JACOBI_MAX_BATCHES: value v > 0 limits the Jacobi kernel to v - 1 divstep batches
  * so that its fallback kernel has to finish the symbols (test knob for the safety net).  MX_KNOB_N2_TIMESLICE: the
  * time-sliced form of two-wavefront launches (resident workgroups that share the groups of elements segment by
- * segment; DESIGN.md §4.1d): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
+ * segment; DESIGN.md §4.4): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
  * workgroups per CU (r = 1..3).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
  * friendly-modulus instances (A/B runs against the plain ones).  MX_KNOB_GENERIC_LATENCY: 1 = the automatic geometry of
  * the generic-modulus modexp never takes the 3-limb latency instances.  MX_KNOB_N2_SPLIT: mx_nsquare_launch_split

@@ -1,6 +1,6 @@
 """Build step: 8-byte alignment of 64-bit instructions in the device assembly of the HIP kernels.
 
-Measured on MI355X (profiles/r03_build_variants_ab.txt, DESIGN.md §4.1e): a 64-bit instruction (VOP3 multiply-adds,
+Measured on MI355X (profiles/r03_build_variants_ab.txt, DESIGN.md §4.6): a 64-bit instruction (VOP3 multiply-adds,
 DPP moves — nearly everything in the Montgomery inner loops) that starts at an address = 4 mod 8 costs the
 wavefront about 0.4 of an issue slot more than one that starts at 0 mod 8, and a run of them keeps its parity until
 the next 32-bit instruction (s_waitcnt, s_nop, VOP2 adds).  Whether the long runs of a loop are aligned is decided

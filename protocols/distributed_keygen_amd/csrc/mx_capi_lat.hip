@@ -2,7 +2,7 @@
 // 3 limbs per lane, the products of the exponentiation modulo the friendly multiple of N.  For launches that leave
 // SIMDs idle — the biprimality-test modexps of a key-generation round at the reference's batch sizes leave 2-25
 // survivors, i.e. a few hundred to a thousand modexps (distributed_keygen.py:1084-1099 looped at :1313-1329): the
-// time of such a launch is the dependent chain of ONE wavefront, and fewer limbs per lane shorten it (DESIGN.md §4.1).
+// time of such a launch is the dependent chain of ONE wavefront, and fewer limbs per lane shorten it (DESIGN.md §4.2).
 // Translation unit of its own, built in parallel with the others.
 #include "mx_upload.hpp"
 #include "mx_powmod.hpp"

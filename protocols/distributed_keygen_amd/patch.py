@@ -89,7 +89,7 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
     ``scalars=False`` leaves the reference's own single-ciphertext ``PaillierSharedKey.partial_decrypt``
     / ``.decrypt`` in place (and with them ``DistributedPaillier.decrypt()`` of ONE ciphertext): a lone
     modexp is a latency-bound chain of ~4800 dependent pair operations — 15-16 ms on the GPU at key_length
-    2048 in the two-wavefront latency geometry (DESIGN.md §4.1d; 39.5 ms in round 2), the same for anything up
+    2048 in the two-wavefront latency geometry (DESIGN.md §4.4; 39.5 ms in round 2), the same for anything up
     to ~1000 ciphertexts, against ~13 ms for one ``gmpy2.powmod`` on a host core — so deployments that
     decrypt ciphertexts one at a time and care about those milliseconds may prefer the reference's scalar
     path there, while ``decrypt_sequence``, the batch methods and the key generation run on the GPU."""
