@@ -51,7 +51,28 @@ NOP_COST = 4.0    # an inserted s_nop is taken when it aligns more than this man
 # Left alone: the instances with 3 limbs per lane (template arguments <K, 3, 29, ...>).  Their blocks are a few dozen
 # instructions on ONE dependent chain (the latency geometry); measured, s_nop insertion cost them 3-6 % (14.8 -> 15.3 ms
 # and 55.9 -> 59.5 ms per decrypt) and re-encoding alone changed nothing (14.87 -> 14.99, 55.9 -> 55.4).
-SKIP = re.compile(r"ELi3ELi29E")
+# ... and the time-sliced instances of the two-wavefront kernel (template argument PERSISTENT = true), which measured the
+# same with and without the pass (profiles/r03_asm_alignment_ab.txt).
+SKIP = re.compile(r"ELi3ELi29E|powmod_n2_split_kernelILi\d+ELi\d+ELi29ELb1E")
+# The pass only touches the kernels it was MEASURED to help (lone launches -3 ... -14 %: the two forms of the N^2 pair
+# kernel at 9 and 18 limbs per lane); every other kernel of the library — the generic modexp (+0.2 % at saturation, lone
+# launches never measured), combine, verdict, sieve, Jacobi, field, inverse — is left exactly as the compiler wrote it.
+ONLY = re.compile(r"powmod_n2_kernel|powmod_n2_split_kernel")
+# The pass reads the compiler's assembly text and the disassembler's output; it was validated (CPU tests of the rules,
+# the whole GPU parity suite on the aligned library) with this toolchain.  With another one it still falls back per
+# function when assembly and disassembly cannot be matched, and build.py prints a note.
+VALIDATED_TOOLCHAIN = "ROCm 7.2.0 (AMD clang 22.0.0git)"
+
+
+def toolchain_note() -> Optional[str]:
+    """None if the assembler in use is the validated one, else a sentence for the build log."""
+    try:
+        out = subprocess.run([str(LLVM_BIN / "clang"), "--version"], capture_output=True, text=True, timeout=30).stdout
+    except Exception as exc:  # pragma: no cover
+        return f"asm_align: could not query the toolchain ({exc}); validated with {VALIDATED_TOOLCHAIN}"
+    m = re.search(r"clang version (\S+)", out)
+    ver = m.group(1) if m else "?"
+    return None if ver.startswith("22.0.0") else f"asm_align: validated with {VALIDATED_TOOLCHAIN}, running with clang {ver}"
 # e32 -> e64 re-encoding: VOP1 / VOP2 / VOPC operations whose VOP3 form takes the same operand text.  Operands:
 # VGPRs, inline constants, and at most ONE scalar source (an SGPR or vcc: a VOP3 encoding on this target reads the
 # constant bus once and takes no literal; a 4-byte e32 instruction has no literal to begin with).
@@ -115,9 +136,10 @@ _depth = re.compile(r"Depth=(\d+)")
 
 
 def align_text(asm: str, sizes: Dict[str, List[Tuple[str, int]]], nop_cost: float = NOP_COST, skip=SKIP,
-               promote: bool = True) -> Tuple[str, Dict[str, int]]:
+               promote: bool = True, only=None) -> Tuple[str, Dict[str, int]]:
     """Returns the assembly with re-encoded e32 instructions and inserted s_nop 0, and {function: changes made}
-    (-1: the function could not be matched with its disassembly and was left alone, -2: its name matches `skip`).
+    (-1: the function could not be matched with its disassembly and was left alone, -2: its name matches `skip` or
+    does not match `only`).
 
     Per function a two-state dynamic programme over the instruction sequence (state = address mod 8 in {0, 4}):
     a 64-bit instruction at 4 mod 8 costs 1, an inserted s_nop `nop_cost`, both weighted 8^loop depth (the compiler
@@ -135,7 +157,7 @@ def align_text(asm: str, sizes: Dict[str, List[Tuple[str, int]]], nop_cost: floa
             i += 1
             continue
         name = m.group(1)
-        if skip is not None and skip.search(name):
+        if (skip is not None and skip.search(name)) or (only is not None and not only.search(name)):
             stats[name] = -2
             out.append(lines[i])
             i += 1
@@ -272,6 +294,6 @@ def misaligned(sizes: Dict[str, List[Tuple[str, int]]]) -> Tuple[int, int]:
 
 def align_file(asm_in: Path, asm_out: Path, scratch_obj: Path, nop_cost: float = NOP_COST) -> Dict[str, int]:
     assemble(asm_in, scratch_obj)
-    text, stats = align_text(asm_in.read_text(), disassembly_sizes(scratch_obj), nop_cost)
+    text, stats = align_text(asm_in.read_text(), disassembly_sizes(scratch_obj), nop_cost, only=ONLY)
     asm_out.write_text(text)
     return stats

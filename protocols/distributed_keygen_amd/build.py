@@ -110,6 +110,12 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     objdir = PKG / "build"
     objdir.mkdir(exist_ok=True)
     align_run = float(os.environ["MX_BUILD_ALIGN_RUN"]) if os.environ.get("MX_BUILD_ALIGN_RUN") else None
+    if align_run is None or align_run > 0:
+        from . import asm_align
+
+        note = asm_align.toolchain_note()
+        if note:
+            print(note)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:      # translation units in parallel
         objs = list(pool.map(lambda src: compile_unit(src, objdir, (), align_run, verbose), SOURCES))
     return link(objs, LIB, verbose)

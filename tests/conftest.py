@@ -17,6 +17,13 @@ GOLDEN = Path(__file__).resolve().parent / "golden"
 
 def pytest_configure(config: pytest.Config) -> None:
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # The GPU suite runs like a process that keeps several launches in flight: 16 HIP hardware queues instead of the
+    # runtime's default of 4, chosen before anything touches the GPU (it cannot be changed afterwards).  With 4, the
+    # chunked int-level path (Engine._pipelined: up to 8 side streams) and every test with more than four streams only
+    # ever exercised four-way concurrency (GPUTEST r03 warning).  No effect on the CPU tests.
+    from protocols.distributed_keygen_amd import configure_hw_queues
+
+    configure_hw_queues(16)
 
 
 @pytest.fixture(scope="session", autouse=True)

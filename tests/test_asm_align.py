@@ -68,6 +68,18 @@ def test_an_e32_instruction_in_front_is_re_encoded_instead_of_an_s_nop():
     asm3, sizes3 = _fn("_ZN2mx6kernelILi32ELi3ELi29EEEv", [("v_mov_b32_e32", 4, "v_mov_b32_e32 v1, v2"), *[MAD] * 9])
     out3, stats3 = A.align_text(asm3, sizes3)
     assert out3 == asm3 and stats3["_ZN2mx6kernelILi32ELi3ELi29EEEv"] == -2
+    # ... and so are the time-sliced instances of the two-wavefront pair kernel; the build's allow-list (ONLY) leaves
+    # every kernel alone that the pass was not measured to help
+    body = [("v_mov_b32_e32", 4, "v_mov_b32_e32 v1, v2"), *[MAD] * 9]
+    ts = "_ZN2mx22powmod_n2_split_kernelILi8ELi9ELi29ELb1ELb1EEEvNS_12PowmodN2ArgsE"
+    plain = "_ZN2mx22powmod_n2_split_kernelILi8ELi9ELi29ELb0ELb1EEEvNS_12PowmodN2ArgsE"
+    generic = "_ZN2mx13powmod_kernelILi8ELi9ELi29ELb0ELb0EEEvNS_10PowmodArgsE"
+    one_wave = "_ZN2mx16powmod_n2_kernelILi4ELi18ELi29ELb1EEEvNS_12PowmodN2ArgsE"
+    for name, touched in ((ts, False), (plain, True), (generic, False), (one_wave, True)):
+        a, sz = _fn(name, body)
+        o, st = A.align_text(a, sz, only=A.ONLY)
+        assert (o != a) == touched and (st[name] > 0) == touched and (touched or st[name] == -2), name
+    assert A.toolchain_note() is None or "validated with" in A.toolchain_note()
     # the optimum over a sequence: re-encode the first, keep the second (which would undo it)
     asm2, sizes2 = _fn("k", [("v_mov_b32_e32", 4, "v_mov_b32_e32 v1, v2"), *[MAD] * 4, ("v_mov_b32_e32", 4, "v_mov_b32_e32 v3, v4"), ("v_mov_b32_e32", 4, "v_mov_b32_e32 v5, v6"), *[MAD] * 4])
     out2, _ = A.align_text(asm2, sizes2, skip=None)
