@@ -650,7 +650,10 @@ class Engine:
                 # with few hardware queues (profiles/r02_hw_queue_collisions.txt)
                 pool = self.__dict__.setdefault("_side_stream_pool", list(self._side_streams))
                 while len(pool) < wanted:
-                    pool.append(torch.cuda.Stream(device=self.device, priority=-1))
+                    # (the runtime serves at most four high-priority streams side by side whatever GPU_MAX_HW_QUEUES says —
+                    # measured: 4 of 7 with 16 queues —, so the streams beyond four are ordinary ones, which do get queues
+                    # of their own when the process was started with enough of them)
+                    pool.append(torch.cuda.Stream(device=self.device, priority=-1 if len(pool) < 4 else 0))
                 cands = self._side_streams + [st for st in pool if st not in self._side_streams][: wanted - len(self._side_streams)]
             ok = self.stream_concurrency(cands)
             if len(ok) < len(cands):
