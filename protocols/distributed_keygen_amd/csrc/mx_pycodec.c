@@ -9,6 +9,7 @@
  *
  *   pack_into(values, limbs, buffer, row_offset) -> None   buffer: writable, C-contiguous, rows of 4*limbs bytes
  *   unpack(buffer, limbs) -> list[int]
+ *   rows_ge(rows, limbs, moduli_rows, group) -> list[int]  indices of rows that are >= their group's modulus
  *   set_threads(n) -> previous setting                     0 = automatic (usable cores, at most 16)
  *
  * Both directions read / write the digits of the int objects directly (CPython's 30-bit digits) and do the bit
@@ -298,6 +299,49 @@ static PyObject* unpack(PyObject* self, PyObject* args) {
 }
 #endif
 
+/* rows_ge(rows, limbs, moduli_rows, group) -> list of the indices e with rows[e] >= moduli_rows[e / group]
+ * (both buffers little-endian uint32 rows of `limbs` words).  Received values are canonical residues already, so the
+ * list is normally empty: this replaces a per-group Python / numpy pass over every row in front of each launch. */
+static PyObject* rows_ge(PyObject* self, PyObject* args) {
+  Py_buffer rows, mods;
+  Py_ssize_t limbs, group;
+  if (!PyArg_ParseTuple(args, "y*ny*n", &rows, &limbs, &mods, &group)) return NULL;
+  PyObject* out = NULL;
+  const Py_ssize_t nbytes = 4 * limbs;
+  if (limbs <= 0 || group <= 0 || rows.len % nbytes != 0 || mods.len % nbytes != 0 || (((uintptr_t)rows.buf | (uintptr_t)mods.buf) & 3)) {
+    PyErr_SetString(PyExc_ValueError, "rows_ge: buffers must be whole, 4-byte aligned rows");
+    goto done;
+  }
+  {
+    const Py_ssize_t n = rows.len / nbytes, ngroups = mods.len / nbytes;
+    if (n > ngroups * group) {
+      PyErr_SetString(PyExc_ValueError, "rows_ge: more rows than moduli x group");
+      goto done;
+    }
+    out = PyList_New(0);
+    if (!out) goto done;
+    const uint32_t* r = (const uint32_t*)rows.buf;
+    const uint32_t* m = (const uint32_t*)mods.buf;
+    for (Py_ssize_t e = 0; e < n; ++e) {
+      const uint32_t* a = r + e * limbs;
+      const uint32_t* b = m + (e / group) * limbs;
+      int ge = 1; /* equal counts as >= */
+      for (Py_ssize_t w = limbs - 1; w >= 0; --w) {
+        if (a[w] != b[w]) { ge = a[w] > b[w]; break; }
+      }
+      if (ge) {
+        PyObject* idx = PyLong_FromSsize_t(e);
+        if (!idx || PyList_Append(out, idx) < 0) { Py_XDECREF(idx); Py_CLEAR(out); goto done; }
+        Py_DECREF(idx);
+      }
+    }
+  }
+done:
+  PyBuffer_Release(&rows);
+  PyBuffer_Release(&mods);
+  return out;
+}
+
 static PyObject* set_threads(PyObject* self, PyObject* args) {
   int n;
   if (!PyArg_ParseTuple(args, "i", &n)) return NULL;
@@ -313,6 +357,7 @@ static PyObject* set_threads(PyObject* self, PyObject* args) {
 static PyMethodDef methods[] = {
     {"pack_into", pack_into, METH_VARARGS, "pack_into(values, limbs, buffer, row_offset): ints -> uint32 rows"},
     {"unpack", unpack, METH_VARARGS, "unpack(buffer, limbs) -> list of ints"},
+    {"rows_ge", rows_ge, METH_VARARGS, "rows_ge(rows, limbs, moduli_rows, group) -> indices of rows >= their modulus"},
     {"set_threads", set_threads, METH_VARARGS, "set_threads(n) -> previous; 0 = automatic (usable cores, at most 16)"},
     {NULL, NULL, 0, NULL}};
 

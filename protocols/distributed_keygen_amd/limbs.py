@@ -95,6 +95,14 @@ def reduce_rows(rows: np.ndarray, moduli) -> np.ndarray:
     one = as_index(moduli)
     mods = [one] if one is not None else [int(m) for m in moduli]
     group = count // len(mods)
+    codec = _codec()
+    room = 32 * limbs
+    if codec is not None and hasattr(codec, "rows_ge") and rows.flags.c_contiguous and all(m > 0 and m.bit_length() <= room for m in mods):
+        # one C pass compares every row with its modulus word by word; normally nothing comes back
+        for k in codec.rows_ge(rows, limbs, pack(mods, limbs), group):
+            v = int.from_bytes(rows[k].tobytes(), "little")
+            rows[k] = np.frombuffer((v % mods[k // group]).to_bytes(4 * limbs, "little"), dtype="<u4")
+        return rows
     view = rows.reshape(len(mods), group, limbs)
     for g, m in enumerate(mods):
         top = (m.bit_length() - 1) // 32

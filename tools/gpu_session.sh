@@ -70,6 +70,9 @@ for step in "$@"; do
     census --queues 16 --label "shipped time-sliced, second process" --shape 9,2 --timeslice 2 --reps 2
     grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
     ;;
+  keygen_profile)
+    python tools/keygen_round_profile.py 65536 > $O/keygen_round_profile.txt 2>&1; head -60 $O/keygen_round_profile.txt
+    ;;
   soak)
     for seed in 4 5; do python tools/soak_round4.py $seed 150; done > $O/soak.txt 2>&1; tail -4 $O/soak.txt
     ;;
