@@ -109,9 +109,14 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
     PackJob jobs[16];
     pthread_t tid[16];
     int started[16] = {0};
+    /* a private copy of the element pointers: the list may be resized by another thread while the lock is released
+     * (its elements must stay alive for the duration of the call — they are the caller's values) */
+    PyObject** items = (PyObject**)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(PyObject*));
+    if (!items) { PyErr_NoMemory(); goto fail; }
+    memcpy(items, PySequence_Fast_ITEMS(fast), (size_t)n * sizeof(PyObject*));
     Py_BEGIN_ALLOW_THREADS
     for (int t = 0; t < nt; ++t) {
-      jobs[t].items = PySequence_Fast_ITEMS(fast); jobs[t].dst = dst; jobs[t].limbs = limbs;
+      jobs[t].items = items; jobs[t].dst = dst; jobs[t].limbs = limbs;
       jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt; jobs[t].bad = -1; jobs[t].bad_kind = 0;
       if (t > 0) started[t] = pthread_create(&tid[t], NULL, pack_worker, &jobs[t]) == 0;
     }
@@ -121,6 +126,7 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
       else pack_worker(&jobs[t]); /* thread creation failed: this thread does the slice */
     }
     Py_END_ALLOW_THREADS
+    PyMem_Free(items);
     for (int t = 0; t < nt; ++t) {
       if (jobs[t].bad_kind == 1) { PyErr_SetString(PyExc_TypeError, "values must be ints"); goto fail; }
       if (jobs[t].bad_kind == 2) {

@@ -399,6 +399,29 @@ def test_c_codec_matches_int_to_bytes():
             limbs.pack(bad, 129)
     with pytest.raises(ValueError):
         limbs.pack_into(vals, 129, np.zeros((10, 129), dtype="<u4"), 0)      # buffer too small
+    # the threaded paths (many elements, every thread count) agree with the single-threaded one and with int.to_bytes
+    codec = limbs._codec()
+    assert codec.DIRECT_DIGITS == 1
+    many = [rng.getrandbits(rng.choice([1, 29, 30, 31, 59, 60, 61, 2053, 4100])) for _ in range(40000)] + [0, (1 << 4128) - 1, True]
+    ref = np.frombuffer(b"".join(int(v).to_bytes(516, "little") for v in many), dtype="<u4").reshape(-1, 129)
+    for threads in (1, 2, 7, 16, 0):
+        prev = codec.set_threads(threads)
+        try:
+            got = limbs.pack(many, 129)
+            assert (got == ref).all(), threads
+            back = limbs.unpack(got)
+            assert back == [int(v) for v in many] and all(type(v) is int for v in back), threads
+        finally:
+            codec.set_threads(prev)
+    with pytest.raises(TypeError):
+        codec.pack_into(many[:5000] + [1.5], 129, np.zeros((5001, 129), dtype="<u4"), 0)     # a failure inside a worker's slice
+    with pytest.raises(ValueError):
+        codec.pack_into(many[:5000] + [-1], 129, np.zeros((5001, 129), dtype="<u4"), 0)
+    # rows_ge: the one-pass residue check behind limbs.reduce_rows
+    mods = [(1 << 100) + 7, (1 << 64) - 1, 12345]
+    vals3 = [5, (1 << 100) + 7, (1 << 100) + 6, (1 << 64) - 1, (1 << 64) - 2, 1 << 90, 12345, 12344, 0]
+    assert codec.rows_ge(limbs.pack(vals3, 4), 4, limbs.pack(mods, 4), 3) == [1, 3, 5, 6]
+    assert limbs.unpack(limbs.reduce_rows(limbs.pack(vals3, 4), mods)) == [v % mods[k // 3] for k, v in enumerate(vals3)]
 
 
 def test_shamir_mirror_matches_reference_vectors(golden_reconstruct):
