@@ -785,6 +785,15 @@ def biprime_roofline(eng, wl: BiprimeWorkload, steps: int, elapsed: float, kerne
     return roof
 
 
+def biprime_lanes(cands_per_gpu: int, steps: int) -> int:
+    """Steps kept in flight for the biprimality workload: two for launches that fill the machine on their own, four for
+    the small shards (a rank of an 8-GPU run gets 512 candidates = 2560 wavefronts for 1024 SIMDs: two in flight leave the
+    machine waiting on the small kernels of a step; measured 0.93 -> 1.04 M modexps/s with four,
+    profiles/r04_biprime_lanes.txt)."""
+    want = 4 if cands_per_gpu <= 1024 else 2
+    return want if steps % want == 0 else 2 if steps % 2 == 0 else 1
+
+
 def dist_info(torch, dist, world: int):
     """What the process group actually is: world size as the backend reports it and the RCCL version."""
     if dist is None:
@@ -804,6 +813,10 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
     total_cands = cands * world if weak else total_cands
     eng.set_limbs_per_lane(args.limbs_per_lane if args.limbs_per_lane >= 0 else 0)
     wl = BiprimeWorkload(eng, key_length, n_parties, cands, seed=0xD15C0 + 3 + 101 * rank)
+    if args.limbs_per_lane <= 0 and nstreams > 1:
+        # the library picks the lane geometry for ONE launch on an idle GPU; with `nstreams` steps in flight the launches
+        # fill the machine between them, so the shape is the one that suits their sum (as pick_decrypt_shape does for c3)
+        eng.set_limbs_per_lane(eng.geometry(wl.mod_bits, cands * wl.KEEP * nstreams, cands * nstreams)[1])
     eng.set_priority_aux(nstreams > 1)          # Jacobi filter, selection and verdict do not queue behind the other lane's modexps
     wl.make_lanes(nstreams, dist, world)
     elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), steps, warmup, nstreams)
@@ -1210,7 +1223,7 @@ def main() -> None:
                     keep_bp = ("metric", "value", "unit", "steps", "ms_per_step", "config", "stages", "roofline", "cpu_baseline")
 
                     def biprime_leg(klen, cands, steps, cpu):
-                        bp = run_biprime(args, eng, torch, None, 0, 1, klen, cands, steps=steps, warmup=2, nstreams=2)
+                        bp = run_biprime(args, eng, torch, None, 0, 1, klen, cands, steps=steps, warmup=2, nstreams=biprime_lanes(cands, steps))
                         bwl = bp.pop("_wl")
                         if cpu and not args.no_cpu_baseline:
                             bp["cpu_baseline"] = cpu_baseline(bwl.mods[0], bwl.exps[0], bwl.g_sample[:40], min(args.cpu_seconds, 3.0),
@@ -1247,7 +1260,7 @@ def main() -> None:
             if rank == 0:
                 out.pop("_wl", None)
             torch.cuda.empty_cache()
-            bp = run_biprime(args, eng, torch, dist, rank, world, 2048, 4096, steps=8, warmup=2, nstreams=2)
+            bp = run_biprime(args, eng, torch, dist, rank, world, 2048, 4096, steps=8, warmup=2, nstreams=biprime_lanes(-(-4096 // world), 8))
             if rank == 0:
                 bp.pop("_wl", None)
                 out["extra"] = {"biprime_k2048": {k: bp[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "distributed", "config", "stages", "roofline") if k in bp}}
@@ -1255,7 +1268,7 @@ def main() -> None:
         key_length = args.key_length or 2048
         weak = args.scaling == "weak"
         total = (args.batch or 4096) if weak else (args.batch * world if args.batch else 4096)
-        nstreams = args.streams if args.streams > 0 else 2
+        nstreams = args.streams if args.streams > 0 else biprime_lanes(total if weak else -(-total // world), args.steps)
         out = run_biprime(args, eng, torch, dist, rank, world, key_length, total, args.steps, args.warmup, nstreams, weak=weak)
         if rank == 0:
             wl = out.pop("_wl")

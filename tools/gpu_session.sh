@@ -70,6 +70,13 @@ for step in "$@"; do
     census --queues 16 --label "shipped time-sliced, second process" --shape 9,2 --timeslice 2 --reps 2
     grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
     ;;
+  biprime_lanes)
+    for spec in "2048 512" "2048 1024" "1024 256"; do set -- $spec
+      for st in 1 2 3 4 6; do
+        python bench.py --workload biprime --key-length $1 --batch $2 --streams $st --steps 12 --warmup 3 --no-cpu-baseline 2>/dev/null | python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('biprime k$1 c$2 streams $st:', round(d['value']), 'modexps/s', round(d['ms_per_step'],2), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'), d['config'].get('geometry_K_L_W_blocks'))"
+      done
+    done | tee $O/biprime_lanes.txt
+    ;;
   keygen_profile)
     python tools/keygen_round_profile.py 65536 > $O/keygen_round_profile.txt 2>&1; head -60 $O/keygen_round_profile.txt
     ;;
@@ -113,7 +120,7 @@ for step in "$@"; do
     tail -c 2500 $O/bench_driver_flags.json; wc -c $O/bench_driver_flags.json
     ;;
   biprime_small)
-    for spec in "1024 256" "2048 512" "2048 100" "2048 25"; do set -- $spec
+    for spec in "1024 256" "2048 512" "2048 100" "2048 25" "2048 1024" "2048 2048" "2048 4096"; do set -- $spec
       python bench.py --workload biprime --key-length $1 --batch $2 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_biprime_k$1_c$2.json 2>/dev/null
       python -c "import json,sys; d=json.loads(open('$O/bench_biprime_k$1_c$2.json').read().strip().splitlines()[-1]); print('biprime k$1 c$2', round(d['value']), 'modexps/s', round(d['ms_per_step'],2), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'))"
     done
