@@ -789,9 +789,13 @@ def biprime_lanes(cands_per_gpu: int, steps: int) -> int:
     """Steps kept in flight for the biprimality workload: two for launches that fill the machine on their own, four for
     the small shards (a rank of an 8-GPU run gets 512 candidates = 2560 wavefronts for 1024 SIMDs: two in flight leave the
     machine waiting on the small kernels of a step; measured 0.93 -> 1.04 M modexps/s with four,
-    profiles/r04_biprime_lanes.txt)."""
-    want = 4 if cands_per_gpu <= 1024 else 2
-    return want if steps % want == 0 else 2 if steps % 2 == 0 else 1
+    profiles/r04_biprime_lanes.txt), six for a keygen round's worth of key_length 1024 (256 candidates = a 2.4 ms kernel
+    behind ~1 ms of dependent small kernels: 3.0 / 4.3 / 5.1 / 5.8 M modexps/s with 1 / 2 / 4 / 6 in flight; the host
+    enqueues a step in 0.2 ms, so it is not launch-bound and HIP graphs buy nothing: profiles/r04_graph_probe.txt)."""
+    for want in ((6, 4, 2) if cands_per_gpu <= 256 else (4, 2) if cands_per_gpu <= 1024 else (2,)):
+        if steps % want == 0:
+            return want
+    return 1
 
 
 def dist_info(torch, dist, world: int):
@@ -1247,7 +1251,7 @@ def main() -> None:
 
                     out["extra"]["biprime_k2048"] = guarded("biprime_k2048", lambda: biprime_leg(2048, 4096, 8, True))
                     # configs[1]: key_length 1024, at the size of a keygen round's survivors and at a saturating size
-                    out["extra"]["biprime_k1024_c256"] = guarded("biprime_k1024_c256", lambda: biprime_leg(1024, 256, 8, False))
+                    out["extra"]["biprime_k1024_c256"] = guarded("biprime_k1024_c256", lambda: biprime_leg(1024, 256, 48, False))
                     out["extra"]["biprime_k1024_c8192"] = guarded("biprime_k1024_c8192", lambda: biprime_leg(1024, 8192, 6, False))
                     # configs[4]: the sweep points of key_length 4096
                     out["extra"]["c5_k4096"] = guarded("c5_k4096", lambda: c5_leg(4096, 8, 4, True))

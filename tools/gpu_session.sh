@@ -70,6 +70,9 @@ for step in "$@"; do
     census --queues 16 --label "shipped time-sliced, second process" --shape 9,2 --timeslice 2 --reps 2
     grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
     ;;
+  graph_probe)
+    python tools/graph_probe.py 1024 256 > $O/graph_probe.txt 2>&1; python tools/graph_probe.py 2048 100 >> $O/graph_probe.txt 2>&1; grep -v amdgpu.ids $O/graph_probe.txt | tail -30
+    ;;
   biprime_lanes)
     for spec in "2048 512" "2048 1024" "1024 256"; do set -- $spec
       for st in 1 2 3 4 6; do
@@ -121,7 +124,8 @@ for step in "$@"; do
     ;;
   biprime_small)
     for spec in "1024 256" "2048 512" "2048 100" "2048 25" "2048 1024" "2048 2048" "2048 4096"; do set -- $spec
-      python bench.py --workload biprime --key-length $1 --batch $2 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_biprime_k$1_c$2.json 2>/dev/null
+      steps=8; [ "$2" -le 256 ] && steps=48
+      python bench.py --workload biprime --key-length $1 --batch $2 --steps $steps --warmup 4 --no-cpu-baseline > $O/bench_biprime_k$1_c$2.json 2>/dev/null
       python -c "import json,sys; d=json.loads(open('$O/bench_biprime_k$1_c$2.json').read().strip().splitlines()[-1]); print('biprime k$1 c$2', round(d['value']), 'modexps/s', round(d['ms_per_step'],2), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'))"
     done
     ;;
