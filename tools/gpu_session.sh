@@ -70,6 +70,9 @@ for step in "$@"; do
     census --queues 16 --label "shipped time-sliced, second process" --shape 9,2 --timeslice 2 --reps 2
     grep -E "^==|WRONG|  rep " $O/census.txt | tail -70
     ;;
+  smoke)
+    ( time python -c "import __graft_entry__ as g; g.build(); g.smoke()" ) > $O/smoke.log 2>&1; tail -4 $O/smoke.log
+    ;;
   graph_probe)
     python tools/graph_probe.py 1024 256 > $O/graph_probe.txt 2>&1; python tools/graph_probe.py 2048 100 >> $O/graph_probe.txt 2>&1; grep -v amdgpu.ids $O/graph_probe.txt | tail -30
     ;;
