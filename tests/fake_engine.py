@@ -83,8 +83,37 @@ class FakeEngine:
         self.calls.append(("shamir_lincomb_batch", len(columns[0]) if columns else 0))
         return [sum(cf * col[e] for cf, col in zip(coeffs, columns)) % prime for e in range(len(columns[0]))]
 
-    def shamir_reconstruct_sieve_batch(self, columns, coeffs, prime, primes):
+    def shamir_reconstruct_sieve_batch(self, columns, coeffs, prime, primes, keep_rows=False):
         self.calls.append(("shamir_reconstruct_sieve_batch", len(columns[0]) if columns else 0))
         mods = [sum(cf * col[e] for cf, col in zip(coeffs, columns)) % prime for e in range(len(columns[0]))]
         bad = [oracle.small_prime_divisors_test(primes, m) for m in mods]
-        return bad, {k: m for k, (m, b) in enumerate(zip(mods, bad)) if not b}
+        surviving = {k: m for k, (m, b) in enumerate(zip(mods, bad)) if not b}
+        if keep_rows:          # the double's "device rows" of the survivors' moduli: a tagged list
+            return bad, surviving, ("mods_rows", [surviving[k] for k in sorted(surviving)]) if surviving else None
+        return bad, surviving
+
+    # the device-resident forms of a key-generation round (biprime.BiprimeRound); handles are tagged Python lists
+    def biprime_v_batch(self, g_values, exps, mods, keep, mods_rows=None, keep_rows=False):
+        self.calls.append(("biprime_v_batch", len(mods)))
+        if mods_rows is not None:
+            assert mods_rows[0] == "mods_rows" and mods_rows[1] == list(mods), "kept moduli rows of other candidates"
+        out = []
+        for gs, e, m in zip(g_values, exps, mods):
+            sel = [g for g in gs if oracle.jacobi_symbol(g, m) == 1][:keep]
+            out.append([oracle.pow_mod(g, e, m) for g in sel])
+        return (out, ("v_rows", [list(v) for v in out])) if keep_rows else out
+
+    def biprime_verdict_columns(self, columns, mods, n_slots, mods_rows=None):
+        self.calls.append(("biprime_verdict_columns", len(mods)))
+        if mods_rows is not None:
+            assert mods_rows[0] == "mods_rows" and mods_rows[1] == list(mods)
+        cols = []
+        for col in columns:
+            if isinstance(col, tuple) and col[0] == "v_rows":       # this party's values "from the device"
+                self.calls.append(("own_column_from_device", len(col[1])))
+                cols.append([x for v in col[1] for x in (list(v[:n_slots]) + [0] * (n_slots - min(n_slots, len(v))))])
+            else:
+                assert len(col) == len(mods) * n_slots
+                cols.append(list(col))
+        v = [[c[g * n_slots:(g + 1) * n_slots] for c in cols] for g in range(len(mods))]
+        return self.biprime_verdict_batch(v, mods)

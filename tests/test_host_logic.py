@@ -572,3 +572,48 @@ def test_engine_entry_points_coerce_int_like_operands():
     for name in ("powmod_batch", "powmod_batch_multi", "powmod_nsquare_batch", "modinv_batch", "combine_batch", "sieve_batch",
                  "jacobi_batch", "biprime_v_batch", "biprime_verdict_batch", "shamir_lincomb_batch", "encrypt_batch"):
         assert hasattr(getattr(engine.Engine, name), "__wrapped__"), name
+
+
+def test_biprime_round_keeps_state_between_steps_and_never_trusts_a_changed_column():
+    """biprime.BiprimeRound through the test double's device-resident forms: the survivors' moduli handle goes from the
+    sieve to the v-calculation and the verdicts, this party's v handle stands in for its column only while the values
+    handed to verdicts() equal the computed ones, and the results equal the list-level functions either way."""
+    import random
+
+    import sympy
+
+    from protocols.distributed_keygen_amd import biprime
+
+    rng = random.Random(11)
+    prime = int(sympy.nextprime(1 << 150))
+    degree, points = 2, [1, 2, 3]
+    moduli = [(rng.getrandbits(62) | 1) * (rng.getrandbits(62) | 1) for _ in range(400)]
+    cols = {i: [] for i in points}
+    for m in moduli:
+        co = [m] + [rng.randrange(prime) for _ in range(degree)]
+        for i in points:
+            cols[i].append(sum(c * i ** k for k, c in enumerate(co)) % prime)
+    primes = [int(q) for q in sympy.primerange(3, 150)]
+    eng = FakeEngine()
+    rnd = biprime.BiprimeRound(eng)
+    surviving = rnd.reconstruct_and_sieve(cols, prime, degree, primes, points=points)
+    assert surviving == {k: m for k, m in enumerate(moduli) if not oracle.small_prime_divisors_test(primes, m)}
+    assert rnd.survivors == sorted(surviving) and rnd.moduli == [surviving[k] for k in rnd.survivors] and len(rnd.moduli) >= 10
+    g = [[rng.randrange(m) for _ in range(20)] for m in rnd.moduli]
+    g[3] = g[3][:2]
+    ps = [rng.getrandbits(50) for _ in rnd.moduli]
+    qs = [rng.getrandbits(50) for _ in rnd.moduli]
+    v2 = rnd.v_calculation(g, 2, ps, qs, 5)
+    assert v2 == biprime.biprime_test_v_calculation_batch(g, 2, rnd.moduli, ps, qs, 5, FakeEngine())
+    others = {i: [[rng.randrange(m) for _ in range(5)] for m in rnd.moduli] for i in (1, 3)}
+    v_by = [{1: others[1][c], 2: list(v2[c]), 3: others[3][c]} for c in range(len(rnd.moduli))]
+    want = biprime.biprime_test_with_v_i_batch(v_by, rnd.moduli, 5, FakeEngine(), errors="return")
+    eng.calls.clear()
+    got = rnd.verdicts(v_by, 5, errors="return")
+    assert [repr(x) for x in got] == [repr(x) for x in want]
+    assert ("own_column_from_device", len(rnd.moduli)) in eng.calls            # equal values: the kept rows stood in
+    v_by[0][2] = [(v_by[0][2][0] + 1) % rnd.moduli[0]] + v_by[0][2][1:]
+    eng.calls.clear()
+    got2 = rnd.verdicts(v_by, 5, errors="return")
+    assert not any(c[0] == "own_column_from_device" for c in eng.calls)        # a changed column is packed like any other
+    assert [repr(x) for x in got2] == [repr(x) for x in biprime.biprime_test_with_v_i_batch(v_by, rnd.moduli, 5, FakeEngine(), errors="return")]

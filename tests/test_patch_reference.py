@@ -245,11 +245,17 @@ def test_compute_modulus_is_drop_in(ref):
         patch.uninstall()
     assert got == base
     kinds = {c[0] for c in eng.calls}
-    assert {"shamir_reconstruct_sieve_batch", "jacobi_batch", "powmod_batch_multi", "biprime_verdict_batch"} <= kinds
+    # one round = biprime.BiprimeRound: reconstruct + sieve, v-calculation and verdicts as one call each per party, the
+    # survivors' moduli and the party's own v rows handed from step to step (the double checks that the kept moduli rows
+    # belong to the candidates of the later calls) — and the exchanged own column, being what was computed, is taken
+    # "from the device"
+    assert {"shamir_reconstruct_sieve_batch", "biprime_v_batch", "biprime_verdict_columns", "biprime_verdict_batch",
+            "own_column_from_device"} <= kinds
     rounds = sum(1 for c in eng.calls if c[0] == "shamir_reconstruct_sieve_batch") // 3
     # N reconstruction (DK:1284) + sieve (DK:1288-1292) of a whole round in one call
     assert all(c[1] == 40 for c in eng.calls if c[0] == "shamir_reconstruct_sieve_batch")
-    assert sum(1 for c in eng.calls if c[0] == "powmod_batch_multi") <= 3 * rounds
+    assert sum(1 for c in eng.calls if c[0] == "biprime_v_batch") <= 3 * rounds
+    assert sum(1 for c in eng.calls if c[0] == "own_column_from_device") == sum(1 for c in eng.calls if c[0] == "biprime_verdict_columns")
 
 
 def test_single_decrypt_interleaved_with_pending_sequence(ref):
