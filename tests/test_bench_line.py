@@ -82,3 +82,14 @@ def test_emit_writes_one_stdout_line_and_the_details_file(bench, tmp_path, monke
     assert got.endswith("\n") and got.count("\n") == 1
     assert json.loads(got)["extra_summary"]["single_batch"] == {"value": 3.0}
     assert json.loads((tmp_path / "bench_extras.json").read_text()) == full
+
+
+def test_committed_instruction_model_describes_the_kernels_as_they_are(bench):
+    """bench.py prices the roofline with an instruction-count model fitted to SQ_INSTS_VALU of a particular version of
+    the device code and refuses it (roofline.frac null) when the kernel sources have changed since.  A kernel edit
+    without a recalibration (tools/gpu_session.sh <tag> profile) must fail HERE, not show up as a null in the driver's
+    record."""
+    model, reason = bench.instr_model()
+    assert model is not None, reason
+    for kind, L, nblk in (("n2", 18, 4), ("n2", 18, 8), ("n2split", 9, 8), ("n2split", 3, 24), ("generic", 18, 4), ("generic", 9, 4), ("generic", 3, 13)):
+        assert bench.instr_per_wave(kind, L, nblk, 4192, 592) is not None, (kind, L, nblk)
