@@ -47,7 +47,8 @@ sys.path.insert(0, str(ROOT))
 # queues, 273 k/s with 16; profiles/r02_hw_queue_collisions.txt).  Must be set before the runtime initialises.
 from protocols.distributed_keygen_amd import configure_hw_queues  # noqa: E402  (no GPU call: sets GPU_MAX_HW_QUEUES)
 
-configure_hw_queues(16)
+HW_QUEUES = int(sys.argv[sys.argv.index("--hw-queues") + 1]) if "--hw-queues" in sys.argv[:-1] else 16
+configure_hw_queues(HW_QUEUES)
 
 HBM_PEAK_GBS = 8000.0                       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 # VALU issue on MI355X, measured with fully independent instruction streams, wall clock AND counters
@@ -96,6 +97,9 @@ def parse() -> argparse.Namespace:
                          "-1 = slices when the launches in flight fit the chip side by side at one wavefront per SIMD")
     ap.add_argument("--segments", type=int, default=0,
                     help="c3/c5: launches per exponentiation (mx_powmod_nsquare_run), 0 = the library's choice")
+    ap.add_argument("--hw-queues", type=int, default=16, help="developer: HIP hardware queues of this process (read before the runtime starts)")
+    ap.add_argument("--priority-aux", type=int, default=-1,
+                    help="developer, biprime: 1 / 0 = short kernels on a high-priority companion stream or on the lane's own stream; -1 = companion when several steps are in flight")
     ap.add_argument("--knob", action="append", default=[], metavar="NAME=VALUE",
                     help="developer override of the library for A/B runs (Engine.debug_knob), e.g. n2_friendly_1w=1")
     ap.add_argument("--generic-modulus", action="store_true",
@@ -788,14 +792,24 @@ def biprime_roofline(eng, wl: BiprimeWorkload, steps: int, elapsed: float, kerne
 def biprime_lanes(cands_per_gpu: int, steps: int) -> int:
     """Steps kept in flight for the biprimality workload: two for launches that fill the machine on their own, four for
     the small shards (a rank of an 8-GPU run gets 512 candidates = 2560 wavefronts for 1024 SIMDs: two in flight leave the
-    machine waiting on the small kernels of a step; measured 0.93 -> 1.04 M modexps/s with four,
-    profiles/r04_biprime_lanes.txt), six for a keygen round's worth of key_length 1024 (256 candidates = a 2.4 ms kernel
-    behind ~1 ms of dependent small kernels: 3.0 / 4.3 / 5.1 / 5.8 M modexps/s with 1 / 2 / 4 / 6 in flight; the host
-    enqueues a step in 0.2 ms, so it is not launch-bound and HIP graphs buy nothing: profiles/r04_graph_probe.txt)."""
-    for want in ((6, 4, 2) if cands_per_gpu <= 256 else (4, 2) if cands_per_gpu <= 1024 else (2,)):
-        if steps % want == 0:
+    machine waiting on the short kernels of a step), twelve for a keygen round's worth of candidates (256 at key_length
+    1024 = a 2.4 ms kernel behind ~1 ms of dependent short kernels).  Measured with the short kernels at raised wave
+    priority (csrc/mx_prio.hpp), profiles/r04_biprime_lanes_queues.txt: key_length 1024 x 256 candidates 5.6 / 7.3 / 7.4 M
+    modexps/s with 4 / 8 / 12 in flight, key_length 2048 x 100 candidates 0.64 / 1.08 / 1.19 M/s; 512 candidates 1.28 M/s
+    with 4 or more.  The host enqueues a step in 0.2 ms: not launch-bound, HIP graphs buy nothing
+    (profiles/r04_graph_probe.txt).  More streams than hardware queues (HW_QUEUES) lose 10-25 %: see priority_aux_for."""
+    for want in ((12, 8, 6, 4, 2) if cands_per_gpu <= 256 else (4, 2) if cands_per_gpu <= 1024 else (2,)):
+        if steps % want == 0 and want <= HW_QUEUES:
             return want
     return 1
+
+
+def priority_aux_for(nstreams: int) -> bool:
+    """Whether the short kernels of a step go to a high-priority companion of the lane's stream (Engine.set_priority_aux):
+    only while lanes + companions fit the hardware queues — streams that share a queue serialise, which costs more
+    (12 lanes + 12 companions on 16 queues: 0.87 instead of 1.19 M modexps/s at 100 candidates) than the companion
+    gains now that the short kernels raise their own wave priority."""
+    return 1 < nstreams and 2 * nstreams <= HW_QUEUES
 
 
 def dist_info(torch, dist, world: int):
@@ -821,7 +835,7 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
         # the library picks the lane geometry for ONE launch on an idle GPU; with `nstreams` steps in flight the launches
         # fill the machine between them, so the shape is the one that suits their sum (as pick_decrypt_shape does for c3)
         eng.set_limbs_per_lane(eng.geometry(wl.mod_bits, cands * wl.KEEP * nstreams, cands * nstreams)[1])
-    eng.set_priority_aux(nstreams > 1)          # Jacobi filter, selection and verdict do not queue behind the other lane's modexps
+    eng.set_priority_aux(priority_aux_for(nstreams) if args.priority_aux < 0 else bool(args.priority_aux))          # Jacobi filter, selection and verdict do not queue behind the other lane's modexps
     wl.make_lanes(nstreams, dist, world)
     elapsed, kernel_ms, launches = time_steps(eng, torch, dist, lambda k: wl.step(k, dist), steps, warmup, nstreams)
     assert launches == steps

@@ -10,6 +10,7 @@
 // geometry of N^2 — no long division anywhere.
 #pragma once
 #include "mx_mont.hpp"
+#include "mx_prio.hpp"
 
 namespace mx {
 
@@ -30,6 +31,7 @@ struct CombineArgs {
 
 template <int K, int L, int W>
 __global__ void __launch_bounds__(64) combine_kernel(CombineArgs A) {
+  aux_wave_priority();
   using M_t = Mont<K, L, W, true>;
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;

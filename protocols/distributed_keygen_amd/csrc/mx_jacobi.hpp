@@ -23,6 +23,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mx_prio.hpp"
 
 namespace mx {
 
@@ -61,6 +62,7 @@ constexpr signed char JACOBI_UNFINISHED = 2;   // marker in the output for jacob
 
 template <int NL>
 __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
+  aux_wave_priority();
   constexpr int NCH = (NL + JC - 1) / JC;
   long long grp, row;
   bool valid;
@@ -231,6 +233,7 @@ __global__ void __launch_bounds__(64) jacobi_kernel(JacobiArgs A) {
 //     result t if n == 1 else 0          (every pass removes a bit: at most 64 * NL + 2 passes)
 template <int NL>
 __global__ void __launch_bounds__(64) jacobi_fallback_kernel(JacobiArgs A) {
+  aux_wave_priority();
   long long grp, row;
   bool valid;
   if (A.skip) {

@@ -7,6 +7,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include "mx_prio.hpp"
 
 namespace mx {
 
@@ -20,6 +21,7 @@ struct SelectArgs {
 };
 
 __global__ void __launch_bounds__(64) select_first_kernel(SelectArgs A) {
+  aux_wave_priority();
   const long long g = blockIdx.x;
   const int lane = threadIdx.x;
   const signed char* fl = A.flags + g * A.group_size;

@@ -5,6 +5,7 @@
 // reconstruction to the verdict; no host big-integer work and no host operand besides the moduli.
 #pragma once
 #include "mx_mont.hpp"
+#include "mx_prio.hpp"
 
 namespace mx {
 
@@ -17,6 +18,7 @@ struct RmodnArgs {
 
 template <int K, int L, int W>
 __global__ void __launch_bounds__(64) rmodn_kernel(RmodnArgs A) {
+  aux_wave_priority();
   using M_t = Mont<K, L, W, true>;
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;

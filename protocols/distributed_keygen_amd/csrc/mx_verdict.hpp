@@ -3,6 +3,7 @@
 // the caller ANDs the slots of a candidate (distributed_keygen.py:1160-1172).
 #pragma once
 #include "mx_mont.hpp"
+#include "mx_prio.hpp"
 
 namespace mx {
 
@@ -17,6 +18,7 @@ struct VerdictArgs {
 
 template <int K, int L, int W>
 __global__ void __launch_bounds__(64) verdict_kernel(VerdictArgs A) {
+  aux_wave_priority();
   using M_t = Mont<K, L, W, true>;
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;

@@ -93,3 +93,17 @@ def test_committed_instruction_model_describes_the_kernels_as_they_are(bench):
     assert model is not None, reason
     for kind, L, nblk in (("n2", 18, 4), ("n2", 18, 8), ("n2split", 9, 8), ("n2split", 3, 24), ("generic", 18, 4), ("generic", 9, 4), ("generic", 3, 13)):
         assert bench.instr_per_wave(kind, L, nblk, 4192, 592) is not None, (kind, L, nblk)
+
+
+def test_steps_in_flight_never_need_more_streams_than_hardware_queues(bench):
+    """bench.biprime_lanes / priority_aux_for: lanes (+ their high-priority companions when used) fit the hardware queues
+    the process asked for — streams that share a queue serialise (profiles/r04_biprime_lanes_queues.txt)."""
+    for cands in (25, 100, 256, 512, 1024, 4096):
+        for steps in (1, 6, 8, 12, 20, 48):
+            lanes = bench.biprime_lanes(cands, steps)
+            assert steps % lanes == 0
+            streams = lanes * (2 if bench.priority_aux_for(lanes) else 1)
+            assert streams <= bench.HW_QUEUES
+    assert bench.biprime_lanes(256, 48) == 12 and not bench.priority_aux_for(12)
+    assert bench.biprime_lanes(512, 8) == 4 and bench.priority_aux_for(4)
+    assert not bench.priority_aux_for(1)

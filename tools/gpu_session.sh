@@ -10,6 +10,9 @@
 #   stress        only the four-stream tests
 #   bench         bench.py with the driver's flags and with the defaults (+ bench_extras.json)
 #   biprime_small bench.py --workload biprime at the literal sizes of configs[1] and of an 8-GPU shard
+#   prio_ab       short kernels at raised wave priority against the noprio variant build
+#   lanes_fine    biprime steps in flight x lane geometry at the small shard sizes
+#   lanes_queues  the same with / without companion streams and 16 / 24 / 32 hardware queues
 #   profile       tools/profile_round.sh <tag> (calibration, bench lines, rocprofv3 traces and counter passes)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -137,6 +140,39 @@ for step in "$@"; do
       python bench.py --workload biprime --key-length $1 --batch $2 --steps $steps --warmup 4 --no-cpu-baseline > $O/bench_biprime_k$1_c$2.json 2>/dev/null
       python -c "import json,sys; d=json.loads(open('$O/bench_biprime_k$1_c$2.json').read().strip().splitlines()[-1]); print('biprime k$1 c$2', round(d['value']), 'modexps/s', round(d['ms_per_step'],2), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'))"
     done
+    ;;
+  prio_ab)
+    # short kernels at raised wave priority (csrc/mx_prio.hpp) against a build without (build_variant.py noprio -DMX_AUX_WAVE_PRIO=0)
+    line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value']), d['unit'], round(d['ms_per_step'],3), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'))"; }
+    for rep in 1 2; do for lib in shipped $V/noprio.so; do
+      [ $lib = shipped ] && unset MX_LIBRARY || export MX_LIBRARY=$R/$lib
+      for st in 6 8 12; do python bench.py --workload biprime --key-length 1024 --batch 256 --streams $st --steps 48 --warmup 12 --no-cpu-baseline 2>/dev/null | line "$lib k1024 c256 lanes $st:"; done
+      for st in 4 8; do python bench.py --workload biprime --key-length 2048 --batch 512 --streams $st --steps 16 --warmup 8 --no-cpu-baseline 2>/dev/null | line "$lib k2048 c512 lanes $st:"; done
+      python bench.py --workload biprime --key-length 2048 --batch 100 --streams 6 --steps 24 --warmup 6 --no-cpu-baseline 2>/dev/null | line "$lib k2048 c100 lanes 6:"
+      python bench.py --workload biprime --no-cpu-baseline 2>/dev/null | line "$lib k2048 c4096:"
+      python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 2>/dev/null | line "$lib c3 driver flags:"
+    done; done | tee $O/prio_ab.txt
+    unset MX_LIBRARY
+    ;;
+  lanes_fine)
+    # steps in flight x lane geometry for the small biprime shards (after csrc/mx_prio.hpp)
+    line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value']), d['unit'], round(d['ms_per_step'],3), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'), d['config'].get('geometry_K_L_W_blocks'))"; }
+    for spec in "1024 256 48" "2048 100 48" "2048 25 48" "2048 256 48" "2048 512 48" "2048 1024 24"; do set -- $spec
+      for lpl in -1 9 18; do for st in 4 6 8 12 16 24; do
+        [ $((${3} % st)) -ne 0 ] && continue
+        python bench.py --workload biprime --key-length $1 --batch $2 --streams $st --limbs-per-lane $lpl --steps $3 --warmup $st --no-cpu-baseline 2>/dev/null | line "k$1 c$2 lpl $lpl lanes $st:"
+      done; done
+    done | tee $O/lanes_fine.txt
+    ;;
+  lanes_queues)
+    # do the lanes need their high-priority companion streams now that the short kernels raise their wave priority, and
+    # is the optimum of 8 lanes the 16 hardware queues (8 lanes + 8 companions)?
+    line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value']), d['unit'], round(d['ms_per_step'],3), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'), d['config'].get('geometry_K_L_W_blocks'))"; }
+    for spec in "1024 256 9" "2048 100 18" "2048 25 9" "2048 512 18"; do set -- $spec
+      for q in 16 24 32; do for aux in 1 0; do for st in 4 8 12 16; do
+        python bench.py --workload biprime --key-length $1 --batch $2 --streams $st --limbs-per-lane $3 --hw-queues $q --priority-aux $aux --steps 48 --warmup $st --no-cpu-baseline 2>/dev/null | line "k$1 c$2 lpl $3 queues $q aux $aux lanes $st:"
+      done; done; done
+    done | tee $O/lanes_queues.txt
     ;;
   profile)
     bash tools/profile_round.sh $tag
