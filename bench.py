@@ -1278,7 +1278,9 @@ def main() -> None:
             if rank == 0:
                 out.pop("_wl", None)
             torch.cuda.empty_cache()
-            bp = run_biprime(args, eng, torch, dist, rank, world, 2048, 4096, steps=8, warmup=2, nstreams=biprime_lanes(-(-4096 // world), 8))
+            # (16 steps: a rank's shard is a 16-64 ms step, and a run of two rounds of four lanes is mostly ramp and drain —
+            # 512 candidates per rank: 1.19 M modexps/s over 8 steps, 1.28-1.31 over 16-48)
+            bp = run_biprime(args, eng, torch, dist, rank, world, 2048, 4096, steps=16, warmup=4, nstreams=biprime_lanes(-(-4096 // world), 16))
             if rank == 0:
                 bp.pop("_wl", None)
                 out["extra"] = {"biprime_k2048": {k: bp[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "ms_per_step", "scaling", "distributed", "config", "stages", "roofline") if k in bp}}

@@ -16,8 +16,11 @@ static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s
   return MX_OK;
 }
 
-// no time-sliced instances at 18 limbs per lane: measured (tools/ts_probe.py), they cost 10-20 % more per operation
-// than the plain launch (the unit loop pushes the kernel over its 256 registers) and never beat the 9-limb ones
+// no time-sliced instances at 18 limbs per lane.  Round 3: the unit loop pushed them over 256 registers (10-20 % more
+// per operation).  Round 4, with the opaque lane position per unit (239 registers, no scratch), one resident workgroup
+// per CU: 3.5 % (2 units per group) to 8 % (8 units) above the plain launch where that fits, 45.0-47.6 ms for 10 000
+// ciphertexts against 42.9 for the 9-limb form at two resident workgroups per CU, never ahead anywhere between 4608
+// and 24 576 (tools/ts_probe.py, profiles/r04_ts_probe_2048.txt): not built.
 template <int K>
 static int launch(bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
   if (ts) return MX_ERR_SIZE;

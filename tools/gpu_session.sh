@@ -13,6 +13,7 @@
 #   prio_ab       short kernels at raised wave priority against the noprio variant build
 #   lanes_fine    biprime steps in flight x lane geometry at the small shard sizes
 #   lanes_queues  the same with / without companion streams and 16 / 24 / 32 hardware queues
+#   ts_probe      time-sliced launches (9 and 18 limbs per lane, resident workgroups, units) against the plain shapes
 #   profile       tools/profile_round.sh <tag> (calibration, bench lines, rocprofv3 traces and counter passes)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -136,7 +137,7 @@ for step in "$@"; do
     ;;
   biprime_small)
     for spec in "1024 256" "2048 512" "2048 100" "2048 25" "2048 1024" "2048 2048" "2048 4096"; do set -- $spec
-      steps=8; [ "$2" -le 256 ] && steps=48
+      steps=16; [ "$2" -le 256 ] && steps=48
       python bench.py --workload biprime --key-length $1 --batch $2 --steps $steps --warmup 4 --no-cpu-baseline > $O/bench_biprime_k$1_c$2.json 2>/dev/null
       python -c "import json,sys; d=json.loads(open('$O/bench_biprime_k$1_c$2.json').read().strip().splitlines()[-1]); print('biprime k$1 c$2', round(d['value']), 'modexps/s', round(d['ms_per_step'],2), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'))"
     done
@@ -173,6 +174,10 @@ for step in "$@"; do
         python bench.py --workload biprime --key-length $1 --batch $2 --streams $st --limbs-per-lane $3 --hw-queues $q --priority-aux $aux --steps 48 --warmup $st --no-cpu-baseline 2>/dev/null | line "k$1 c$2 lpl $3 queues $q aux $aux lanes $st:"
       done; done; done
     done | tee $O/lanes_queues.txt
+    ;;
+  ts_probe)
+    python tools/ts_probe.py 2048 > $O/ts_probe_2048.txt 2>&1; cat $O/ts_probe_2048.txt
+    python tools/ts_probe.py 4096 > $O/ts_probe_4096.txt 2>&1; cat $O/ts_probe_4096.txt
     ;;
   profile)
     bash tools/profile_round.sh $tag

@@ -22,7 +22,7 @@ python bench.py --no-cpu-baseline --no-extras --batch 40000 --steps 12 --warmup 
 python bench.py --no-cpu-baseline --no-extras --batch 8192 --streams 1 --steps 12 --warmup 4 > $O/bench_single_stream_8192.json 2>/dev/null
 python bench.py --workload biprime > $O/bench_biprime.json 2>/dev/null
 python bench.py --workload biprime --key-length 1024 --batch 8192 --no-cpu-baseline > $O/bench_biprime_k1024.json 2>/dev/null
-for c in 512 1024 2048; do python bench.py --workload biprime --batch $c --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_biprime_c$c.json 2>/dev/null; done
+for c in 512 1024 2048; do python bench.py --workload biprime --batch $c --steps 16 --warmup 4 --no-cpu-baseline > $O/bench_biprime_c$c.json 2>/dev/null; done
 python bench.py --workload c5 --no-extras > $O/bench_c5_b4096.json 2>/dev/null
 MX_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 > $O/bench_rccl_single_rank.json 2> $O/bench_rccl_single_rank.err
 MX_BENCH_FORCE_DIST=1 python bench.py --workload biprime --no-cpu-baseline > $O/bench_biprime_rccl_single_rank.json 2>/dev/null
