@@ -152,7 +152,9 @@ int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t* d_bases, 
 /* ---- small-prime sieve -----------------------------------------------------------------
  * d_out[e] = 1 if some h_primes[k] divides candidate e else 0.  Replaces
  * `__small_prime_divisors_test(prime_list, n)` (DK:1197-1209) looped over the batch of
- * candidates at DK:1288-1292.  Primes must be odd, >= 3 and < 2^21; limbs <= 1024. */
+ * candidates at DK:1288-1292.  Primes must be odd, >= 3 and < 2^31; limbs <= 1024
+ * (lists whose largest prime is below 2^21 — the reference's default threshold is 2000 — run without any
+ * intermediate reduction; larger ones fold the 64-bit columns every floor(2^32 / max prime) - 1 limbs). */
 int64_t mx_sieve_workspace_bytes(int limbs, int n_primes);
 int mx_sieve(const uint32_t* d_candidates, uint8_t* d_out, const uint32_t* h_primes, int n_primes,
              int limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes, void* stream);

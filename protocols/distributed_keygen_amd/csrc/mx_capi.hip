@@ -494,8 +494,11 @@ extern "C" int mx_sieve(const uint32_t* d_cands, uint8_t* d_out, const uint32_t*
                         int64_t batch, void* d_ws, int64_t ws_bytes, void* stream) {
   if (!d_cands || !d_out || !h_primes || !d_ws || limbs <= 0 || n_primes <= 0 || batch <= 0) return MX_ERR_ARG;
   if (limbs > 1024) return MX_ERR_SIZE;
-  for (int k = 0; k < n_primes; ++k)
-    if (!(h_primes[k] & 1u) || h_primes[k] < 3 || h_primes[k] >= (1u << 21)) return MX_ERR_ARG;
+  uint32_t top = 3;
+  for (int k = 0; k < n_primes; ++k) {
+    if (!(h_primes[k] & 1u) || h_primes[k] < 3 || h_primes[k] >= (1u << 31)) return MX_ERR_ARG;
+    if (h_primes[k] > top) top = h_primes[k];
+  }
   hipStream_t s = (hipStream_t)stream;
   SievePlan p = plan_sieve(limbs, n_primes);
   if (p.total > ws_bytes) return MX_ERR_WORKSPACE;
@@ -508,6 +511,9 @@ extern "C" int mx_sieve(const uint32_t* d_cands, uint8_t* d_out, const uint32_t*
   a.inv = (u64*)(ws + p.off_inv);
   a.lim = (u64*)(ws + p.off_lim);
   a.batch = batch; a.limbs = limbs; a.np = n_primes; a.np_pad = p.np_pad;
+  // limbs a 64-bit column takes between two folds (mx_sieve.hpp): 2^32 ((chunk + 1) top + 1) < 2^64
+  const int64_t chunk = (int64_t)(0xFFFFFFFEull / top) - 1;          // >= 1 for top < 2^31
+  a.chunk = (int)std::min<int64_t>(chunk, limbs);
   hipLaunchKernelGGL(mx::sieve_setup_kernel, dim3((unsigned)(p.np_pad / 64)), dim3(64), 0, s, a);
   MX_HIP(hipGetLastError());
   int64_t nblocks = (batch + mx::SIEVE_C - 1) / mx::SIEVE_C;

@@ -43,7 +43,7 @@ def _save(cls: Any, name: str) -> None:
 
 # Engine limits that the reference does not have (include/mxpaillier.h); checked once at install time
 # and again at the start of compute_modulus, before any message of a keygen round has been exchanged.
-MAX_SIEVE_PRIME = (1 << 21) - 1          # mx_sieve: primes < 2^21
+MAX_SIEVE_PRIME = (1 << 31) - 1          # mx_sieve: primes < 2^31
 MAX_JACOBI_BITS = 257 * 32               # mx_jacobi: moduli up to 257 words (key_length <= 8192, the modexp engine's own limit for N^2)
 
 
@@ -56,7 +56,7 @@ def check_limits(engine: Any = None, prime_list: Optional[Iterable[int]] = None,
         if top > MAX_SIEVE_PRIME:
             raise ValueError(
                 f"prime_threshold too large for the GPU sieve: largest prime {top} > {MAX_SIEVE_PRIME} "
-                "(use prime_threshold < 2^21, or uninstall the patch for this key generation)")
+                "(use prime_threshold < 2^31, or uninstall the patch for this key generation)")
     if prime_length is not None:
         # candidate moduli have 2 * (prime_length + ceil(log2(parties))) bits at most (DK:874-876)
         extra = max(1, (max(1, n_parties) - 1).bit_length())

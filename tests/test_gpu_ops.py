@@ -42,6 +42,35 @@ def test_sieve_random(eng, bits, threshold, batch):
     assert 0 < sum(want) < batch
 
 
+@pytest.mark.parametrize("bits,top", [(2051, (1 << 21) + 17), (2051, 1 << 26), (4102, 1 << 30), (8200, (1 << 31) - 1), (100, (1 << 31) - 1), (31, 1 << 22)])
+def test_sieve_primes_beyond_two_to_the_21(eng, bits, top):
+    """Lists with large primes (prime_threshold above 2^21: the reference takes any, DK:552-554): the 64-bit columns
+    are folded every floor(2^32 / max prime) - 1 limbs — at 2^31 - 1 after every limb.  Candidates: multiples of each
+    large prime alone, all-ones rows (the largest column sums), neighbours of multiples, random rows."""
+    import sympy
+
+    rng = random.Random(bits ^ top)
+    large = [int(sympy.prevprime(top + 1))]
+    while len(large) < 70:                                  # more than one 64-lane pass of primes
+        large.append(int(sympy.prevprime(large[-1] - rng.randrange(1, 1 << 12))))
+    primes = [3, 5, 7] + sorted(large)
+    full = (1 << bits) - 1
+    cands = []
+    for q in large[:24]:
+        m = (rng.getrandbits(bits) | (1 << (bits - 1))) // q * q
+        while any(m % s == 0 for s in (3, 5, 7)) or m.bit_length() > bits:
+            m -= q
+        cands += [m, m + 2, m - q + 1]
+    cands += [full, full - 1, q, q * q if (q * q).bit_length() <= bits else q, 1, 0]
+    cands += [rng.getrandbits(bits) for _ in range(200)]
+    cands = [c for c in cands if 0 <= c <= full]
+    want = [oracle.small_prime_divisors_test(primes, c) for c in cands]
+    assert eng.sieve_batch(cands, primes) == want
+    assert sum(want) >= 24 and sum(want) < len(cands)
+    with pytest.raises(Exception):
+        eng.sieve_batch([15], [3, (1 << 31) + 11])
+
+
 def test_sieve_edge(eng):
     assert eng.sieve_batch([], [3, 5]) == []
     assert eng.sieve_batch([15, 7], []) == [False, False]

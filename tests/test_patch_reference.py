@@ -355,8 +355,9 @@ def test_limits_are_checked_before_any_round(ref):
     from protocols.distributed_keygen_amd import patch
 
     patch.check_limits(None, [3, 5, 1999], 1024, 3)
+    patch.check_limits(None, [3, 5, (1 << 21) + 7], 1024, 3)
     with pytest.raises(ValueError, match="prime_threshold"):
-        patch.check_limits(None, [3, 5, (1 << 21) + 7], 1024, 3)
+        patch.check_limits(None, [3, 5, (1 << 31) + 11], 1024, 3)
     patch.check_limits(None, [3, 5], 4096, 5)                    # key_length 8192 is inside the engine's range
     with pytest.raises(ValueError, match="key_length"):
         patch.check_limits(None, [3, 5], 4200, 3)
