@@ -328,7 +328,9 @@ class DecryptWorkload:
                     "work": None, "done": None,
                 })
             stream = eng.cu_slice_streams(nstreams)[k] if cu_slices else lane_stream(torch, k, nstreams)
-            self.lanes.append({"stream": stream, "hp": small_stream(torch, k), "bufs": bufs, "turn": 0})
+            # the recombination's companion stream only while lanes + companions fit the hardware queues (priority_aux_for)
+            hp = small_stream(torch, k) if nstreams == 1 or priority_aux_for(nstreams) else stream
+            self.lanes.append({"stream": stream, "hp": hp, "bufs": bufs, "turn": 0})
         torch.cuda.synchronize()
 
     def step(self, k: int, dist) -> None:
@@ -1269,7 +1271,9 @@ def main() -> None:
                     out["extra"]["biprime_k1024_c8192"] = guarded("biprime_k1024_c8192", lambda: biprime_leg(1024, 8192, 6, False))
                     # configs[4]: the sweep points of key_length 4096
                     out["extra"]["c5_k4096"] = guarded("c5_k4096", lambda: c5_leg(4096, 8, 4, True))
-                    out["extra"]["c5_k4096_b1024"] = guarded("c5_k4096_b1024", lambda: c5_leg(1024, 8, 4, False))
+                    # 1024 per step: twelve in flight (one launch is 256 wavefronts; 4 / 8 / 12 in flight: 32.6 / 36.8 / 37.2 k/s,
+                    # profiles/r04_decrypt_lanes.txt — past eight lanes the recombination shares the lane's stream)
+                    out["extra"]["c5_k4096_b1024"] = guarded("c5_k4096_b1024", lambda: c5_leg(1024, 24, 12, False))
                     out["extra"]["c5_k4096_b16384"] = guarded("c5_k4096_b16384", lambda: c5_leg(16384, 4, 2, False))
                     out["end_to_end_keygen"] = guarded("end_to_end_keygen", lambda: leg_keygen_round(eng, torch, args))
         if world > 1 and not args.no_extras and args.workload == "c3" and not args.generic_modulus:

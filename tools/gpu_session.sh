@@ -14,6 +14,7 @@
 #   lanes_fine    biprime steps in flight x lane geometry at the small shard sizes
 #   lanes_queues  the same with / without companion streams and 16 / 24 / 32 hardware queues
 #   ts_probe      time-sliced launches (9 and 18 limbs per lane, resident workgroups, units) against the plain shapes
+#   decrypt_lanes c3 / c5 steps in flight beyond four
 #   profile       tools/profile_round.sh <tag> (calibration, bench lines, rocprofv3 traces and counter passes)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -178,6 +179,17 @@ for step in "$@"; do
   ts_probe)
     python tools/ts_probe.py 2048 > $O/ts_probe_2048.txt 2>&1; cat $O/ts_probe_2048.txt
     python tools/ts_probe.py 4096 > $O/ts_probe_4096.txt 2>&1; cat $O/ts_probe_4096.txt
+    ;;
+  decrypt_lanes)
+    # partial decryption + recombination with more steps in flight than the default four (the recombination kernel raises
+    # its wave priority; beyond 8 lanes it runs on the lane's own stream)
+    line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value']), d['unit'], round(d['ms_per_step'],3), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'), d['config'].get('geometry_K_L_W_blocks'), d['config'].get('wavefronts_per_group'))"; }
+    for spec in "c5 1024 48" "c5 2048 48" "c5 4096 24" "c3 2048 48" "c3 4096 48" "c3 10000 24"; do set -- $spec
+      for st in 4 6 8 12 16; do
+        [ $((${3} % st)) -ne 0 ] && continue
+        python bench.py --workload $1 --batch $2 --streams $st --steps $3 --warmup $st --no-cpu-baseline --no-extras 2>/dev/null | line "$1 b$2 lanes $st:"
+      done
+    done | tee $O/decrypt_lanes.txt
     ;;
   profile)
     bash tools/profile_round.sh $tag
