@@ -79,7 +79,7 @@ for step in "$@"; do
     # the N > 1 code paths on one GPU: two ranks over gloo (slices, gathers, the distributed biprime leg), one rank over RCCL
     MX_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 8 --warmup 2 > $O/bench_two_ranks_gloo_one_gpu.json 2> $O/bench_two_ranks_gloo_one_gpu.err; tail -c 1200 $O/bench_two_ranks_gloo_one_gpu.json; echo
     MX_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5 > $O/bench_rccl_single_rank.json 2> $O/bench_rccl_single_rank.err; tail -c 600 $O/bench_rccl_single_rank.json; echo
-    MX_BENCH_FORCE_DIST=1 python bench.py --workload biprime --batch 512 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_biprime_c512_rccl_single_rank.json 2>/dev/null; tail -c 500 $O/bench_biprime_c512_rccl_single_rank.json; echo
+    MX_BENCH_FORCE_DIST=1 python bench.py --workload biprime --batch 512 --steps 16 --warmup 4 --no-cpu-baseline > $O/bench_biprime_c512_rccl_single_rank.json 2>/dev/null; tail -c 500 $O/bench_biprime_c512_rccl_single_rank.json; echo
     ;;
   smoke)
     ( time python -c "import __graft_entry__ as g; g.build(); g.smoke()" ) > $O/smoke.log 2>&1; tail -4 $O/smoke.log
