@@ -274,7 +274,7 @@ def lane_stream(torch, k: int, nstreams: int):
     of 38 k modexps/s that way)."""
     if nstreams == 1:
         return torch.cuda.current_stream()
-    while len(_LANE_STREAMS) <= k:
+    while len(_LANE_STREAMS) <= max(k, MAX_LANES - 1):          # all of them at the first call: early, distinct hardware queues
         _LANE_STREAMS.append(torch.cuda.Stream())
     return _LANE_STREAMS[k]
 
@@ -791,27 +791,33 @@ def biprime_roofline(eng, wl: BiprimeWorkload, steps: int, elapsed: float, kerne
     return roof
 
 
+MAX_LANES = 8
+
+
 def biprime_lanes(cands_per_gpu: int, steps: int) -> int:
     """Steps kept in flight for the biprimality workload: two for launches that fill the machine on their own, four for
     the small shards (a rank of an 8-GPU run gets 512 candidates = 2560 wavefronts for 1024 SIMDs: two in flight leave the
-    machine waiting on the short kernels of a step), twelve for a keygen round's worth of candidates (256 at key_length
+    machine waiting on the short kernels of a step), eight for a keygen round's worth of candidates (256 at key_length
     1024 = a 2.4 ms kernel behind ~1 ms of dependent short kernels).  Measured with the short kernels at raised wave
     priority (csrc/mx_prio.hpp), profiles/r04_biprime_lanes_queues.txt: key_length 1024 x 256 candidates 5.6 / 7.3 / 7.4 M
     modexps/s with 4 / 8 / 12 in flight, key_length 2048 x 100 candidates 0.64 / 1.08 / 1.19 M/s; 512 candidates 1.28 M/s
     with 4 or more.  The host enqueues a step in 0.2 ms: not launch-bound, HIP graphs buy nothing
-    (profiles/r04_graph_probe.txt).  More streams than hardware queues (HW_QUEUES) lose 10-25 %: see priority_aux_for."""
-    for want in ((12, 8, 6, 4, 2) if cands_per_gpu <= 256 else (4, 2) if cands_per_gpu <= 1024 else (2,)):
-        if steps % want == 0 and want <= HW_QUEUES:
+    (profiles/r04_graph_probe.txt).
+    Not more than MAX_LANES: every stream a process has used owns a hardware queue for good, and a process that has
+    used more than ~24 of them is time-sliced by the queue scheduler from then on — twelve lanes for this leg were
+    0.1 M/s faster on their own and cost every LATER leg of the same process 30-45 % (key_length 4096: 39 -> 23 k/s;
+    profiles/r04_bench_queue_budget.txt)."""
+    for want in ((8, 6, 4, 2) if cands_per_gpu <= 256 else (4, 2) if cands_per_gpu <= 1024 else (2,)):
+        if steps % want == 0 and want <= MAX_LANES:
             return want
     return 1
 
 
 def priority_aux_for(nstreams: int) -> bool:
-    """Whether the short kernels of a step go to a high-priority companion of the lane's stream (Engine.set_priority_aux):
-    only while lanes + companions fit the hardware queues — streams that share a queue serialise, which costs more
-    (12 lanes + 12 companions on 16 queues: 0.87 instead of 1.19 M modexps/s at 100 candidates) than the companion
-    gains now that the short kernels raise their own wave priority."""
-    return 1 < nstreams and 2 * nstreams <= HW_QUEUES
+    """Whether the short kernels of a step go to a high-priority companion of the lane's stream (Engine.set_priority_aux,
+    DecryptWorkload.make_lanes): for up to four lanes.  Beyond that the companions buy nothing now that the short kernels
+    raise their own wave priority (profiles/r04_biprime_lanes_queues.txt) and would be eight more hardware queues."""
+    return 1 < nstreams <= 4
 
 
 def dist_info(torch, dist, world: int):
@@ -1271,9 +1277,9 @@ def main() -> None:
                     out["extra"]["biprime_k1024_c8192"] = guarded("biprime_k1024_c8192", lambda: biprime_leg(1024, 8192, 6, False))
                     # configs[4]: the sweep points of key_length 4096
                     out["extra"]["c5_k4096"] = guarded("c5_k4096", lambda: c5_leg(4096, 8, 4, True))
-                    # 1024 per step: twelve in flight (one launch is 256 wavefronts; 4 / 8 / 12 in flight: 32.6 / 36.8 / 37.2 k/s,
-                    # profiles/r04_decrypt_lanes.txt — past eight lanes the recombination shares the lane's stream)
-                    out["extra"]["c5_k4096_b1024"] = guarded("c5_k4096_b1024", lambda: c5_leg(1024, 24, 12, False))
+                    # 1024 per step: eight in flight (one launch is 256 wavefronts; 4 / 8 / 12 in flight: 32.6 / 36.8 / 37.2 k/s,
+                    # profiles/r04_decrypt_lanes.txt — past four lanes the recombination shares the lane's stream)
+                    out["extra"]["c5_k4096_b1024"] = guarded("c5_k4096_b1024", lambda: c5_leg(1024, 24, 8, False))
                     out["extra"]["c5_k4096_b16384"] = guarded("c5_k4096_b16384", lambda: c5_leg(16384, 4, 2, False))
                     out["end_to_end_keygen"] = guarded("end_to_end_keygen", lambda: leg_keygen_round(eng, torch, args))
         if world > 1 and not args.no_extras and args.workload == "c3" and not args.generic_modulus:

@@ -15,6 +15,7 @@
 #   lanes_queues  the same with / without companion streams and 16 / 24 / 32 hardware queues
 #   ts_probe      time-sliced launches (9 and 18 limbs per lane, resident workgroups, units) against the plain shapes
 #   decrypt_lanes c3 / c5 steps in flight beyond four
+#   bench_queues  the whole default bench with 16 / 24 / 32 hardware queues
 #   profile       tools/profile_round.sh <tag> (calibration, bench lines, rocprofv3 traces and counter passes)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
@@ -190,6 +191,18 @@ for step in "$@"; do
         python bench.py --workload $1 --batch $2 --streams $st --steps $3 --warmup $st --no-cpu-baseline --no-extras 2>/dev/null | line "$1 b$2 lanes $st:"
       done
     done | tee $O/decrypt_lanes.txt
+    ;;
+  bench_queues)
+    # the whole default bench (all legs in one process) with 16 / 24 / 32 hardware queues
+    for q in 16 24 32; do
+      python bench.py --steps 20 --warmup 5 --hw-queues $q --cpu-seconds 1 > $O/bench_q$q.json 2> $O/bench_q$q.err; cp bench_extras.json $O/bench_q${q}_extras.json
+      python - $O/bench_q${q}_extras.json $q <<'PY'
+import json, sys
+e = json.load(open(sys.argv[1]))
+print("queues", sys.argv[2], "headline", round(e["value"]), "single_batch", round(e["single_batch"]["value"]), "end_to_end", round(e["end_to_end"]["value"]),
+      " ".join(f"{k} {round(v['value'])}" for k, v in e["extra"].items() if isinstance(v, dict) and "value" in v), "keygen", round(e["end_to_end_keygen"]["value"]))
+PY
+    done | tee $O/bench_queues.txt
     ;;
   profile)
     bash tools/profile_round.sh $tag
