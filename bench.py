@@ -274,7 +274,7 @@ def lane_stream(torch, k: int, nstreams: int):
     of 38 k modexps/s that way)."""
     if nstreams == 1:
         return torch.cuda.current_stream()
-    while len(_LANE_STREAMS) <= max(k, MAX_LANES - 1):          # all of them at the first call: early, distinct hardware queues
+    while len(_LANE_STREAMS) <= k:
         _LANE_STREAMS.append(torch.cuda.Stream())
     return _LANE_STREAMS[k]
 
