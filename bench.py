@@ -311,10 +311,9 @@ class DecryptWorkload:
 
     def make_lanes(self, nstreams: int, dist, world: int, cu_slices: bool = False) -> None:
         """One lane per step in flight (with `cu_slices` each lane's stream is confined to its own slice of the compute
-        units, Engine.cu_slice_streams: for launches so small that several of them fit the chip side by side).  A lane has TWO sets of buffers and a high-priority stream for its
-        recombinations: the recombination of step k reads set A on that stream while the modexp of step k+1
-        already writes set B on the lane's stream (a caller that pipelines decryptions double-buffers the same way),
-        so the 0.5 ms recombination no longer holds up the next 30 ms launch while it waits for wavefront slots."""
+        units, Engine.cu_slice_streams: for launches so small that several of them fit the chip side by side).  A lane has TWO sets of buffers: the recombination of
+        step k reads set A while the modexp of step k+1 already writes set B (a caller that pipelines decryptions
+        double-buffers the same way).  With one lane the recombination has a high-priority stream of its own."""
         torch, eng = self.torch, self.eng
         self.lanes = []
         for k in range(nstreams):
@@ -328,8 +327,11 @@ class DecryptWorkload:
                     "work": None, "done": None,
                 })
             stream = eng.cu_slice_streams(nstreams)[k] if cu_slices else lane_stream(torch, k, nstreams)
-            # the recombination's companion stream only while lanes + companions fit the hardware queues (priority_aux_for)
-            hp = small_stream(torch, k) if nstreams == 1 or priority_aux_for(nstreams) else stream
+            # Several lanes: the recombination runs on the lane's own stream — combine_kernel raises its wave priority
+            # (csrc/mx_prio.hpp), and with that a high-priority companion per lane measured 0.9 % SLOWER on the headline
+            # (304.1 vs 307.4 k/s, three alternating runs on one box) besides costing four hardware queues.  One lane: the
+            # companion lets the recombination of step k overlap the launch of step k + 1.
+            hp = small_stream(torch, k) if nstreams == 1 else stream
             self.lanes.append({"stream": stream, "hp": hp, "bufs": bufs, "turn": 0})
         torch.cuda.synchronize()
 
@@ -493,7 +495,7 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
     lpl, wpg = pick_decrypt_shape(eng, args, wl.n.bit_length(), batch, nstreams)
     eng.set_limbs_per_lane(lpl)
     eng.set_wavefronts_per_group(wpg)
-    eng.set_priority_aux(False)                 # the lanes run their recombinations on their own high-priority streams (make_lanes)
+    eng.set_priority_aux(False)                 # the lanes place their recombinations themselves (make_lanes)
     # Launches that fit a 1/nstreams slice of the chip at one wavefront per SIMD: the dispatcher would stack them on the
     # same CUs of every XCD, so every lane gets its own CUs (same range in every XCD) instead.
     cu_slices = False
