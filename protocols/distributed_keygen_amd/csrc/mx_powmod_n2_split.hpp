@@ -271,8 +271,10 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
       for (int j = 0; j < L; ++j) acc[j] = slot_at(N2_SLOT_CARRY, j);
     }
     int pos = 0;                                      // squarings executed by the tape so far
+    const tape_ptr_t tape = (tape_ptr_t)A.tape;        // scalar loads (mx_powmod_n2.hpp)
     for (int k = 0; k < A.ntape; ++k) {
-      const u32 word = A.tape[k];
+      if (pos >= pos_end) break;                       // the rest belongs to later segments
+      const u32 word = tape[k];
       const u32 op = word >> 28;
       const int arg = (int)(word & 0x0FFFFFFFu);
       if (op == N2_MULC) pos += 1;                       // the last product has a tape position of its own (mx_powmod_n2.hpp)
