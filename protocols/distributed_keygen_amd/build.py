@@ -25,11 +25,32 @@ def _hipcc() -> str:
     raise RuntimeError("hipcc not found (set HIPCC)")
 
 
-def needs_build() -> bool:
+STAMP = PKG / "build" / "sources.sha256"      # digest of everything the library was built from, written after the link
+
+
+def sources_digest() -> str:
+    import hashlib
+
+    h = hashlib.sha256()
+    for p in SOURCES + HEADERS + BUILD_INPUTS:
+        h.update(p.name.encode() + b"\0" + p.read_bytes() + b"\0")
+    return h.hexdigest()
+
+
+def _lib_stale() -> bool:
+    """The library against the sources it was built from: by content where the build left its stamp (a checkout or a
+    copy of the tree changes modification times without changing a byte), by modification time otherwise."""
     if not LIB.exists():
         return True
-    t = LIB.stat().st_mtime
-    if any(p.stat().st_mtime > t for p in SOURCES + HEADERS + BUILD_INPUTS):
+    try:
+        return STAMP.read_text().strip() != sources_digest()
+    except OSError:
+        t = LIB.stat().st_mtime
+        return any(p.stat().st_mtime > t for p in SOURCES + HEADERS + BUILD_INPUTS)
+
+
+def needs_build() -> bool:
+    if _lib_stale():
         return True
     return not CODEC.exists() or CODEC_SRC.stat().st_mtime > CODEC.stat().st_mtime
 
@@ -103,7 +124,7 @@ def build(force: bool = False, verbose: bool = False) -> Path:
     if not force and not needs_build():
         return LIB
     build_codec(verbose)
-    if not force and LIB.exists() and not any(p.stat().st_mtime > LIB.stat().st_mtime for p in SOURCES + HEADERS + BUILD_INPUTS):
+    if not force and not _lib_stale():
         return LIB
     from concurrent.futures import ThreadPoolExecutor
 
@@ -118,7 +139,10 @@ def build(force: bool = False, verbose: bool = False) -> Path:
             print(note)
     with ThreadPoolExecutor(max_workers=len(SOURCES)) as pool:      # translation units in parallel
         objs = list(pool.map(lambda src: compile_unit(src, objdir, (), align_run, verbose), SOURCES))
-    return link(objs, LIB, verbose)
+    digest = sources_digest()
+    out = link(objs, LIB, verbose)
+    STAMP.write_text(digest + "\n")
+    return out
 
 
 if __name__ == "__main__":

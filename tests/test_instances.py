@@ -116,3 +116,23 @@ def test_no_kernel_has_a_private_segment():
         assert any(tmpl in names[r[0]] for r in modexp), tmpl
     offenders = [(names[r[0]], r[1], r[2]) for r in rows if r[1] or r[2]]
     assert not offenders, offenders          # nor any other kernel of the library (round 4: the 257-word Jacobi instances too)
+
+
+def test_library_staleness_is_decided_by_content_not_by_modification_time():
+    """build.needs_build(): a checkout or a copy of the tree renews modification times without changing a byte — the
+    library is stale only if a source differs from the digest the build stamped (protocols/.../build/sources.sha256)."""
+    import os
+
+    from protocols.distributed_keygen_amd import build as B
+
+    if not B.STAMP.exists():
+        pytest.skip("library built before the stamp existed")
+    assert B.STAMP.read_text().strip() == B.sources_digest(), "libmxpaillier.so was not built from the sources in the tree"
+    assert not B.needs_build()
+    header = B.HEADERS[0]
+    st = header.stat()
+    try:
+        os.utime(header, None)                      # newer than the library, same bytes
+        assert not B.needs_build()
+    finally:
+        os.utime(header, (st.st_atime, st.st_mtime))
