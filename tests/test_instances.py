@@ -9,6 +9,8 @@ each of them.
 
 from __future__ import annotations
 
+import pytest
+
 import instance_cases as ic
 
 
