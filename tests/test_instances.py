@@ -9,6 +9,8 @@ each of them.
 
 from __future__ import annotations
 
+from pathlib import Path
+
 import pytest
 
 import instance_cases as ic
@@ -138,3 +140,41 @@ def test_library_staleness_is_decided_by_content_not_by_modification_time():
         assert not B.needs_build()
     finally:
         os.utime(header, (st.st_atime, st.st_mtime))
+
+
+def test_short_kernels_raise_their_wave_priority_and_modexp_kernels_do_not(tmp_path):
+    """csrc/mx_prio.hpp: the Jacobi filter, selection, R mod N, verdict and recombination kernels start with
+    `s_setprio 3` (they share SIMDs with other steps' modexp wavefronts); no modexp kernel touches its
+    priority.  Read from the disassembly of the library as built."""
+    import subprocess
+    import sys
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent / "tools"))
+    import scratch_report
+
+    from protocols.distributed_keygen_amd import asm_align, build as B
+
+    objdump = asm_align.LLVM_BIN / "llvm-objdump"
+    if not objdump.exists() or not B.LIB.exists():
+        pytest.skip("no llvm-objdump / library")
+    short = ("jacobi_kernel", "jacobi_fallback_kernel", "select_first_kernel", "rmodn_kernel", "verdict_kernel", "combine_kernel")
+    raised, modexp_with_prio, seen_short = set(), set(), set()
+    for i, elf in enumerate(scratch_report.code_objects_of_library(B.LIB)):
+        f = tmp_path / f"co{i}.elf"
+        f.write_bytes(elf)
+        text = subprocess.run([str(objdump), "-d", str(f)], capture_output=True, text=True, check=True).stdout
+        fn = None
+        for line in text.splitlines():
+            if line.endswith(">:"):
+                fn = line.split("<", 1)[1][:-2]
+                if any(s in fn for s in short):
+                    seen_short.add(fn)
+            elif "s_setprio" in line and fn:
+                if any(s in fn for s in short):
+                    assert "s_setprio 3" in line, (fn, line)
+                    raised.add(fn)
+                elif "powmod" in fn:
+                    modexp_with_prio.add(fn)
+    assert len(seen_short) >= 20, sorted(seen_short)[:5]
+    assert seen_short == raised, sorted(seen_short - raised)[:5]
+    assert not modexp_with_prio, sorted(modexp_with_prio)[:5]

@@ -64,6 +64,25 @@ def kernels_of_library(path):
     return out
 
 
+def code_objects_of_library(path):
+    """The raw gfx950 code objects (ELF images) inside a built library's offload bundles."""
+    import struct
+
+    data = Path(path).read_bytes()
+    magic = b"__CLANG_OFFLOAD_BUNDLE__"
+    pos = data.find(magic)
+    while pos >= 0:
+        (count,) = struct.unpack_from("<Q", data, pos + len(magic))
+        cur = pos + len(magic) + 8
+        for _ in range(count):
+            off, size, tlen = struct.unpack_from("<QQQ", data, cur)
+            triple = data[cur + 24 : cur + 24 + tlen].decode()
+            cur += 24 + tlen
+            if "amdgcn" in triple and size:
+                yield data[pos + off : pos + off + size]
+        pos = data.find(magic, pos + len(magic))
+
+
 def _kernels_of_code_object(elf: bytes, msgpack):
     import struct
 
