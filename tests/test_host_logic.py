@@ -617,3 +617,36 @@ def test_biprime_round_keeps_state_between_steps_and_never_trusts_a_changed_colu
     got2 = rnd.verdicts(v_by, 5, errors="return")
     assert not any(c[0] == "own_column_from_device" for c in eng.calls)        # a changed column is packed like any other
     assert [repr(x) for x in got2] == [repr(x) for x in biprime.biprime_test_with_v_i_batch(v_by, rnd.moduli, 5, FakeEngine(), errors="return")]
+
+
+def test_sieve_columns_never_overflow_64_bits_with_the_hosts_chunk():
+    """csrc/mx_sieve.hpp / mx_sieve in mx_capi.hip restated with Python ints: with chunk = (2^32 - 2) // top - 1 limbs
+    between two folds, a 64-bit column never reaches 2^64 — worst case: every candidate limb 2^32 - 1 and every table
+    entry l - 1 — and the folded column keeps the residue."""
+    import random
+
+    rng = random.Random(5)
+    M64 = 1 << 64
+    for top in (3, 2000, (1 << 21) - 9, (1 << 21) + 17, (1 << 26) + 15, (1 << 30) + 3, (1 << 31) - 1):
+        chunk = (0xFFFFFFFE // top) - 1
+        assert chunk >= 1
+        for limbs in (1, 2, 3, 64, 257, 1024):
+            step = min(chunk, limbs)
+            for l in {top, 3, max(3, top // 2) | 1}:
+                pw = [pow(2, 32 * j, l) for j in range(limbs)]
+                for worst in (True, False):
+                    cand = [0xFFFFFFFF] * limbs if worst else [rng.getrandbits(32) for _ in range(limbs)]
+                    table = [l - 1] * limbs if worst else pw          # the bound must hold for ANY entry below l
+                    acc, peak = 0, 0
+                    for j0 in range(0, limbs, step):
+                        j1 = min(j0 + step, limbs)
+                        for j in range(j0, j1):
+                            acc += cand[j] * table[j]
+                            peak = max(peak, acc)
+                        if j1 < limbs:
+                            acc = (acc & 0xFFFFFFFF) + (acc >> 32) * (table[1] if worst else pw[1])
+                            peak = max(peak, acc)
+                    assert peak < M64, (top, limbs, l, worst)
+                    if not worst:
+                        n = sum(c << (32 * j) for j, c in enumerate(cand))
+                        assert acc % l == n % l, (top, limbs, l)
