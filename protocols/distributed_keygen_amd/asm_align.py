@@ -54,10 +54,12 @@ NOP_COST = 4.0    # an inserted s_nop is taken when it aligns more than this man
 # ... and the time-sliced instances of the two-wavefront kernel (template argument PERSISTENT = true), which measured the
 # same with and without the pass (profiles/r03_asm_alignment_ab.txt).
 SKIP = re.compile(r"ELi3ELi29E|powmod_n2_split_kernelILi\d+ELi\d+ELi29ELb1E")
-# The pass only touches the kernels it was MEASURED to help (lone launches -3 ... -14 %: the two forms of the N^2 pair
-# kernel at 9 and 18 limbs per lane); every other kernel of the library — the generic modexp (+0.2 % at saturation, lone
-# launches never measured), combine, verdict, sieve, Jacobi, field, inverse — is left exactly as the compiler wrote it.
-ONLY = re.compile(r"powmod_n2_kernel|powmod_n2_split_kernel")
+# The pass only touches the kernels it was MEASURED to help: the two forms of the N^2 pair kernel at 9 and 18 limbs per
+# lane (lone launches -3 ... -14 %) and the generic modexp at 9 and 18 (lone launches -7 ... -9 %: 2.57 -> 2.38 ms for 256
+# candidates at key_length 1024, 13.9 -> 12.7 ms for one wide launch at 2048, profiles/r04_sweep_generic*.txt; +0.2 % at
+# saturation); every other kernel of the library — combine, verdict, sieve, Jacobi, field, inverse, the 3-limb latency
+# instances, the time-sliced instances — is left exactly as the compiler wrote it.
+ONLY = re.compile(r"powmod_n2_kernel|powmod_n2_split_kernel|powmod_kernel")
 # The pass reads the compiler's assembly text and the disassembler's output; it was validated (CPU tests of the rules,
 # the whole GPU parity suite on the aligned library) with this toolchain.  With another one it still falls back per
 # function when assembly and disassembly cannot be matched, and build.py prints a note.

@@ -74,8 +74,10 @@ def test_an_e32_instruction_in_front_is_re_encoded_instead_of_an_s_nop():
     ts = "_ZN2mx22powmod_n2_split_kernelILi8ELi9ELi29ELb1ELb1EEEvNS_12PowmodN2ArgsE"
     plain = "_ZN2mx22powmod_n2_split_kernelILi8ELi9ELi29ELb0ELb1EEEvNS_12PowmodN2ArgsE"
     generic = "_ZN2mx13powmod_kernelILi8ELi9ELi29ELb0ELb0EEEvNS_10PowmodArgsE"
+    generic_latency = "_ZN2mx13powmod_kernelILi32ELi3ELi29ELb0ELb1EEEvNS_10PowmodArgsE"
+    combine = "_ZN2mx14combine_kernelILi16ELi9ELi29EEEvNS_11CombineArgsE"
     one_wave = "_ZN2mx16powmod_n2_kernelILi4ELi18ELi29ELb1EEEvNS_12PowmodN2ArgsE"
-    for name, touched in ((ts, False), (plain, True), (generic, False), (one_wave, True)):
+    for name, touched in ((ts, False), (plain, True), (generic, True), (generic_latency, False), (combine, False), (one_wave, True)):
         a, sz = _fn(name, body)
         o, st = A.align_text(a, sz, only=A.ONLY)
         assert (o != a) == touched and (st[name] > 0) == touched and (touched or st[name] == -2), name
