@@ -16,7 +16,8 @@ Workloads:
       rows and the verdict bytes are all-gathered (the biprimality vote, :1331-1360).
   c5 (configs[4])  c3 at key_length 4096 (8200-bit modulus), batch 4096.
 
-  python bench.py --gpus N --steps K --warmup W      (N > 1: launched by torch.distributed.run)
+  python bench.py --gpus N --steps K --warmup W      (N > 1: under torch.distributed.run, or started directly — it then
+                                                      spawns the N ranks itself, spawn_ranks below)
 
 Inputs are resident in HBM before the timed region.  Prints ONE JSON line (rank 0) whose `roofline`
 is the VALU instruction-issue roof (the path is integer-only: no MFMA, HBM three orders of
@@ -1157,8 +1158,75 @@ def emit_result(out: dict, result_fd: int) -> None:
 
 
 # ---------------------------------------------------------------------------------------------------
+# `python bench.py --gpus N` without a launcher: this process starts the N ranks itself
+# ---------------------------------------------------------------------------------------------------
+def rank_environment(rank: int, world: int, port: int, base=None) -> dict:
+    """What torch.distributed.run would export for local rank `rank` of a one-node job."""
+    env = dict(os.environ if base is None else base)
+    env.update({"RANK": str(rank), "LOCAL_RANK": str(rank), "WORLD_SIZE": str(world), "LOCAL_WORLD_SIZE": str(world),
+                "MASTER_ADDR": "127.0.0.1", "MASTER_PORT": str(port), "MX_BENCH_SPAWNED": "1"})
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")       # dmabuf IPC: the only form this pool's host driver supports
+    return env
+
+
+def rank_command(argv, script=None) -> list:
+    return [sys.executable, str(script or Path(__file__).resolve()), *argv]
+
+
+def spawn_ranks(argv, world: int, script=None, poll_s: float = 0.2) -> int:
+    """One FRESH child process per GPU (this parent has made no GPU call and makes none), rendezvous on 127.0.0.1.
+    Rank 0's single stdout line is relayed as this process's single stdout line; the other ranks' stdout goes to
+    stderr.  Returns 0, or the exit code of the first rank that failed — the remaining ranks (exactly the PIDs started
+    here) are then terminated instead of being left in a collective nobody will complete."""
+    import socket
+    import threading
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        procs.append(subprocess.Popen(rank_command(argv, script), env=rank_environment(r, world, port),
+                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=(r == 0)))
+    captured = []
+    reader = threading.Thread(target=lambda: captured.extend(procs[0].stdout), daemon=True)
+    reader.start()
+    failed = 0
+    try:
+        while any(p.poll() is None for p in procs):
+            bad = next((p for p in procs if p.poll() not in (None, 0)), None)
+            if bad is not None:
+                failed = bad.returncode
+                sys.stderr.write(f"bench.py: rank {procs.index(bad)} exited with {failed}; stopping the other ranks\n")
+                break
+            time.sleep(poll_s)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=20)
+            except subprocess.TimeoutExpired:
+                p.kill()
+                p.wait()
+    reader.join(timeout=5)
+    failed = failed or next((p.returncode for p in procs if p.returncode != 0), 0)
+    lines = [ln.strip() for ln in captured if ln.strip()]
+    if failed == 0 and not lines:
+        sys.stderr.write("bench.py: rank 0 printed no result line\n")
+        failed = 1
+    if failed == 0:
+        sys.stdout.write(lines[-1] + "\n")
+        sys.stdout.flush()
+    return failed if failed > 0 else (128 - failed if failed < 0 else 0)
+
+
 def main() -> None:
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started the way a one-GPU run is started: become the launcher (before torch or the HIP runtime is loaded)
+        raise SystemExit(spawn_ranks(sys.argv[1:], args.gpus))
     # stdout carries exactly ONE line, the JSON result.  Libraries write banners to the C-level stdout
     # (RCCL prints its version block when the first communicator is created, and stdio would flush it
     # after Python's own output), so file descriptor 1 is pointed at stderr for the whole run and the
@@ -1172,12 +1240,16 @@ def main() -> None:
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one process per GPU)")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: start bench.py directly (it spawns one process per GPU) "
+                         "or under torch.distributed.run with --nproc-per-node equal to --gpus")
     # one process per GPU; MX_BENCH_BACKEND=gloo lets several ranks share one GPU (single-GPU smoke
     # test of the multi-rank code path; RCCL refuses two ranks on one device)
     backend = os.environ.get("MX_BENCH_BACKEND", "nccl")
-    local_rank = local_rank % max(1, torch.cuda.device_count())
+    n_dev = torch.cuda.device_count()
+    if backend == "nccl" and 0 < n_dev < world:
+        raise SystemExit(f"--gpus {world} on a node with {n_dev} GPU(s): RCCL needs one device per rank "
+                         "(MX_BENCH_BACKEND=gloo runs the multi-rank code path with ranks sharing a device)")
+    local_rank = local_rank % max(1, n_dev)
     torch.cuda.set_device(local_rank)
     dist = None
     # MX_BENCH_FORCE_DIST=1 runs the process-group code path (RCCL init, all-gather, barrier) with a

@@ -10,13 +10,19 @@ full list (distributed_keygen.py:463-466, 510-515, 1288-1292, 1313-1329).  The s
 is needed.  For the biprimality test a candidate's bases stay on one GPU (its modulus and
 exponent are loaded once) and the verdict bytes are what is gathered — the "vote".
 
+Two input forms.  Replicated (default): every rank passes the FULL batch and works on its slice —
+for callers that hold the whole list anyway, as the reference's loops do.  Shard-only
+(``total=<units of the whole batch>``): a rank passes ONLY rows [lo, hi) of
+``shard_bounds(total, rank, world)`` (and only that slice's moduli / exponents), so it packs and
+uploads 1/world of the batch; the result is the same full, ordered tensor on every rank.
+
 The functions take the tensor-level engine API, so they are backend-agnostic: the tests drive
 them with the ``gloo`` backend on CPU tensors and a test double of the engine.
 """
 
 from __future__ import annotations
 
-from typing import Any, Sequence, Tuple
+from typing import Any, Optional, Sequence, Tuple
 
 
 def shard_bounds(total: int, rank: int, world: int) -> Tuple[int, int]:
@@ -72,11 +78,28 @@ def all_gather_rows(local, total_rows: int, group: Any = None):
     return _gather_rows(_pad_rows(local, per), world, group)[:total_rows]
 
 
-def sharded_powmod_shared(engine: Any, bases_t, mod: int, exp: int, group: Any = None):
+def _check_shard(rows: int, total: int, rank: int, world: int, unit: int = 1) -> int:
+    """Shard-only input: `rows` must be this rank's slice of `total` units (`unit` rows each); returns units per rank."""
+    lo, hi = shard_bounds(total, rank, world)
+    if rows != (hi - lo) * unit:
+        raise ValueError(f"rank {rank} of {world} holds {rows} rows; its shard of {total} units is [{lo}, {hi}) = {(hi - lo) * unit} rows")
+    return -(-total // world)
+
+
+def _pad_list(seq: Sequence[int], n: int, filler: int = 3) -> list:
+    """Pad per-unit host operands to `n` (results of padding units are discarded; an empty shard gets a valid odd modulus)."""
+    seq = list(seq)
+    return seq + [seq[-1] if seq else filler] * (n - len(seq))
+
+
+def sharded_powmod_shared(engine: Any, bases_t, mod: int, exp: int, group: Any = None, total: Optional[int] = None):
     """Full-batch ``engine.powmod_shared_t`` computed as world slices + one all-gather."""
     rank, world = _world(group)
     if world == 1:
         return engine.powmod_shared_t(bases_t, mod, exp)
+    if total is not None:
+        per = _check_shard(bases_t.shape[0], total, rank, world)
+        return _gather_rows(engine.powmod_shared_t(_pad_rows(bases_t, per), mod, exp), world, group)[:total]
     batch = bases_t.shape[0]
     per = -(-batch // world)
     padded = _pad_rows(bases_t, per * world)
@@ -84,12 +107,15 @@ def sharded_powmod_shared(engine: Any, bases_t, mod: int, exp: int, group: Any =
     return _gather_rows(local, world, group)[:batch]
 
 
-def sharded_powmod_nsquare(engine: Any, bases_t, n: int, exp: int, group: Any = None):
+def sharded_powmod_nsquare(engine: Any, bases_t, n: int, exp: int, group: Any = None, total: Optional[int] = None):
     """Full-batch ``engine.powmod_nsquare_t`` (partial decryptions modulo n^2) as world slices + one
     all-gather — the multi-GPU form of the loop distributed_keygen.py:463-466."""
     rank, world = _world(group)
     if world == 1:
         return engine.powmod_nsquare_t(bases_t, n, exp)
+    if total is not None:
+        per = _check_shard(bases_t.shape[0], total, rank, world)
+        return _gather_rows(engine.powmod_nsquare_t(_pad_rows(bases_t, per), n, exp), world, group)[:total]
     batch = bases_t.shape[0]
     per = -(-batch // world)
     padded = _pad_rows(bases_t, per * world)
@@ -98,12 +124,20 @@ def sharded_powmod_nsquare(engine: Any, bases_t, n: int, exp: int, group: Any = 
 
 
 def sharded_powmod_multi(
-    engine: Any, bases_t, mods: Sequence[int], exps: Sequence[int], group_size: int, group: Any = None
+    engine: Any, bases_t, mods: Sequence[int], exps: Sequence[int], group_size: int, group: Any = None,
+    total: Optional[int] = None,
 ):
-    """``engine.powmod_multi_t`` with the candidate groups split across ranks."""
+    """``engine.powmod_multi_t`` with the candidate groups split across ranks (`total` = candidate groups of the whole
+    batch when the caller passes only its shard's bases, moduli and exponents)."""
     rank, world = _world(group)
     if world == 1:
         return engine.powmod_multi_t(bases_t, mods, exps, group_size)
+    if total is not None:
+        per = _check_shard(bases_t.shape[0], total, rank, world, group_size)
+        if len(mods) * group_size != bases_t.shape[0] or len(exps) != len(mods):
+            raise ValueError("shard-only input: one modulus and one exponent per candidate group of the shard")
+        local = engine.powmod_multi_t(_pad_rows(bases_t, per * group_size), _pad_list(mods, per), _pad_list(exps, per, 1), group_size)
+        return _gather_rows(local, world, group)[: total * group_size]
     groups = len(mods)
     per = -(-groups // world)
     mods_p = list(mods) + [mods[-1]] * (per * world - groups)
@@ -116,11 +150,14 @@ def sharded_powmod_multi(
     return _gather_rows(local, world, group)[: groups * group_size]
 
 
-def sharded_sieve(engine: Any, cands_t, primes: Sequence[int], group: Any = None):
+def sharded_sieve(engine: Any, cands_t, primes: Sequence[int], group: Any = None, total: Optional[int] = None):
     """uint8 verdict per candidate; candidates split across ranks, verdict bytes all-gathered."""
     rank, world = _world(group)
     if world == 1:
         return engine.sieve_t(cands_t, primes)
+    if total is not None:
+        per = _check_shard(cands_t.shape[0], total, rank, world)
+        return _gather_rows(engine.sieve_t(_pad_rows(cands_t, per), primes), world, group)[:total]
     batch = cands_t.shape[0]
     per = -(-batch // world)
     padded = _pad_rows(cands_t, per * world)
@@ -128,17 +165,27 @@ def sharded_sieve(engine: Any, cands_t, primes: Sequence[int], group: Any = None
     return _gather_rows(local, world, group)[:batch]
 
 
-def sharded_combine(engine: Any, partials_t, n: int, theta_inv: int, group: Any = None):
+def sharded_combine(engine: Any, partials_t, n: int, theta_inv: int, group: Any = None, total: Optional[int] = None):
     """``engine.combine_t`` with the ciphertexts (dim 1 of partials_t) split across ranks.  Plaintext
     and status travel as ONE row per ciphertext (mx_combine_run's packed output), so the exchange is a
     single all-gather."""
     rank, world = _world(group)
     if world == 1:
         return engine.combine_t(partials_t, n, theta_inv)
-    batch = partials_t.shape[1]
-    per = -(-batch // world)
     import torch
 
+    if total is not None:
+        per = _check_shard(partials_t.shape[1], total, rank, world)
+        have = partials_t.shape[1]
+        if have == 0:          # an empty shard: ones recombine to status 1 rows that the trim below discards
+            partials_t = torch.ones((partials_t.shape[0], per, partials_t.shape[2]), dtype=partials_t.dtype, device=partials_t.device)
+        elif have != per:
+            partials_t = torch.cat([partials_t, partials_t[:, -1:].expand(-1, per - have, -1)], dim=1)
+        packed = engine.combine_t(partials_t.contiguous(), n, theta_inv, packed=True)
+        full = _gather_rows(packed, world, group)[:total]
+        return full[:, :-1].contiguous(), full[:, -1].to(torch.uint8)
+    batch = partials_t.shape[1]
+    per = -(-batch // world)
     if per * world != batch:
         pad = per * world - batch
         partials_t = torch.cat([partials_t, partials_t[:, -1:].expand(-1, pad, -1)], dim=1)
@@ -148,7 +195,7 @@ def sharded_combine(engine: Any, partials_t, n: int, theta_inv: int, group: Any 
 
 
 def sharded_biprime_v(engine: Any, g_t, mods: Sequence[int], exps: Sequence[int], group_size: int, keep: int,
-                      group: Any = None):
+                      group: Any = None, total: Optional[int] = None):
     """The v-calculation of a keygen round (distributed_keygen.py:1084-1099 looped at :1313-1329) with
     the candidates split contiguously across ranks: every rank runs the fused Jacobi filter ->
     selection of the first `keep` generators -> `keep` modexps on ITS candidates
@@ -160,23 +207,30 @@ def sharded_biprime_v(engine: Any, g_t, mods: Sequence[int], exps: Sequence[int]
         return engine.biprime_v_t(g_t, list(mods), list(exps), group_size, keep)
     import torch
 
-    groups = len(mods)
     limbs = g_t.shape[1]
-    per = -(-groups // world)
-    mods_p = list(mods) + [mods[-1]] * (per * world - groups)
-    exps_p = list(exps) + [exps[-1]] * (per * world - groups)
-    padded = _pad_rows(g_t, per * world * group_size)
-    lo = rank * per
-    v_t, cnt_t = engine.biprime_v_t(
-        padded[lo * group_size : (lo + per) * group_size].contiguous(), mods_p[lo : lo + per], exps_p[lo : lo + per],
-        group_size, keep,
-    )
+    if total is not None:      # shard-only: g_t, mods, exps are this rank's candidates
+        per = _check_shard(g_t.shape[0], total, rank, world, group_size)
+        if len(mods) * group_size != g_t.shape[0] or len(exps) != len(mods):
+            raise ValueError("shard-only input: one modulus and one exponent per candidate of the shard")
+        groups = total
+        v_t, cnt_t = engine.biprime_v_t(_pad_rows(g_t, per * group_size), _pad_list(mods, per), _pad_list(exps, per, 1), group_size, keep)
+    else:
+        groups = len(mods)
+        per = -(-groups // world)
+        mods_p = list(mods) + [mods[-1]] * (per * world - groups)
+        exps_p = list(exps) + [exps[-1]] * (per * world - groups)
+        padded = _pad_rows(g_t, per * world * group_size)
+        lo = rank * per
+        v_t, cnt_t = engine.biprime_v_t(
+            padded[lo * group_size : (lo + per) * group_size].contiguous(), mods_p[lo : lo + per], exps_p[lo : lo + per],
+            group_size, keep,
+        )
     row = torch.cat([v_t.reshape(per, keep * limbs), cnt_t.reshape(per, 1).to(v_t.dtype)], dim=1)
     full = _gather_rows(row, world, group)[:groups]
     return full[:, : keep * limbs].reshape(groups * keep, limbs).contiguous(), full[:, -1].contiguous()
 
 
-def sharded_biprime_vote(engine: Any, v_t, mods: Sequence[int], group: Any = None):
+def sharded_biprime_vote(engine: Any, v_t, mods: Sequence[int], group: Any = None, total: Optional[int] = None):
     """Per-slot pass bytes [groups, n_slots] of ``engine.biprime_verdict_t`` with candidates split
     across ranks; the pass bytes are all-gathered (the biprimality vote)."""
     rank, world = _world(group)
@@ -184,6 +238,17 @@ def sharded_biprime_vote(engine: Any, v_t, mods: Sequence[int], group: Any = Non
         return engine.biprime_verdict_t(v_t, mods)
     import torch
 
+    if total is not None:      # shard-only: v_t [parties, shard candidates, slots, limbs] and the shard's moduli
+        per = _check_shard(v_t.shape[1], total, rank, world)
+        if len(mods) != v_t.shape[1]:
+            raise ValueError("shard-only input: one modulus per candidate of the shard")
+        have = v_t.shape[1]
+        if have == 0:
+            v_t = torch.zeros((v_t.shape[0], per) + tuple(v_t.shape[2:]), dtype=v_t.dtype, device=v_t.device)
+        elif have != per:
+            v_t = torch.cat([v_t, v_t[:, -1:].expand(-1, per - have, -1, -1)], dim=1)
+        local = engine.biprime_verdict_t(v_t.contiguous(), _pad_list(mods, per))
+        return _gather_rows(local, world, group)[:total]
     groups = len(mods)
     per = -(-groups // world)
     mods_p = list(mods) + [mods[-1]] * (per * world - groups)

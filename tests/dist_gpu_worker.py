@@ -104,6 +104,21 @@ def main() -> None:
     lo, hi = mxdist.shard_bounds(1, rank, world)
     local = eng.powmod_shared_t(rows(bases[lo:hi], L.limbs_for(mod)), mod, e1) if hi > lo else torch.zeros((0, L.limbs_for(mod)), dtype=torch.int32, device=eng.device)
     assert ints(mxdist.all_gather_rows(local, 1)) == [pow(bases[0], e1, mod)]
+    # ---- shard-only inputs: every rank packs and uploads ONLY its slice (total= names the whole batch)
+    lo, hi = mxdist.shard_bounds(len(cts), rank, world)
+    assert ints(mxdist.sharded_powmod_nsquare(eng, rows(cts[lo:hi], limbs2), n, exp, total=len(cts))) == [pow(c, exp, n2) for c in cts]
+    m2_t, st2 = mxdist.sharded_combine(eng, torch.stack([rows(p[lo:hi], limbs2) for p in parts]), n, key.theta_inv, total=len(cts))
+    assert st2.tolist() == want_st and torch.equal(m2_t[:11], m_t[:11]) and torch.equal(m2_t[12:], m_t[12:])
+    lo, hi = mxdist.shard_bounds(len(cm), rank, world)
+    v2_t, cnt2 = mxdist.sharded_biprime_v(eng, rows(gens[lo * 24 : hi * 24], 17), cm[lo:hi], ce[lo:hi], 24, 8, total=len(cm))
+    assert cnt2.tolist() == want_c and torch.equal(v2_t, v_t)
+    lo, hi = mxdist.shard_bounds(5, rank, world)
+    assert mxdist.sharded_biprime_vote(eng, v[:, lo:hi].contiguous(), [m0] * (hi - lo), total=5).tolist() == votes.tolist()
+    lo, hi = mxdist.shard_bounds(len(cands), rank, world)
+    assert torch.equal(mxdist.sharded_sieve(eng, rows(cands[lo:hi], 17), primes, total=len(cands)), got)
+    lo, hi = mxdist.shard_bounds(1, rank, world)       # an empty shard on rank 1
+    one = mxdist.sharded_powmod_multi(eng, rows(flat[lo * 6 : hi * 6], 17), mods[lo:hi], exps[lo:hi], 6, total=1)
+    assert ints(one) == [pow(b, exps[0], mods[0]) for b in flat[:6]]
     torch.cuda.synchronize()
     dist.barrier()
     dist.destroy_process_group()

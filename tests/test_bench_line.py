@@ -108,3 +108,60 @@ def test_steps_in_flight_stay_within_the_stream_budget(bench):
     assert bench.biprime_lanes(256, 48) == 8 and not bench.priority_aux_for(8)
     assert bench.biprime_lanes(512, 16) == 4 and bench.priority_aux_for(4)
     assert not bench.priority_aux_for(1)
+
+
+# --- `python bench.py --gpus N` started without a launcher ---------------------------------------
+_RANK_SCRIPT = """
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == os.environ["RANK"] and os.environ["MASTER_ADDR"] == "127.0.0.1"
+assert int(os.environ["MASTER_PORT"]) > 0 and os.environ["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+mode = sys.argv[sys.argv.index("--mode") + 1]
+print("banner of rank", rank)                     # ranks other than 0: must not reach the parent's stdout
+if mode == "fail" and rank == 1:
+    sys.exit(7)
+if mode == "fail":
+    time.sleep(60)                                # a rank waiting in a collective its peer will never join
+if rank == 0:
+    print(json.dumps({"world": world, "argv": sys.argv[1:]}))
+"""
+
+
+def test_rank_command_and_environment(bench):
+    cmd = bench.rank_command(["--gpus", "4", "--steps", "8"])
+    assert cmd[0] == sys.executable and Path(cmd[1]) == ROOT / "bench.py" and cmd[2:] == ["--gpus", "4", "--steps", "8"]
+    env = bench.rank_environment(3, 4, 29999, base={"PATH": "/bin", "HSA_ENABLE_IPC_MODE_LEGACY": "0"})
+    assert (env["RANK"], env["LOCAL_RANK"], env["WORLD_SIZE"], env["MASTER_ADDR"], env["MASTER_PORT"]) == ("3", "3", "4", "127.0.0.1", "29999")
+    assert env["PATH"] == "/bin"
+
+
+def test_spawn_ranks_relays_rank0_line(bench, tmp_path, capfd):
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    rc = bench.spawn_ranks(["--gpus", "3", "--mode", "ok"], 3, script=script)
+    out = capfd.readouterr().out.strip().splitlines()
+    assert rc == 0
+    assert json.loads(out[-1]) == {"world": 3, "argv": ["--gpus", "3", "--mode", "ok"]}
+    assert sum(1 for ln in out if ln.startswith("{")) == 1
+
+
+def test_spawn_ranks_propagates_a_failing_rank(bench, tmp_path, capfd):
+    import time
+
+    script = tmp_path / "rank.py"
+    script.write_text(_RANK_SCRIPT)
+    t0 = time.perf_counter()
+    rc = bench.spawn_ranks(["--gpus", "2", "--mode", "fail"], 2, script=script)
+    assert rc == 7 and time.perf_counter() - t0 < 30          # rank 0 was stopped, not waited for
+    assert not [ln for ln in capfd.readouterr().out.splitlines() if ln.startswith("{")]
+
+
+def test_main_becomes_the_launcher_before_any_gpu_call(bench, monkeypatch):
+    """--gpus N > 1 without WORLD_SIZE: main() hands over to spawn_ranks before torch is imported by bench.main"""
+    seen = {}
+    monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "8", "--steps", "4", "--warmup", "1"])
+    monkeypatch.setattr(bench, "spawn_ranks", lambda argv, world: seen.update(argv=argv, world=world) or 0)
+    with pytest.raises(SystemExit) as exc:
+        bench.main()
+    assert exc.value.code == 0 and seen == {"argv": ["--gpus", "8", "--steps", "4", "--warmup", "1"], "world": 8}

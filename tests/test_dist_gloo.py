@@ -102,6 +102,46 @@ def _worker(rank: int, world: int, port: int, ret) -> None:
         votes = mxdist.sharded_biprime_vote(eng, v, [m0, m0, m0])
         assert votes.tolist() == [[1, 1], [0, 1], [1, 1]]
         assert mxdist.shard_bounds(7, 0, 2) == (0, 4) and mxdist.shard_bounds(7, 1, 2) == (4, 7)
+        # --- shard-only inputs: a rank packs and passes ONLY its slice, `total` names the whole
+        me = dist.get_rank()
+        lo, hi = mxdist.shard_bounds(7, me, 2)
+        got = mxdist.sharded_powmod_shared(eng, _rows(bases[lo:hi], L.limbs_for(mod)), mod, exp, total=7)
+        assert _ints(got) == [pow(b, exp, mod) for b in bases]
+        lo, hi = mxdist.shard_bounds(5, me, 2)
+        got = mxdist.sharded_powmod_nsquare(eng, _rows(cs[lo:hi], L.limbs_for(n_small * n_small)), n_small, exp, total=5)
+        assert _ints(got) == [pow(c, exp, n_small * n_small) for c in cs]
+        lo, hi = mxdist.shard_bounds(3, me, 2)
+        got = mxdist.sharded_powmod_multi(eng, _rows(flat[lo * 5 : hi * 5], 5), mods[lo:hi], exps[lo:hi], 5, total=3)
+        assert _ints(got) == [pow(b, exps[k // 5], mods[k // 5]) for k, b in enumerate(flat)]
+        lo, hi = mxdist.shard_bounds(9, me, 2)
+        got = mxdist.sharded_sieve(eng, _rows(cands[lo:hi], 3), primes, total=9)
+        assert [bool(x) for x in got.tolist()] == [oracle.small_prime_divisors_test(primes, c) for c in cands]
+        lo, hi = mxdist.shard_bounds(5, me, 2)
+        m_t, st = mxdist.sharded_combine(eng, pt[:, lo:hi].contiguous(), key.n, key.theta_inv, total=5)
+        assert st.tolist() == [0, 0, 0, 1, 0] and [m for m, s_ in zip(_ints(m_t), st.tolist()) if not s_] == [3, 1, 4, 5]
+        v_t2, cnt2 = mxdist.sharded_biprime_v(eng, _rows(gens[lo * 12 : hi * 12], 5), cm[lo:hi], ce[lo:hi], 12, 4, total=5)
+        assert cnt2.tolist() == want_c and _ints(v_t2) == want_v
+        lo, hi = mxdist.shard_bounds(3, me, 2)
+        votes = mxdist.sharded_biprime_vote(eng, v[:, lo:hi].contiguous(), [m0] * (hi - lo), total=3)
+        assert votes.tolist() == [[1, 1], [0, 1], [1, 1]]
+        # one unit over two ranks: rank 1 passes an EMPTY shard to every operator and still joins the collective
+        lo, hi = mxdist.shard_bounds(1, me, 2)
+        got = mxdist.sharded_powmod_shared(eng, _rows(bases[lo:hi], L.limbs_for(mod)), mod, exp, total=1)
+        assert _ints(got) == [pow(bases[0], exp, mod)]
+        got = mxdist.sharded_powmod_multi(eng, _rows(flat[lo * 5 : hi * 5], 5), mods[lo:hi], exps[lo:hi], 5, total=1)
+        assert _ints(got) == [pow(b, exps[0], mods[0]) for b in flat[:5]]
+        m_t, st = mxdist.sharded_combine(eng, pt[:, lo:hi].contiguous(), key.n, key.theta_inv, total=1)
+        assert st.tolist() == [0] and _ints(m_t) == [3]
+        v_t2, cnt2 = mxdist.sharded_biprime_v(eng, _rows(gens[lo * 12 : hi * 12], 5), cm[lo:hi], ce[lo:hi], 12, 4, total=1)
+        assert cnt2.tolist() == want_c[:1] and _ints(v_t2) == want_v[:4]
+        votes = mxdist.sharded_biprime_vote(eng, v[:, lo:hi].contiguous(), [m0] * (hi - lo), total=1)
+        assert votes.tolist() == [[1, 1]]
+        # a shard of the wrong size is refused before the collective (every rank raises: nobody is left waiting)
+        try:
+            mxdist.sharded_sieve(eng, _rows(cands, 3), primes, total=9)
+            raise AssertionError("full input with total= accepted")
+        except ValueError:
+            pass
         ret[rank] = "ok"
     except Exception as exc:  # surfaced by the parent
         import traceback
