@@ -589,6 +589,43 @@ class Engine:
             t.record_stream(cur)
         return res, self.torch.cat(kept, dim=0)
 
+    def powmod_nsquare_groups(self, jobs: Sequence[Tuple[Sequence[int], int, int]]) -> List[List[int]]:
+        """[[pow_mod(b, exp, n*n) for b in bases] for (bases, exp, n) in jobs] with the jobs' launches SIDE BY SIDE on
+        separate streams: the partial decryptions of several keys — or of the parties of one key that share this
+        process and GPU (``distributed=False``: same N, every party its own exponent, hence its own tape) — that are
+        pending at the same time (coalesce.Coalescer).  A launch of up to ~1000 ciphertexts lasts as long as one
+        wavefront's dependent chain whatever its size, so k small jobs one after the other cost k chains and side by
+        side one.  Every job is launched in the shape that suits the SUM in flight (``saturating_shape``)."""
+        jobs = [(b if isinstance(b, list) else list(b), int(e), int(n)) for b, e, n in jobs]
+        live = [k for k, (b, _, _) in enumerate(jobs) if len(b)]
+        total = sum(len(jobs[k][0]) for k in live)
+        if len(live) <= 1 or total >= self.PIPELINE_MIN:
+            return [self.powmod_nsquare_batch(b, e, n) if len(b) else [] for b, e, n in jobs]
+        torch = self.torch
+        streams = self._chunk_streams(min(len(live), self.PIPELINE_STREAMS))
+        cur = torch.cuda.current_stream(self.device)
+        n_bits = max(jobs[k][2].bit_length() for k in live)
+        shape = self.saturating_shape(n_bits, total)
+        outs: Dict[int, Any] = {}
+        for j, k in enumerate(live):
+            bases, exp, n = jobs[k]
+            _check_modulus(n)
+            n2 = n * n
+            limbs2 = _limbs.limbs_for(n2)
+            rows = _limbs.pack_reduced(bases, limbs2, n2)
+            self.nsquare_plan(n, exp)                     # prepared on the caller's stream, before the fan-out
+            side = streams[j % len(streams)]
+            side.wait_stream(cur)
+            with torch.cuda.stream(side):
+                outs[k] = self.powmod_nsquare_t(self.to_device(rows), n, exp, segments=1, shape=shape)
+        res: List[List[int]] = [[] for _ in jobs]
+        for j, k in enumerate(live):
+            with torch.cuda.stream(streams[j % len(streams)]):
+                res[k] = _limbs.unpack(self.to_host(outs[k]))     # copied on, and waited for through, the producing stream
+        for side in streams[: len(live)]:
+            cur.wait_stream(side)
+        return res
+
     # ------------------------------------------------------------------ chunked execution on several streams
     PIPELINE_MIN = 20000       # elements from which an int-level batch is cut into chunks
     PIPELINE_STREAMS = 8

@@ -5,6 +5,10 @@ script uses at scripts/bench_batch_size.py:94-110):
 
   PaillierSharedKey.partial_decrypt / .decrypt           paillier_shared_key.py:52-127
       -> GPU-backed, plus new .partial_decrypt_batch / .decrypt_batch
+  DistributedPaillier._decrypt_raw                       distributed_keygen.py:314-382
+      -> same receivers logic, message id and message content; its two arithmetic call sites (:345-349 partial
+         decryption, :378-380 recombination) are awaits on a per-process micro-batcher (coalesce.Coalescer): every
+         ``decrypt()`` coroutine pending in the same turn of the event loop shares ONE launch per key
   DistributedPaillier._decrypt_sequence_raw              distributed_keygen.py:430-517
       -> same receivers logic, message id and message content, with its two loops (:463-466 partial
          decryptions, :510-515 recombinations) executed as ONE launch each; received partial
@@ -28,11 +32,18 @@ import importlib
 from typing import Any, Dict, Iterable, List, Optional
 
 from . import biprime, shamir
+from .coalesce import Coalescer
 from .shared_key import GpuPaillierSharedKey
 
 DEFAULT_PACKAGE = "tno.mpc.protocols.distributed_keygen"
 _saved: Dict[Any, Dict[str, Any]] = {}
 _saved_names: Dict[Any, Dict[str, Any]] = {}      # module -> {name: original leaf function}
+_coalescers: Dict[str, Coalescer] = {}            # package -> the micro-batcher of its installed patch
+
+
+def coalescer(package: str = DEFAULT_PACKAGE) -> Optional[Coalescer]:
+    """The micro-batcher behind the patched ``_decrypt_raw`` of `package` (its ``stats`` count launches)."""
+    return _coalescers.get(package)
 
 
 def _save(cls: Any, name: str) -> None:
@@ -79,8 +90,18 @@ def _gpu_key(key: Any, engine: Any) -> GpuPaillierSharedKey:
     return cached
 
 
-def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = True, leaf: bool = False) -> None:
-    """``leaf=True`` additionally rebinds the arithmetic leaf itself — the names ``pow_mod`` / ``mod_inv``
+def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = True, leaf: bool = False,
+            linger: float = 0.0, hw_queues: int = 16) -> None:
+    """``hw_queues``: the engine keeps several launches in flight (chunks of long sequences, the batches of co-located
+    parties), which needs more HIP hardware queues than the runtime's default of 4; they can only be chosen before
+    the process first touches the GPU, so install() asks for them here (``configure_hw_queues``; 0 = leave alone) and
+    warns when it is too late — the engine then measures what it has and uses fewer streams.
+
+    ``linger``: seconds a burst of single ``decrypt()`` calls may wait for stragglers before its launch (0 = until
+    the event loop has run every coroutine that was runnable, which is what ``asyncio.gather`` over an in-process
+    pool needs; a few milliseconds suit pools whose messages arrive over a network).
+
+    ``leaf=True`` additionally rebinds the arithmetic leaf itself — the names ``pow_mod`` / ``mod_inv``
     that distributed_keygen.py:35 and paillier_shared_key.py:20 import from the un-vendored
     tno.mpc.encryption_schemes.utils — to ``operators.pow_mod`` / ``operators.mod_inv``, so that any
     remaining scalar call site of those modules (e.g. ``mod_inv(theta, n)`` in the reference's own
@@ -98,6 +119,20 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
     PSK = psk_mod.PaillierSharedKey
     DP = dk_mod.DistributedPaillier
     check_limits(engine)
+    if hw_queues:
+        import os
+
+        from . import configure_hw_queues
+
+        if not configure_hw_queues(hw_queues) and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < hw_queues:
+            import warnings
+
+            warnings.warn(
+                "protocols.distributed_keygen_amd.patch.install(): the HIP runtime of this process was initialised before "
+                f"the patch was installed, with its default of 4 hardware queues instead of {hw_queues}; launches that are meant "
+                "to run side by side (long decrypt_sequence calls, co-located parties) will partly serialise.  Call "
+                "patch.install() — or protocols.distributed_keygen_amd.configure_hw_queues() — before the first GPU call.",
+                RuntimeWarning, stacklevel=2)
     if leaf:
         from . import operators
 
@@ -149,9 +184,46 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
         _save(PSK, name)
         setattr(PSK, name, fn)
 
+    # ------------------------------------------------------------------ decrypt of ONE ciphertext, coalesced
+    EncodedPlaintext = dk_mod.EncodedPlaintext
+    batcher = _coalescers[package] = Coalescer(engine, linger=linger)
+
+    async def _decrypt_raw(self: Any, ciphertext: Any, receivers: Optional[List[str]] = None):
+        """DK:314-382 with the same receivers logic (:331-343), message id (:352-355) and message content (:357-364).
+        The partial decryption (:345-349) and the recombination (:378-380) are awaited from the micro-batcher, so
+        the coroutines of ``asyncio.gather(*(scheme.decrypt(c) for c in cs))`` share one launch per step instead of
+        blocking the loop for one launch each; results and exceptions are per coroutine, as in the reference."""
+        if receivers is not None:
+            self_receive = "self" in receivers
+            receivers_without_self = [recv for recv in receivers if recv != "self"] if self_receive else receivers
+        else:
+            self_receive = True
+            receivers_without_self = receivers
+        key = _gpu_key(self.secret_key, engine)
+        partial_decryption_shares = {self.index: await batcher.partial_decrypt(key, ciphertext)}
+        encryption_hash = bin(ciphertext.peek_value()).zfill(32)[2:34]
+        message_id = f"distributed_decryption_session#{self.session_id}_hash#{encryption_hash}"
+        if receivers_without_self is None or len(receivers_without_self) != 0:
+            self.pool.async_broadcast(
+                {"content": "partial_decryption", "value": partial_decryption_shares[self.index]},
+                msg_id=message_id,
+                handler_names=receivers_without_self,
+            )
+        if not self_receive:
+            return None
+        for party, message in await self.pool.recv_all(msg_id=message_id):
+            msg_content = message["content"]
+            err_msg = f"received a share for {msg_content}, but expected partial_decryption"
+            assert msg_content == "partial_decryption", err_msg
+            partial_decryption_shares[self.party_indices[party]] = message["value"]
+        return EncodedPlaintext(await batcher.decrypt(key, partial_decryption_shares), scheme=self)
+
+    if scalars:
+        _save(DP, "_decrypt_raw")
+        setattr(DP, "_decrypt_raw", _decrypt_raw)
+
     # ------------------------------------------------------------------ decrypt_sequence
     _save(DP, "_decrypt_sequence_raw")
-    EncodedPlaintext = dk_mod.EncodedPlaintext
 
     async def _decrypt_sequence_raw(self: Any, ciphertext_sequence: Iterable[Any], receivers: Optional[List[str]] = None):
         """DK:430-517 with the same receivers logic (:447-461), message id (:469-475) and message content
@@ -311,3 +383,4 @@ def uninstall() -> None:
             else:
                 setattr(cls, name, orig)
     _saved.clear()
+    _coalescers.clear()
