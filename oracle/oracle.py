@@ -216,6 +216,14 @@ def shamir_mul_add(p_share: int, q_share: int, zero_share: int, prime: int) -> i
     return (p_share * q_share % prime + zero_share) % prime
 
 
+def shamir_share(secret: int, prime: int, number_of_parties: int, degree: int, rng) -> dict:
+    """`ShamirSecretSharingScheme.share_secret` of the un-vendored package as `_generate_pq` uses it (DK:785-823 through
+    utils.py:252-260): a random polynomial of `degree` with constant term `secret`, evaluated at 1..n.  `rng` supplies
+    the coefficients (test-side randomness; the scheme's own is `secrets`)."""
+    coeffs = [secret % prime] + [rng.randrange(prime) for _ in range(degree)]
+    return {i: sum(c * pow(i, k, prime) for k, c in enumerate(coeffs)) % prime for i in range(1, number_of_parties + 1)}
+
+
 def shamir_reconstruct(shares: dict, prime: int, degree: int) -> int:
     """`candidate_n.reconstruct()` (DK:1284, UT:263-270): value at 0 of the polynomial through the
     first degree+1 shares in party order."""

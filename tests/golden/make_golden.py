@@ -624,7 +624,7 @@ def gen_reconstruct(dk) -> dict:
                 pool = _MemPool(hub, me)
                 party_indices = {("self" if n == me else n): k for k, n in enumerate(names, start=1)}
                 _, prime_length, _, sh_t, sh_2t, _ = DP.setup_input(pool, key_length, 200, t)
-                p_sh, q_sh, zero, _, _ = await DP._generate_pq(
+                p_sh, q_sh, zero, p_add, q_add = await DP._generate_pq(
                     pool, i, prime_length, party_indices, sh_t, sh_2t, 99, batch_size=batch, msg_id=f"pq_{label}")
                 candidate_n = p_sh * q_sh                     # DK:1274
                 candidate_n += zero                           # DK:1277
@@ -634,7 +634,8 @@ def gen_reconstruct(dk) -> dict:
                 }
                 await dk.exchange_reconstruct(candidate_n, i, pool, party_indices, msg_id=f"n_{label}")   # DK:1281
                 moduli = candidate_n.reconstruct()            # DK:1284
-                record[i] = (mine, moduli, sh_t.modulus, [dict(v.get_shares()) for v in candidate_n.variables])
+                record[i] = (mine, moduli, sh_t.modulus, [dict(v.get_shares()) for v in candidate_n.variables],
+                             [int(x) for x in p_add], [int(x) for x in q_add])
 
             async def run():
                 await asyncio.gather(*[party(i, me) for i, me in enumerate(names, start=1)])
@@ -649,10 +650,29 @@ def gen_reconstruct(dk) -> dict:
         assert int(prime) == int(sympy.nextprime(2 ** (2 * (key_length // 2 + math.ceil(math.log2(n_parties))))))   # DK:647-651
         for i in record:                                       # every party saw the same share table
             assert record[i][3] == record[1][3]
+        # The pin that does not depend on the Shamir stand-in: the additive shares p_i, q_i come from the reference's own
+        # candidate generation (DK:854-876, its secrets-based sampling), and whatever Shamir implementation carries them,
+        # the modulus of candidate k is (sum_i p_i[k]) * (sum_i q_i[k]).
+        for k, m in enumerate(moduli):
+            assert m == sum(record[i][4][k] for i in record) * sum(record[i][5][k] for i in record), (label, k)
         out[label] = {
             "key_length": key_length, "n_parties": n_parties, "t": t, "degree": 2 * t, "prime": hx(int(prime)),
             "shares": {str(i): {k: [hx(v) for v in vals] for k, vals in record[i][0].items()} for i in sorted(record)},
             "moduli": [hx(m) for m in moduli],
+            "p_additive": {str(i): [hx(v) for v in record[i][4]] for i in sorted(record)},
+            "q_additive": {str(i): [hx(v) for v in record[i][5]] for i in sorted(record)},
+            "provenance": {
+                "reference_code": "DistributedPaillier.setup_input (Shamir prime, DK:647-651), _generate_pq (additive shares "
+                                  "p_additive / q_additive, DK:854-876; the share-and-exchange flow DK:720-852), Batched / "
+                                  "ShamirVariable containers (utils.py:175-298, 386-500: which share is multiplied with "
+                                  "which, `+= zero`), exchange_reconstruct (utils.py:560-594)",
+                "stand_in_code": "tno.mpc.encryption_schemes.shamir is not vendored: ShamirSecretSharingScheme.share_secret "
+                                 "(random polynomial, evaluation at 1..n), ShamirShares.__add__ / __mul__ (share-wise modulo "
+                                 "the prime) and .reconstruct_secret (Lagrange at 0 over the first degree+1 points) are the "
+                                 "textbook stand-in of this script — so `shares` (p, q, zero, n) are stand-in numbers",
+                "pinned_by_reference_alone": "`moduli` == (sum p_additive) * (sum q_additive) per candidate (asserted when "
+                                             "generated): both factors come from the reference's own sampling",
+            },
         }
     return out
 

@@ -43,9 +43,6 @@ class AdditiveVariable:
     def get_share(self, index: int) -> int:
         return self._sharing[index]            # KeyError on an unset slot
 
-    def get_shares(self) -> Dict[int, int]:
-        return self._sharing
-
     def clone(self) -> "AdditiveVariable":
         return AdditiveVariable(self.label, self.modulus)
 
@@ -177,8 +174,21 @@ class DistributedPaillier:
 
     # ---- decryption
     async def _decrypt_raw(self, ciphertext: Any, receivers: Optional[List[str]] = None):
-        res = await self._decrypt_sequence_raw([ciphertext], receivers)
-        return None if res is None else res[0]
+        """One ciphertext: a message of its own kind ("partial_decryption", a bare value) under an id made of the
+        ciphertext's leading bits only — the shape of the reference's single-ciphertext protocol."""
+        self_receive = receivers is None or "self" in receivers
+        others = None if receivers is None else [r for r in receivers if r != "self"]
+        mine = self.secret_key.partial_decrypt(ciphertext)
+        msg_id = f"distributed_decryption_session#{self.session_id}_hash#{bin(ciphertext.peek_value()).zfill(32)[2:34]}"
+        if others is None or others:
+            self.pool.async_broadcast({"content": "partial_decryption", "value": mine}, msg_id=msg_id, handler_names=others)
+        if not self_receive:
+            return None
+        collected = {self.index: mine}
+        for party, message in await self.pool.recv_all(msg_id=msg_id):
+            assert message["content"] == "partial_decryption"
+            collected[self.party_indices[party]] = message["value"]
+        return EncodedPlaintext(self.secret_key.decrypt(collected), scheme=self)
 
     async def _decrypt_sequence_raw(self, ciphertext_sequence: Iterable[Any], receivers: Optional[List[str]] = None):
         sequence = list(ciphertext_sequence)
@@ -237,7 +247,7 @@ class DistributedPaillier:
         return out[0], out[1], out[2], p_add, q_add
 
     @classmethod
-    async def __biprime_test_g_generation(cls, correct_param_biprime, index, moduli, party_indices, pool, msg_id):
+    async def __biprime_test_g_generation(cls, correct_param_biprime, index, candidate_n_list, party_indices, pool, msg_id):
         """4 x correct_param jointly random values in [0, N) per modulus: every party contributes a seed, the
         values are derived from all seeds (identical on every party)."""
         seed = rng.getrandbits(128)
@@ -247,7 +257,7 @@ class DistributedPaillier:
             seeds[party_indices[party]] = message["value"]
         joint = hashlib.sha256(repr(sorted(seeds.items())).encode()).digest()
         g_rng = random.Random(joint)
-        return [[g_rng.randrange(n) for _ in range(4 * correct_param_biprime)] for n in moduli]
+        return [[g_rng.randrange(n) for _ in range(4 * correct_param_biprime)] for n in candidate_n_list]
 
     # ---- key generation: the three tests
     @classmethod

@@ -69,6 +69,15 @@ def decrypt_single(parties: List[Any], ct: Any):
     return asyncio.run(run())
 
 
+def decrypt_many(parties: List[Any], cts: List[Any], return_exceptions: bool = False):
+    """Every party decrypts every ciphertext with a coroutine of its own — `asyncio.gather(*(scheme.decrypt(c) ...))`,
+    the shape of the reference's own test (test/test_distributed_keygen.py:132-158).  Results party-major."""
+    async def run():
+        return await asyncio.gather(*[dp._decrypt_raw(c) for dp in parties for c in cts], return_exceptions=return_exceptions)
+
+    return asyncio.run(run())
+
+
 def keygen(seed: int, key_length: int, batch_size: int, prime_threshold: int = 200, correct_param: int = 20, t: int = 1) -> List[int]:
     """Three parties run DistributedPaillier.compute_modulus (patched or not) with seeded randomness; returns the
     modulus every party ended with."""

@@ -305,7 +305,24 @@ def test_shamir_field_kernels_golden(eng, golden_reconstruct):
         shares = {int(i): {k: [unhex(v) for v in vals] for k, vals in d.items()} for i, d in grp["shares"].items()}
         for i, d in shares.items():
             assert shamir.mul_add_shares_batch(d["p"], d["q"], d["zero"], prime, eng) == d["n"], (label, i)
-        assert shamir.reconstruct_batch({i: d["n"] for i, d in shares.items()}, prime, degree, eng) == [unhex(m) for m in grp["moduli"]]
+        got = shamir.reconstruct_batch({i: d["n"] for i, d in shares.items()}, prime, degree, eng)
+        assert got == [unhex(m) for m in grp["moduli"]]
+        # the pin that owes nothing to the Shamir stand-in of make_golden.py (see `provenance` in the fixture): the
+        # additive shares come from the reference's own candidate sampling, and N_k = (sum p_i[k]) * (sum q_i[k])
+        p_add = [[unhex(v) for v in grp["p_additive"][i]] for i in sorted(grp["p_additive"])]
+        q_add = [[unhex(v) for v in grp["q_additive"][i]] for i in sorted(grp["q_additive"])]
+        assert got == [sum(p[k] for p in p_add) * sum(q[k] for q in q_add) for k in range(len(got))], label
+        # ... and with a sharing the REFERENCE-side numbers alone determine up to the polynomials: this party shares its
+        # own additive parts with fresh polynomials (the oracle's restatement of the un-vendored scheme), the device
+        # multiplies, adds a sharing of zero and interpolates — the same moduli again
+        rng = random.Random(len(label))
+        n_parties, t, count = grp["n_parties"], grp["t"], len(got)
+        ps = [oracle.shamir_share(sum(p[k] for p in p_add), prime, n_parties, t, rng) for k in range(count)]
+        qs = [oracle.shamir_share(sum(q[k] for q in q_add), prime, n_parties, t, rng) for k in range(count)]
+        zs = [oracle.shamir_share(0, prime, n_parties, 2 * t, rng) for k in range(count)]
+        n_sh = {i: shamir.mul_add_shares_batch([s_[i] for s_ in ps], [s_[i] for s_ in qs], [s_[i] for s_ in zs], prime, eng)
+                for i in range(1, n_parties + 1)}
+        assert shamir.reconstruct_batch(n_sh, prime, degree, eng) == got, label
 
 
 @pytest.mark.parametrize("bits,terms,batch", [(61, 3, 70), (133, 5, 33), (1030, 3, 129), (2054, 5, 64), (2054, 9, 17), (4102, 3, 9)])

@@ -67,6 +67,70 @@ def test_patched_decrypt_sequence_on_the_hip_engine(eng, key_length, count):
         patch.uninstall()
 
 
+def test_concurrent_single_decrypts_are_coalesced_on_the_hip_engine(eng):
+    """3 co-located parties x 256 concurrent `decrypt()` coroutines at key_length 2048.  Unpatched
+    shape: 768 lone launches of ~13 ms each.  Coalesced: per party ONE modexp launch (the three parties' launches side
+    by side: same N, different exponents) and ONE recombination launch — bit-identical plaintexts, per-coroutine
+    exceptions, well under 60 ms of wall time per burst once the per-key plans exist."""
+    import time
+
+    from protocols.distributed_keygen_amd import patch, synthetic
+
+    key = synthetic.make_key(2048, 3, 1)
+    rng = random.Random(2048)
+    count = 256
+    msgs = [0, 1, key.n - 1] + [rng.randrange(key.n) for _ in range(count - 3)]
+    cts, seen = [], set()
+    while len(cts) < count:                                  # distinct leading bits: the message id is made of them
+        c = synthetic.encrypt(key, msgs[len(cts)], rng)
+        tag = bin(c).zfill(32)[2:34]
+        if tag not in seen:
+            seen.add(tag)
+            cts.append(c)
+    patch.install(engine=eng, package=sh.PACKAGE)
+    try:
+        parties = sh.parties_for_key(key)
+        got = sh.decrypt_many(parties, sh.ciphertexts(key, cts))        # first burst: prepares the per-key plans
+        assert [e.value for e in got] == msgs * 3 and all(type(e.value) is int for e in got)
+        stats = patch.coalescer(sh.PACKAGE).stats
+        assert stats["partial_launches"] == 3 and stats["combine_launches"] == 3 and stats["largest_batch"] == count
+        walls = []
+        for _ in range(3):
+            cobjs = sh.ciphertexts(key, cts)
+            t0 = time.perf_counter()
+            got = sh.decrypt_many(parties, cobjs)
+            walls.append(time.perf_counter() - t0)
+            assert [e.value for e in got] == msgs * 3 and all(not c.fresh for c in cobjs)
+        stats = patch.coalescer(sh.PACKAGE).stats
+        assert stats["partial_launches"] == 12 and stats["combine_launches"] == 12          # <= 3 launches per party and burst
+        print(f"3 parties x {count} concurrent decrypt(): {[round(w * 1e3, 1) for w in walls]} ms per burst")
+        assert min(walls) < 0.060, walls
+        # per-coroutine errors: one tampered partial decryption on the wire poisons exactly the recombinations that use it
+        victim_tag = bin(cts[7]).zfill(32)[2:34]
+        hub = parties[0].pool.hub
+        orig_deliver = type(parties[1].pool)._deliver
+
+        def tamper(self, to, message, msg_id):
+            if self.me == "p2" and msg_id.endswith("#" + victim_tag):
+                message = dict(message, value=(message["value"] + 1) % key.n_square)
+            orig_deliver(self, to, message, msg_id)
+
+        type(parties[1].pool)._deliver = tamper
+        try:
+            res = sh.decrypt_many(parties, sh.ciphertexts(key, cts[:16]), return_exceptions=True)
+        finally:
+            type(parties[1].pool)._deliver = orig_deliver
+        for p in range(3):
+            for k in range(16):
+                r = res[p * 16 + k]
+                if k == 7 and p != 1:             # parties 1 and 3 received p2's tampered share for ciphertext 7
+                    assert isinstance(r, ValueError) and "not divisible by N" in str(r)
+                else:
+                    assert r.value == msgs[k]
+    finally:
+        patch.uninstall()
+
+
 def test_patched_compute_modulus_on_the_hip_engine(eng):
     """The stand-in's keygen loop, unpatched (CPython + sympy) and patched (HIP engine), from the same seed:
     the same biprime.  Candidates, generators and exchanged shares are identical in both runs, so every

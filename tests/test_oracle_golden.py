@@ -125,6 +125,23 @@ def test_shamir_field_steps_match_reference(golden_reconstruct):
             assert [oracle.shamir_mul_add(d["p"][k], d["q"][k], d["zero"][k], prime) for k in range(count)] == d["n"], (label, i)
         for k in range(count):
             assert oracle.shamir_reconstruct({i: d["n"][k] for i, d in shares.items()}, prime, degree) == unhex(grp["moduli"][k])
+        # pinned by the reference's own code alone (fixture `provenance`): N_k = (sum of the parties' additive p shares)
+        # * (sum of their additive q shares), both sampled by DistributedPaillier._generate_pq itself (DK:854-876)
+        p_add = [[unhex(v) for v in grp["p_additive"][i]] for i in sorted(grp["p_additive"])]
+        q_add = [[unhex(v) for v in grp["q_additive"][i]] for i in sorted(grp["q_additive"])]
+        assert [unhex(m) for m in grp["moduli"]] == [sum(p[k] for p in p_add) * sum(q[k] for q in q_add) for k in range(count)]
+        assert all(p[k] % 4 == (3 if i == 0 else 0) for i, p in enumerate(p_add) for k in range(count))      # DK:855-858
+        # the oracle's sharing -> multiply-add -> reconstruct pipeline from those additive shares lands on the same moduli
+        import random as _random
+
+        rng = _random.Random(7)
+        n_parties, t = grp["n_parties"], grp["t"]
+        for k in range(count):
+            ps = oracle.shamir_share(sum(p[k] for p in p_add), prime, n_parties, t, rng)
+            qs = oracle.shamir_share(sum(q[k] for q in q_add), prime, n_parties, t, rng)
+            zs = oracle.shamir_share(0, prime, n_parties, 2 * t, rng)
+            n_sh = {i: oracle.shamir_mul_add(ps[i], qs[i], zs[i], prime) for i in ps}
+            assert oracle.shamir_reconstruct(n_sh, prime, degree) == unhex(grp["moduli"][k])
         # the moduli have the documented size: sum of n shares of key_length/2 bits, squared (SURVEY hard part 1)
         for m in grp["moduli"]:
             assert grp["key_length"] <= unhex(m).bit_length() <= grp["key_length"] + 2 * (grp["n_parties"] - 1).bit_length() + 1
