@@ -223,8 +223,9 @@ def valu_roofline(kernel: str, instr_per_launch, launches: int, elapsed: float, 
     out["frac"] = achieved / peak
     out["mac_share"] = mac_share
     out["frac_at_measured_clock"] = (achieved / (SIMDS * clock_mhz * 1e6 / mix_cycles)) if clock_mhz else None
-    if out["frac_at_measured_clock"] is not None and out["frac_at_measured_clock"] > 1.0:
-        out["frac_at_measured_clock"] = None          # the clock samples cannot be right: report none rather than > 1
+    # above 1 the instruction model, the issue costs or — for the short kernels of a biprime step, where a 0.3 ms probe can
+    # catch a clock the governor has already lowered — the clock samples are off: the raw value stays, flagged
+    out["clock_sample_inconsistent"] = bool(out["frac_at_measured_clock"] is not None and out["frac_at_measured_clock"] > 1.0)
     out["frac_macs_vs_multiply_issue_peak"] = achieved * share / MAC_ISSUE_PEAK
     out["frac_vs_guide_vector_peak"] = achieved / GUIDE_VECTOR_PEAK
     out["guide_vector_peak"] = GUIDE_VECTOR_PEAK / 1e9
@@ -440,8 +441,8 @@ def time_steps(eng, torch, dist, step_fn, steps: int, warmup: int, nstreams: int
     kernel_total_ms, launches = eng.profile_collect()
     clocks = [eng.clock_probe_mhz(h) for h in probes]
     # (a few samples of 0.3 ms: good to a few per cent for the long launches of the decryption workloads; beside the short
-    # kernels of a biprime step a sample can catch a clock the governor has already lowered — valu_roofline drops a
-    # frac_at_measured_clock above 1 instead of reporting it)
+    # kernels of a biprime step a sample can catch a clock the governor has already lowered — valu_roofline flags a
+    # frac_at_measured_clock above 1 as clock_sample_inconsistent)
     CLOCK["mhz"] = sum(clocks) / len(clocks) if clocks else None
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
@@ -1057,7 +1058,7 @@ def compact_roofline(roof):
     if not isinstance(roof, dict):
         return None
     r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "concurrent_launches", "mac_share",
-                     "frac_at_measured_clock", "shader_clock_mhz_measured", "frac_macs_vs_multiply_issue_peak",
+                     "frac_at_measured_clock", "clock_sample_inconsistent", "shader_clock_mhz_measured", "frac_macs_vs_multiply_issue_peak",
                      "frac_vs_guide_vector_peak", "instructions_per_launch"))
     r["traffic"] = _num(roof.get("traffic"))
     if roof.get("frac") is None:

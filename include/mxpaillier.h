@@ -143,6 +143,18 @@ typedef struct mx_nsquare_plan {
 int64_t mx_nsquare_plan_bytes(int limbs_n, int exp_limbs);
 int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp, int limbs_n,
                               int exp_limbs, void* d_plan, int64_t plan_bytes, void* stream);
+/* The same with options (flags = 0: exactly mx_powmod_nsquare_prepare).
+ * MX_PLAN_FIXED_WINDOW: a fixed-window tape — w squarings and ONE multiplication per w-bit window, a window of zero
+ * bits multiplying by the domain's one — instead of the sliding-window tape, whose runs of squarings and number of
+ * multiplications are a function of the exponent's bits.  The exponent is the party's Lagrange-folded secret share
+ * (PSK:79-85): with this flag the sequence and number of operations a launch executes, hence its duration and the
+ * kernel-trace of a profiler, depend on the exponent's LENGTH only.  The table row a window reads is still selected by
+ * the secret digit (addresses, not timing of the instruction stream).  Cost: 762 instead of 592 pair multiplications
+ * for a 4197-bit exponent (w = 6, the same 64-row table) = +4.5 % instructions.  plan->window then reports w + 1 (the
+ * table region is sized as 2^(window - 1) rows either way).  Same results bit for bit. */
+#define MX_PLAN_FIXED_WINDOW 1
+int mx_powmod_nsquare_prepare_ex(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp, int limbs_n,
+                                 int exp_limbs, int flags, void* d_plan, int64_t plan_bytes, void* stream);
 /* workspace of one run (the table of odd powers of every base; one per launch in flight) */
 int64_t mx_powmod_nsquare_run_workspace_bytes(const mx_nsquare_plan* plan, int64_t batch);
 int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t* d_bases, uint32_t* d_out, int limbs2,
@@ -276,11 +288,6 @@ int mx_select_first(const uint32_t* d_rows, const int8_t* d_flags, uint32_t* d_o
  * Runs the DPP cross-lane primitives against their ds_bpermute reference forms for every group
  * width on the current device; returns the number of mismatching lanes (0 = pass) or MX_ERR_*. */
 int mx_selftest_lanes(void* stream);
-/* Modexp lane geometry: 9 (narrow: more lanes per element, best for one small batch at a time),
- * 18 (wide: fewer, busier lanes; best when the GPU is saturated, e.g. several batches in flight on
- * different streams) or 0 (automatic from the batch size, the default).  Process-wide; only the older entry
- * points without a limbs_per_lane argument read it. */
-int mx_set_limbs_per_lane(int limbs_per_lane);
 /* Developer overrides, explicit calls only (the library reads no environment variables).  value 0 restores
  * the default.  MX_KNOB_N2_SEGMENTS: launches per mx_powmod_nsquare_run exponentiation when the caller passes
  * segments = 0 (1..64).  MX_KNOB_JACOBI_MAX_BATCHES: value v > 0 limits the Jacobi kernel to v - 1 divstep batches
@@ -290,7 +297,10 @@ int mx_set_limbs_per_lane(int limbs_per_lane);
  * workgroups per CU (r = 1..3).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
  * friendly-modulus instances (A/B runs against the plain ones).  MX_KNOB_GENERIC_LATENCY: 1 = the automatic geometry of
  * the generic-modulus modexp never takes the 3-limb latency instances.  MX_KNOB_N2_SPLIT: mx_nsquare_launch_split
- * 1 = never reports a split, 2 = whenever one exists.  Process-wide; returns MX_OK / MX_ERR_ARG. */
+ * 1 = never reports a split, 2 = whenever one exists.  These are the ONLY process-wide settings the library has (ABI 4.0
+ * dropped mx_set_limbs_per_lane: launch shapes are call arguments, the entry points without one leave the choice to the
+ * library); each is an atomic integer, so flipping one while another thread launches is well defined (that launch sees
+ * the old or the new value).  Production callers never need them.  Returns MX_OK / MX_ERR_ARG. */
 #define MX_KNOB_N2_SEGMENTS 1
 #define MX_KNOB_JACOBI_MAX_BATCHES 2
 #define MX_KNOB_N2_TIMESLICE 3
@@ -329,13 +339,13 @@ int mx_geometry(int mod_bits, int* lanes_per_element, int* limbs_per_lane, int* 
 int mx_profile(int enable);
 int mx_profile_collect(double* total_ms, int* launches);
 /* Geometry mx_powmod_nsquare launches for a modulus N of `n_bits` bits and `batch` bases (it depends
- * on the batch: the wide geometry is chosen when one launch brings enough wavefronts, see
- * mx_set_limbs_per_lane); returns MX_OK or MX_ERR_SIZE. */
+ * on the batch: the wide geometry is chosen when one launch brings enough wavefronts); returns MX_OK or
+ * MX_ERR_SIZE. */
 int mx_nsquare_geometry(int n_bits, int64_t batch, int* lanes_per_element, int* limbs_per_lane, int* limb_bits,
                         int* blocks);
 
 /* Geometry for an explicit limbs_per_lane (9 | 18 | 0 = the library's automatic choice for this
- * batch), independent of the process-wide override: of a mx_powmod_nsquare_run launch, and of a
+ * batch): of a mx_powmod_nsquare_run launch, and of a
  * mx_powmod_shared_lpl (groups = 1) / mx_powmod_multi_dev (groups > 1) launch. */
 int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_lane, int* lanes_per_element,
                             int* limbs_per_lane_out, int* limb_bits, int* blocks);

@@ -33,6 +33,8 @@ class CombinePlan(ctypes.Structure):
     ]
 
 
+MX_PLAN_FIXED_WINDOW = 1      # include/mxpaillier.h
+
 _P4 = [POINTER(c_int)] * 4
 
 # name -> (restype, argtypes); every symbol include/mxpaillier.h declares
@@ -49,6 +51,7 @@ SYMBOLS = {
     "mx_powmod_multi_dev": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_int64, c_int, c_void_p, c_int64, c_void_p]),
     "mx_nsquare_plan_bytes": (c_int64, [c_int, c_int]),
     "mx_powmod_nsquare_prepare": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
+    "mx_powmod_nsquare_prepare_ex": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_powmod_nsquare_run_workspace_bytes": (c_int64, [POINTER(NsquarePlan), c_int64]),
     "mx_powmod_nsquare_run": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_nsquare_launch_shape": (c_int, [c_int, c_int64, c_int, c_int, *_P4, POINTER(c_int)]),
@@ -79,7 +82,6 @@ SYMBOLS = {
     "mx_jacobi_workspace_bytes": (c_int64, [c_int, c_int64]),
     "mx_jacobi": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_select_first": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_void_p]),
-    "mx_set_limbs_per_lane": (c_int, [c_int]),
     "mx_selftest_lanes": (c_int, [c_void_p]),
     "mx_debug_knob": (c_int, [c_int, c_int]),
     "mx_spin": (c_int, [c_int64, c_void_p]),

@@ -22,6 +22,18 @@ from __future__ import annotations
 from typing import Any, Dict, List, Sequence
 
 
+def _accepts(fn: Any, keyword: str) -> bool:
+    """Does `fn` take `keyword`?  (Feature detection of an engine's device-resident forms: by signature, so that a
+    TypeError raised INSIDE a real engine call is never mistaken for a missing feature.)"""
+    import inspect
+
+    try:
+        params = inspect.signature(fn).parameters
+    except (TypeError, ValueError):
+        return False
+    return keyword in params or any(p.kind is inspect.Parameter.VAR_KEYWORD for p in params.values())
+
+
 def _engine(engine: Any) -> Any:
     if engine is not None:
         return engine
@@ -220,10 +232,10 @@ class BiprimeRound:
             return {}
         coeffs = shamir.lagrange_coefficients_at_zero(pts, prime, eng)
         columns = [shares_by_party[i] for i in pts]
-        try:
+        if _accepts(eng.shamir_reconstruct_sieve_batch, "keep_rows"):
             self.has_divisor, surviving, self._mods_rows = eng.shamir_reconstruct_sieve_batch(
                 columns, coeffs, prime, list(prime_list), keep_rows=True)
-        except TypeError:                     # an engine without the device-resident form
+        else:                                 # an engine without the device-resident form
             self.has_divisor, surviving = eng.shamir_reconstruct_sieve_batch(columns, coeffs, prime, list(prime_list))
         self.survivors = sorted(surviving)
         self.moduli = [surviving[k] for k in self.survivors]

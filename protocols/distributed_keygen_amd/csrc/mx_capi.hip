@@ -15,13 +15,12 @@
 
 namespace mxh {
 thread_local hipError_t g_last_hip = hipSuccess;
-int g_limbs_per_lane = 0;
-int g_knob_n2_segments = 0;
-int g_knob_n2_timeslice = 0;
-int g_knob_n2_friendly_1w = 0;
-int g_knob_generic_latency = 0;
-int g_knob_n2_split = 0;
-int g_knob_jacobi_max_batches = 0;
+Knob g_knob_n2_segments;
+Knob g_knob_n2_timeslice;
+Knob g_knob_n2_friendly_1w;
+Knob g_knob_generic_latency;
+Knob g_knob_n2_split;
+Knob g_knob_jacobi_max_batches;
 }
 MxProfile g_mx_profile;
 
@@ -276,7 +275,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 303; }
+int mx_version(void) { return 400; }
 
 const char* mx_error_string(int code) {
   switch (code) {
@@ -291,12 +290,6 @@ const char* mx_error_string(int code) {
 }
 
 const char* mx_last_hip_error(void) { return hipGetErrorString(g_last_hip); }
-
-int mx_set_limbs_per_lane(int limbs_per_lane) {
-  if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE && limbs_per_lane != LIMBS_PER_LANE_WIDE) return MX_ERR_ARG;
-  g_limbs_per_lane = limbs_per_lane;
-  return MX_OK;
-}
 
 int mx_debug_knob(int knob, int value) {
   if (value < 0) return MX_ERR_ARG;
@@ -341,8 +334,7 @@ int mx_profile_collect(double* total_ms, int* launches) {
 
 int mx_geometry(int mod_bits, int* k, int* l, int* w, int* blocks) {
   Geometry g;
-  int lpl = (override_limbs_per_lane() == LIMBS_PER_LANE_WIDE) ? LIMBS_PER_LANE_WIDE : LIMBS_PER_LANE;
-  if (!choose_geometry(mod_bits, g, lpl)) return MX_ERR_SIZE;
+  if (!choose_geometry(mod_bits, g, LIMBS_PER_LANE)) return MX_ERR_SIZE;
   if (k) *k = g.K;
   if (l) *l = g.L;
   if (w) *w = g.W;
@@ -366,7 +358,7 @@ int64_t mx_powmod_workspace_bytes(int limbs, int exp_limbs, int64_t batch, int64
 int mx_powmod_shared(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
                      int limbs, int exp_limbs, int64_t batch, void* d_workspace, int64_t workspace_bytes,
                      void* stream) {
-  return powmod_impl(d_bases, d_out, h_mod, h_exp, limbs, exp_limbs, 1, batch, override_limbs_per_lane(),
+  return powmod_impl(d_bases, d_out, h_mod, h_exp, limbs, exp_limbs, 1, batch, 0,
                      d_workspace, workspace_bytes, stream);
 }
 
@@ -382,7 +374,7 @@ int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_
                     int limbs, int exp_limbs, int64_t groups, int64_t group_size, void* d_workspace,
                     int64_t workspace_bytes, void* stream) {
   return powmod_impl(d_bases, d_out, h_mods, h_exps, limbs, exp_limbs, groups, group_size,
-                     override_limbs_per_lane(), d_workspace, workspace_bytes, stream);
+                     0, d_workspace, workspace_bytes, stream);
 }
 
 int mx_powmod_multi_dev(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* d_mods, const uint32_t* d_exps,

@@ -334,7 +334,7 @@ extern "C" int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_
 }
 
 extern "C" int mx_nsquare_geometry(int n_bits, int64_t batch, int* k, int* l, int* w, int* blocks) {
-  return mx_nsquare_geometry_for(n_bits, batch, override_limbs_per_lane(), k, l, w, blocks);
+  return mx_nsquare_geometry_for(n_bits, batch, 0, k, l, w, blocks);
 }
 
 extern "C" int64_t mx_nsquare_plan_bytes(int limbs_n, int exp_limbs) {
@@ -344,7 +344,26 @@ extern "C" int64_t mx_nsquare_plan_bytes(int limbs_n, int exp_limbs) {
 
 extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp,
                                          int limbs_n, int exp_limbs, void* d_plan, int64_t plan_bytes, void* stream) {
+  return mx_powmod_nsquare_prepare_ex(plan, h_n, h_exp, limbs_n, exp_limbs, 0, d_plan, plan_bytes, stream);
+}
+
+// Width of the fixed-window schedule (MX_PLAN_FIXED_WINDOW): every window costs a multiplication, so narrower windows
+// than the sliding schedule's pay; the table holds x^1 .. x^(2^w - 1) (digit 0 multiplies by the domain's one).
+static int fixed_window_n2(int exp_bits) {
+  int best = 1;
+  long bestc = -1;
+  for (int w = 1; w <= 7; ++w) {
+    const long c = (exp_bits + w - 1) / w + (1L << w) - 2;
+    if (bestc < 0 || c < bestc) { bestc = c; best = w; }
+  }
+  return best;
+}
+
+extern "C" int mx_powmod_nsquare_prepare_ex(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp,
+                                            int limbs_n, int exp_limbs, int flags, void* d_plan, int64_t plan_bytes,
+                                            void* stream) {
   if (!plan || !h_n || !h_exp || !d_plan) return MX_ERR_ARG;
+  if (flags & ~MX_PLAN_FIXED_WINDOW) return MX_ERR_ARG;
   if (limbs_n <= 0 || exp_limbs <= 0) return MX_ERR_ARG;
   if (!(h_n[0] & 1u)) return MX_ERR_MODULUS;
   const int bits = bit_length(h_n, limbs_n);
@@ -372,6 +391,28 @@ extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* 
   };
   if (ebits == 0) {
     emit(mx::N2_LOAD, mx::N2_SLOT_ONE);
+  } else if (flags & MX_PLAN_FIXED_WINDOW) {
+    // Fixed windows of fw bits from the least significant end: the SEQUENCE of operations — fw squarings and one
+    // multiplication per window, whatever the digits — depends on the exponent's bit length only, not on its bits
+    // (the sliding schedule's run lengths and multiplication count do).  Which table row a window reads still does.
+    const int fw = fixed_window_n2(ebits);
+    auto digit = [&](int d) {
+      u32 v = 0;
+      for (int b = fw - 1; b >= 0; --b) {
+        const int i = d * fw + b;
+        v = (v << 1) | ((i < 32 * exp_limbs) ? ((h_exp[i >> 5] >> (i & 31)) & 1u) : 0u);
+      }
+      return (int)v;
+    };
+    auto slot_of = [&](int dg) { return dg ? mx::N2_SLOT_TABLE + dg - 1 : mx::N2_SLOT_ONE; };
+    emit(mx::N2_LOAD, mx::N2_SLOT_LO); emit(mx::N2_MUL, mx::N2_SLOT_K1); emit(mx::N2_STORE, mx::N2_SLOT_TMP);
+    emit(mx::N2_LOAD, mx::N2_SLOT_HI); emit(mx::N2_MUL, mx::N2_SLOT_K2); emit(mx::N2_ADD, mx::N2_SLOT_TMP);
+    emit(mx::N2_STORE, mx::N2_SLOT_TABLE);
+    for (int t = 2; t < (1 << fw); ++t) { emit(mx::N2_MUL, mx::N2_SLOT_TABLE); emit(mx::N2_STORE, mx::N2_SLOT_TABLE + t - 1); }
+    const int nwin = (ebits + fw - 1) / fw;
+    emit(mx::N2_LOAD, slot_of(digit(nwin - 1)));
+    for (int d = nwin - 2; d >= 0; --d) { emit(mx::N2_SQR, fw); emit(mx::N2_MUL, slot_of(digit(d))); }
+    w = fw + 1;                              // the table region: 2^(w - 1) = 2^fw pair slots (one more than used)
   } else {
     w = sliding_window(ebits);
     std::vector<SlidingOp> ops = sliding_schedule(h_exp, exp_limbs, w);
@@ -532,6 +573,6 @@ extern "C" int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const
   }
   mx_nsquare_plan plan;
   MX_TRY(mx_powmod_nsquare_prepare(&plan, h_n, h_exp, limbs_n, exp_limbs, d_ws, pb, stream));
-  return mx_powmod_nsquare_run(&plan, d_bases, d_out, limbs2, batch, override_limbs_per_lane(), 0, 0,
+  return mx_powmod_nsquare_run(&plan, d_bases, d_out, limbs2, batch, 0, 0, 0,
                                (char*)d_ws + pb, ws_bytes - pb, stream);
 }

@@ -6,6 +6,7 @@
 #include <vector>
 #include <string>
 #include <cstdlib>
+#include <atomic>
 #include "../../../include/mxpaillier.h"
 
 namespace mxh {
@@ -194,21 +195,22 @@ inline std::vector<u32> pack_sliding_ops(const std::vector<SlidingOp>& ops) {
   return out;
 }
 
-// Limbs per lane (9 narrow / 18 wide) are a per-call argument of the entry points that end in _lpl,
-// _dev or _run.  The older entry points without that argument honour a process-wide override
-// (mx_set_limbs_per_lane); 0 = automatic.  The library reads NO environment variables: developer
-// overrides are explicit calls (mx_debug_knob), so a stray variable cannot change a production launch.
-extern int g_limbs_per_lane;
-extern int g_knob_n2_segments;        // MX_KNOB_N2_SEGMENTS: 0 = automatic
-extern int g_knob_n2_timeslice;       // MX_KNOB_N2_TIMESLICE: 0 = automatic, 1 = never, 2 = always (two-wavefront launches)
-extern int g_knob_n2_friendly_1w;     // MX_KNOB_N2_FRIENDLY_1W: 0 = friendly-modulus instances of the one-wavefront wide kernel where they exist, 1 = never
-extern int g_knob_n2_split;           // MX_KNOB_N2_SPLIT: 0 = mx_nsquare_launch_split reports a split where it pays, 1 = never, 2 = whenever a split exists
-extern int g_knob_generic_latency;    // MX_KNOB_GENERIC_LATENCY: 0 = the automatic choice may take the 3-limb instances of the generic kernel, 1 = never
-extern int g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
-inline int override_limbs_per_lane() {
-  if (g_limbs_per_lane == LIMBS_PER_LANE || g_limbs_per_lane == LIMBS_PER_LANE_WIDE) return g_limbs_per_lane;
-  return 0;
-}
+// Limbs per lane (3 latency / 9 narrow / 18 wide) and the other launch-shape choices are per-call ARGUMENTS of the
+// entry points; the entry points without such an argument leave the choice to the library.  The library reads NO
+// environment variable and keeps no tuning state that a production caller can set: what remains process-wide are the
+// developer knobs below (explicit mx_debug_knob calls, for A/B runs and for tests that must reach a fallback path), held
+// in atomics so that a knob flipped by one thread while another launches is a defined read of the old or the new value.
+struct Knob {
+  std::atomic<int> v{0};
+  operator int() const { return v.load(std::memory_order_relaxed); }
+  Knob& operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
+};
+extern Knob g_knob_n2_segments;        // MX_KNOB_N2_SEGMENTS: 0 = automatic
+extern Knob g_knob_n2_timeslice;       // MX_KNOB_N2_TIMESLICE: 0 = automatic, 1 = never, 2 = always (two-wavefront launches)
+extern Knob g_knob_n2_friendly_1w;     // MX_KNOB_N2_FRIENDLY_1W: 0 = friendly-modulus instances of the one-wavefront wide kernel where they exist, 1 = never
+extern Knob g_knob_n2_split;           // MX_KNOB_N2_SPLIT: 0 = mx_nsquare_launch_split reports a split where it pays, 1 = never, 2 = whenever a split exists
+extern Knob g_knob_generic_latency;    // MX_KNOB_GENERIC_LATENCY: 0 = the automatic choice may take the 3-limb instances of the generic kernel, 1 = never
+extern Knob g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 

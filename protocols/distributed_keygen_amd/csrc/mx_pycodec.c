@@ -103,17 +103,24 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
     PyErr_SetString(PyExc_ValueError, "buffer too small for the rows");
     goto fail;
   }
+  if (((uintptr_t)out.buf & 3u) != 0) {
+    PyErr_SetString(PyExc_ValueError, "rows must be 4-byte aligned");
+    goto fail;
+  }
   {
     uint32_t* dst = (uint32_t*)((unsigned char*)out.buf + row_offset * nbytes);
     const int nt = usable_threads(n, 1024);
     PackJob jobs[16];
     pthread_t tid[16];
     int started[16] = {0};
-    /* a private copy of the element pointers: the list may be resized by another thread while the lock is released
-     * (its elements must stay alive for the duration of the call — they are the caller's values) */
+    /* a private copy of the element pointers, each with a reference of its own: another thread may resize, clear or
+     * overwrite the list while the lock is released, and the workers read the objects' headers and digits */
     PyObject** items = (PyObject**)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(PyObject*));
     if (!items) { PyErr_NoMemory(); goto fail; }
-    memcpy(items, PySequence_Fast_ITEMS(fast), (size_t)n * sizeof(PyObject*));
+    {
+      PyObject** src = PySequence_Fast_ITEMS(fast);
+      for (Py_ssize_t i = 0; i < n; ++i) { items[i] = src[i]; Py_INCREF(items[i]); }
+    }
     Py_BEGIN_ALLOW_THREADS
     for (int t = 0; t < nt; ++t) {
       jobs[t].items = items; jobs[t].dst = dst; jobs[t].limbs = limbs;
@@ -126,6 +133,7 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
       else pack_worker(&jobs[t]); /* thread creation failed: this thread does the slice */
     }
     Py_END_ALLOW_THREADS
+    for (Py_ssize_t i = 0; i < n; ++i) Py_DECREF(items[i]);
     PyMem_Free(items);
     for (int t = 0; t < nt; ++t) {
       if (jobs[t].bad_kind == 1) { PyErr_SetString(PyExc_TypeError, "values must be ints"); goto fail; }
@@ -256,6 +264,10 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
   const Py_ssize_t nbytes = 4 * limbs;
   if (limbs <= 0 || row_offset < 0 || (row_offset + n) * nbytes > out.len) {
     PyErr_SetString(PyExc_ValueError, "buffer too small for the rows");
+    goto fail;
+  }
+  if (((uintptr_t)out.buf & 3u) != 0) {
+    PyErr_SetString(PyExc_ValueError, "rows must be 4-byte aligned");
     goto fail;
   }
   unsigned char* dst = (unsigned char*)out.buf + row_offset * nbytes;

@@ -122,7 +122,8 @@ class Engine:
         self._lpl = 0                          # lane geometry of this engine's modexp launches (0 = automatic)
         self._wpg = 0                          # wavefronts per group of the N^2 pair kernel (0 = automatic, 1, 2)
         self._segments = 0                     # launches per N^2 exponentiation (0 = automatic; include/mxpaillier.h)
-        self._n2_plans: "OrderedDict[Tuple[int, int], _Plan]" = OrderedDict()
+        self._fixed_window = False             # tapes of new N^2 plans: fixed windows (secret-independent schedule) instead of sliding ones
+        self._n2_plans: "OrderedDict[Tuple[int, int, bool], _Plan]" = OrderedDict()
         self._combine_plans: "OrderedDict[Tuple[int, int, int], _Plan]" = OrderedDict()
         self._side_streams: List[Any] = []     # chunked int-level batches (_pipelined): streams verified concurrent
         self._side_streams_capped = False      # the process has fewer concurrent queues than chunks were wanted
@@ -178,8 +179,9 @@ class Engine:
 
     def set_limbs_per_lane(self, limbs_per_lane: int) -> None:
         """Lane geometry of this engine's modexp launches: 0 = automatic (from the batch size), 9 =
-        narrow, 18 = wide, 3 = the latency geometry of the N^2 pair kernel (two wavefronts per group; the
-        generic-modulus kernels treat it as automatic).  Passed with every call (no process-wide state)."""
+        narrow, 18 = wide, 3 = the latency geometry (the N^2 pair kernel: two wavefronts per group, any key
+        length; the generic-modulus kernels: moduli up to 5533 bits, wider ones fall back to the automatic
+        choice).  Passed with every call (no process-wide state)."""
         if limbs_per_lane not in (0, 3, 9, 18):
             raise ValueError("limbs_per_lane must be 0, 3, 9 or 18")
         self._lpl = int(limbs_per_lane)
@@ -192,7 +194,15 @@ class Engine:
             raise ValueError("wavefronts per group must be 0, 1 or 2")
         self._wpg = int(wavefronts)
 
-    def _lpl_generic(self) -> int:
+    GENERIC_LATENCY_MAX_BITS = 29 * 3 * 64 - 4 - 31      # 5533: widest modulus with a 3-limb generic instance (mx_host.hpp: choose_geometry)
+
+    def _lpl_generic(self, mod_bits: int = 0) -> int:
+        """The engine's lane geometry as the generic-modulus kernels take it.  The latency geometry (3) exists for the
+        N^2 pair kernel at every key length but for a GENERIC modulus only up to 5533 bits: an engine tuned with
+        set_limbs_per_lane(3) for low-latency decryptions leaves wider generic launches (N^2 of key_length 4096 through
+        powmod_batch, say) to the library's automatic choice instead of failing with MX_ERR_SIZE."""
+        if self._lpl == 3 and mod_bits > self.GENERIC_LATENCY_MAX_BITS:
+            return 0
         return self._lpl if self._lpl in (3, 9, 18) else 0
 
     def set_segments(self, segments: int) -> None:
@@ -200,6 +210,14 @@ class Engine:
         if not 0 <= segments <= 64:
             raise ValueError("segments must be 0..64")
         self._segments = int(segments)
+
+    def set_fixed_window(self, enable: bool) -> None:
+        """Partial decryptions (powmod_nsquare_*) with a FIXED-window tape (MX_PLAN_FIXED_WINDOW, include/mxpaillier.h): the
+        number and order of the squarings and multiplications of a launch then depend on the exponent's bit length
+        only — the exponent is the party's secret share folded with its Lagrange coefficient (PSK:79-85), and the default
+        sliding-window tape is a function of its bits, like gmpy2's mpz_powm.  +4.5 % instructions at key_length 2048;
+        the table row a window reads is still chosen by the secret digit.  Same results bit for bit."""
+        self._fixed_window = bool(enable)
 
     def set_priority_aux(self, enable: bool) -> None:
         """With several launches in flight on several streams, the small kernels of a step (recombination,
@@ -238,7 +256,7 @@ class Engine:
         import ctypes
 
         k, l, w, b = (ctypes.c_int() for _ in range(4))
-        _lib.check(self.lib.mx_powmod_geometry_for(mod_bits, batch, groups, self._lpl_generic(), k, l, w, b), "mx_powmod_geometry_for")
+        _lib.check(self.lib.mx_powmod_geometry_for(mod_bits, batch, groups, self._lpl_generic(mod_bits), k, l, w, b), "mx_powmod_geometry_for")
         return k.value, l.value, w.value, b.value
 
     def debug_knob(self, knob: str, value: int) -> None:
@@ -332,7 +350,8 @@ class Engine:
     def nsquare_launch_split(self, n_bits: int, batch: int) -> Optional[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
         """(rows of the first launch, its shape, the shape of the rest) when ONE powmod_nsquare batch of this size is
         better run as two launches side by side (mx_nsquare_launch_split) and this engine's settings leave the choice to
-        the library; None otherwise."""
+        the library; None otherwise.  powmod_nsquare_t follows the hint unless the caller fixed the shape or asked for
+        more than one segment (both parts run as single launches); with profile() on, the two launches count as two."""
         import ctypes
 
         if self._lpl or self._wpg:
@@ -385,7 +404,7 @@ class Engine:
             ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, 1))
             rc = self.lib.mx_powmod_shared_lpl(
                 bases_t.data_ptr(), out_t.data_ptr(), h_mod.ctypes.data, h_exp.ctypes.data,
-                limbs, elimbs, batch, self._lpl_generic(), ws.data_ptr(), ws.numel(), self._stream_ptr(),
+                limbs, elimbs, batch, self._lpl_generic(mod.bit_length()), ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_shared_lpl")
         return out_t
@@ -417,7 +436,7 @@ class Engine:
             ws = self._workspace(self.lib.mx_powmod_workspace_bytes(limbs, elimbs, batch, groups))
             rc = self.lib.mx_powmod_multi_dev(
                 bases_t.data_ptr(), out_t.data_ptr(), mods_t.data_ptr(), exps_t.data_ptr(),
-                limbs, elimbs, mod_bits, exp_bits, groups, group_size, self._lpl_generic(), ws.data_ptr(), ws.numel(),
+                limbs, elimbs, mod_bits, exp_bits, groups, group_size, self._lpl_generic(mod_bits), ws.data_ptr(), ws.numel(),
                 self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_multi_dev")
@@ -428,7 +447,7 @@ class Engine:
     def nsquare_plan(self, n: int, exp: int) -> _Plan:
         """The plan of `x -> x^exp mod n^2` (constants and tape of mx_powmod_nsquare_prepare), cached:
         (n, exp) is a key's public modulus and the party's Lagrange-folded share (PSK:46, PSK:79-85)."""
-        key = (n, exp)
+        key = (n, exp, self._fixed_window)
         plan = self._n2_plans.get(key)
         if plan is not None:
             self._n2_plans.move_to_end(key)
@@ -444,11 +463,11 @@ class Engine:
         with self.torch.cuda.device(self.device):
             nbytes = _lib.check(self.lib.mx_nsquare_plan_bytes(limbs_n, elimbs), "mx_nsquare_plan_bytes")
             block = self.torch.empty(int(nbytes), dtype=self.torch.uint8, device=self.device)
-            rc = self.lib.mx_powmod_nsquare_prepare(
-                desc, h_n.ctypes.data, h_exp.ctypes.data, limbs_n, elimbs, block.data_ptr(), block.numel(),
-                self._stream_ptr(),
+            rc = self.lib.mx_powmod_nsquare_prepare_ex(
+                desc, h_n.ctypes.data, h_exp.ctypes.data, limbs_n, elimbs, _lib.MX_PLAN_FIXED_WINDOW if self._fixed_window else 0,
+                block.data_ptr(), block.numel(), self._stream_ptr(),
             )
-            _lib.check(rc, "mx_powmod_nsquare_prepare")
+            _lib.check(rc, "mx_powmod_nsquare_prepare_ex")
             ready = self.torch.cuda.Event()
             ready.record(self.torch.cuda.current_stream(self.device))
         plan = _Plan(desc, block, self._stream_ptr(), ready)
@@ -506,7 +525,11 @@ class Engine:
         plan = self.nsquare_plan(n, exp)
         if out_t is None:
             out_t = self.torch.empty_like(bases_t)
-        split = self.nsquare_launch_split(n.bit_length(), batch) if shape is None and bases_t.is_contiguous() and out_t.is_contiguous() else None
+        # (the split form runs both parts as single launches: an explicit number of segments — the `segments` argument
+        # or Engine.set_segments() above 1 — only has a meaning in the one-launch form and disables the split)
+        split = None
+        if shape is None and segments in (None, 0, 1) and self._segments in (0, 1) and bases_t.is_contiguous() and out_t.is_contiguous():
+            split = self.nsquare_launch_split(n.bit_length(), batch)
         if split is not None:
             # one batch just above a capacity step of the wide two-wavefront shape: the part that fills the CUs once in
             # that shape on this stream, the rest at 9 limbs per lane on a companion stream at the same time
@@ -1135,9 +1158,8 @@ class Engine:
         groups = len(mods)
         if groups == 0:
             return ([], None) if keep_rows else []
-        if mods_rows is None:
-            for m in mods:
-                _check_modulus(m)
+        for m in mods:          # the int moduli are passed either way: an even N reconstructed from malformed shares (the
+            _check_modulus(m)   # sieve's list starts at 3) must raise here, not reach the Montgomery and Jacobi kernels
         gsize = max(len(g) for g in g_values)
         if gsize == 0 or keep == 0:
             return ([[] for _ in mods], None) if keep_rows else [[] for _ in mods]
@@ -1304,9 +1326,8 @@ class Engine:
             return []
         if n_slots == 0:
             return [[] for _ in mods]
-        if mods_rows is None:
-            for m in mods:
-                _check_modulus(m)
+        for m in mods:
+            _check_modulus(m)
         limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
         torch = self.torch
         parts = []

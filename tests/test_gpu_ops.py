@@ -680,3 +680,27 @@ def test_cu_slice_streams_run_small_launches_side_by_side(eng):
     want = [pow(b, e, n2) for b in bases]
     for out in outs:
         assert L.unpack(eng.to_host(out)) == want
+
+
+def test_latency_geometry_setting_falls_back_for_wide_generic_moduli(eng):
+    """an engine tuned with set_limbs_per_lane(3) for low-latency N^2 decryptions must still take
+    generic moduli wider than the 3-limb generic instances exist for (5533 bits) — N^2 of key_length 4096 through
+    powmod_batch / powmod_batch_multi — by leaving those launches to the automatic geometry, and must run the latency
+    instances where they exist."""
+    rng = random.Random(8200)
+    eng.set_limbs_per_lane(3)
+    try:
+        mod = rng.getrandbits(8200) | (1 << 8199) | 1
+        exp = rng.getrandbits(300)
+        bases = [rng.randrange(mod) for _ in range(5)]
+        assert eng.geometry(8200, 5, 1)[1] in (9, 18)
+        assert eng.powmod_batch(bases, exp, mod) == [pow(b, exp, mod) for b in bases]
+        mods = [rng.getrandbits(5600) | (1 << 5599) | 1 for _ in range(2)]
+        exps = [rng.getrandbits(200) for _ in mods]
+        groups = [[rng.randrange(m) for _ in range(3)] for m in mods]
+        assert eng.powmod_batch_multi(groups, exps, mods) == [[pow(b, e, m) for b in bs] for bs, e, m in zip(groups, exps, mods)]
+        small = rng.getrandbits(2053) | (1 << 2052) | 1
+        assert eng.geometry(2053, 5, 1)[1] == 3
+        assert eng.powmod_batch(bases[:3], exp, small) == [pow(b % small, exp, small) for b in bases[:3]]
+    finally:
+        eng.set_limbs_per_lane(0)

@@ -343,3 +343,51 @@ def test_powmod_nsquare_split_launch_is_bit_identical(eng):
         eng.debug_knob("n2_split", 0)
         eng.set_limbs_per_lane(0)
         eng.set_wavefronts_per_group(0)
+
+
+def test_fixed_window_tape_is_bit_identical_and_secret_independent_in_shape(eng):
+    """MX_PLAN_FIXED_WINDOW: the tape of a partial decryption with fixed windows — one multiplication
+    per window whatever the digits, zero windows multiplying by the domain's one — gives the same results as the
+    sliding-window tape in every launch shape and with segments, and its operation counts are a function of the
+    exponent's LENGTH only (two exponents of one length with very different bits: identical counts; the sliding tape
+    differs between them)."""
+    rng = random.Random(4197)
+    n = rng.getrandbits(1027) | (1 << 1026) | 1
+    n2 = n * n
+    bases = [0, 1, n, n + 1, n2 - 1] + [rng.randrange(n2) for _ in range(28)]
+    e_dense = (1 << 900) - 1                                  # all ones
+    e_sparse = (1 << 899) | 1                                 # two ones, 898 zero bits between them
+    e_random = rng.getrandbits(900) | (1 << 899)
+    e_zero_windows = ((rng.getrandbits(300) | (1 << 299)) << 600) | rng.getrandbits(100)      # a long run of zero windows
+    try:
+        eng.set_fixed_window(True)
+        shapes = {e: (eng.nsquare_plan(n, e).desc.n_sqr, eng.nsquare_plan(n, e).desc.n_mul, eng.nsquare_plan(n, e).desc.ntape)
+                  for e in (e_dense, e_sparse, e_random, e_zero_windows)}
+        assert len(set(shapes.values())) == 1, shapes           # schedule = f(bit length) only
+        for lpl, wpg, seg in ((0, 0, 0), (9, 1, 1), (18, 1, 4), (3, 2, 1), (9, 2, 3), (18, 2, 1)):
+            eng.set_limbs_per_lane(lpl)
+            eng.set_wavefronts_per_group(wpg)
+            eng.set_segments(seg)
+            for e in (e_dense, e_sparse, e_random, e_zero_windows, 5, 1, 0, (1 << 64) + 1):
+                assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n2) for b in bases], (lpl, wpg, seg, e.bit_length())
+        eng.set_fixed_window(False)
+        sliding = {e: eng.nsquare_plan(n, e).desc.n_mul for e in (e_dense, e_sparse)}
+        assert sliding[e_dense] != sliding[e_sparse]            # the default tape does depend on the bits
+        fixed_cost = shapes[e_dense][1]
+        assert sliding[e_sparse] < fixed_cost                   # and is never dearer
+    finally:
+        eng.set_fixed_window(False)
+        eng.set_segments(0)
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
+    # key_length 2048 at the headline's exponent length: the cost the header states (762 vs ~592 multiplications)
+    key_n = rng.getrandbits(2051) | (1 << 2050) | 1
+    e = rng.getrandbits(4197) | (1 << 4196)
+    cts = [rng.randrange(key_n * key_n) for _ in range(9)]
+    try:
+        eng.set_fixed_window(True)
+        d = eng.nsquare_plan(key_n, e).desc
+        assert d.window == 7 and 755 <= d.n_mul <= 770 and d.n_sqr <= 4197
+        assert eng.powmod_nsquare_batch(cts, e, key_n) == [pow(c, e, key_n * key_n) for c in cts]
+    finally:
+        eng.set_fixed_window(False)

@@ -32,7 +32,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     # ABI 3.0: mx_powmod_nsquare_run gained wavefronts_per_group, mx_nsquare_plan.geometries; 3.1: mx_nsquare_launch_timesliced;
     # 3.2: mx_nsquare_launch_instance, MX_KNOB_N2_FRIENDLY_1W; 3.3: limbs_per_lane 3 for the generic kernel,
     # mx_nsquare_launch_split, MX_KNOB_GENERIC_LATENCY / MX_KNOB_N2_SPLIT
-    assert lib.mx_version() == 303
+    # 4.0: mx_set_limbs_per_lane removed (no process-wide launch-shape state), knobs atomic, mx_powmod_nsquare_prepare_ex
+    # with MX_PLAN_FIXED_WINDOW
+    assert lib.mx_version() == 400
     assert lib.mx_error_string(-3).decode().startswith("modulus")
 
 
@@ -269,7 +271,7 @@ def test_c_abi_status_codes_without_gpu():
     assert lib.mx_jacobi(fake, fake, p(even), 8, 1, 4, fake, 1 << 30, None) == -3
     assert lib.mx_jacobi(fake, fake, p(mod), 258, 1, 4, fake, 1 << 30, None) == -2
     assert lib.mx_mulmod_shared(fake, fake, fake, p(even), 8, 4, fake, 1 << 30, None) == -3
-    assert lib.mx_set_limbs_per_lane(7) == -1 and lib.mx_set_limbs_per_lane(0) == 0
+    assert not hasattr(lib, "mx_set_limbs_per_lane")                 # ABI 4.0: no process-wide launch-shape setting
     # developer knobs, probes and CU-slice streams: argument checks come before any HIP call
     import ctypes
 
@@ -650,3 +652,15 @@ def test_sieve_columns_never_overflow_64_bits_with_the_hosts_chunk():
                     if not worst:
                         n = sum(c << (32 * j) for j, c in enumerate(cand))
                         assert acc % l == n % l, (top, limbs, l)
+
+
+def test_latency_geometry_is_passed_to_generic_launches_only_where_it_exists():
+    """Engine._lpl_generic — 3 limbs per lane for generic moduli up to 5533 bits, automatic beyond."""
+    from protocols.distributed_keygen_amd.engine import Engine
+
+    e = Engine.__new__(Engine)          # no GPU: only the setting and the rule
+    e._lpl = 3
+    assert e._lpl_generic(2053) == 3 and e._lpl_generic(5533) == 3 and e._lpl_generic(5534) == 0 and e._lpl_generic(8200) == 0
+    for lpl in (0, 9, 18):
+        e._lpl = lpl
+        assert e._lpl_generic(8200) == lpl and e._lpl_generic(1029) == lpl
