@@ -1035,6 +1035,85 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
 
 
 # ---------------------------------------------------------------------------------------------------
+# The short kernels of the path: rate and issue fraction, each at the shape it has in a full-size
+# step.  Instruction counts per launch come from a counter pass of THIS function (tools/short_kernels.py:
+# rocprofv3 --pmc SQ_INSTS_VALU), committed as profiles/r05_short_kernels.json; the durations are measured live.
+# ---------------------------------------------------------------------------------------------------
+SHORT_KERNELS = ROOT / "profiles" / "r05_short_kernels.json"
+PLAIN_ISSUE_PEAK = SIMDS * NOMINAL_HZ / OTHER_CYCLES
+
+
+def short_kernel_cases(eng, torch):
+    """([(name, kernel-name substring, units, unit, callable)], operands to keep alive); every operand is resident on
+    the device before the first call."""
+    import sympy
+
+    from protocols.distributed_keygen_amd import limbs as L
+
+    bp = BiprimeWorkload(eng, 2048, 5, 4096, seed=0xD15C0 + 3)
+    rng = random.Random(0x5EED)
+    limbs = bp.limbs
+    primes = [int(q) for q in sympy.primerange(3, 2001)]            # prime_threshold 2000 (DK:85)
+    cands = [(rng.getrandbits(2053) | (1 << 2052) | 1) for _ in range(65536)]
+    cands_t = eng.to_device(L.pack(cands, limbs))
+    sieve_out = torch.empty(len(cands), dtype=torch.uint8, device=eng.device)
+    jac_out = torch.empty(bp.cands * bp.GENS, dtype=torch.int8, device=eng.device)
+    verdict = torch.empty((bp.cands, bp.KEEP), dtype=torch.uint8, device=eng.device)
+    dw = DecryptWorkload(eng, 2048, 10000, 0, False)
+    msg = torch.empty((dw.batch, dw.limbs), dtype=torch.int32, device=eng.device)
+    status = torch.zeros(dw.batch, dtype=torch.uint8, device=eng.device)
+    prime_p = int(sympy.nextprime(1 << (2 * (1024 + 3))))               # the Shamir prime of a 5-party key_length-2048 keygen (DK:647-651)
+    sh_limbs = L.limbs_for(prime_p)
+    base_col = [rng.randrange(prime_p) for _ in range(4096)]
+    share_cols = torch.stack([eng.to_device(L.pack(base_col[k:] + base_col[:k], sh_limbs)).repeat(16, 1) for k in range(5)])
+    coeffs = [rng.randrange(prime_p) for _ in range(5)]
+    cases = [
+        ("jacobi", "jacobi_kernel", bp.cands * bp.GENS, "symbols", lambda: eng.jacobi_t(bp.g_t, bp.mods_op, bp.GENS, out_t=jac_out)),
+        ("sieve", "sieve_kernel", len(cands), "candidates", lambda: eng.sieve_t(cands_t, primes, out_t=sieve_out)),
+        ("combine", "combine_kernel", dw.batch, "ciphertexts",
+         lambda: eng.combine_t(dw.partials_t, dw.n, dw.theta_inv, out_t=msg, status_t=status)),
+        ("verdict", "verdict_kernel", bp.cands * bp.KEEP, "slots", lambda: eng.biprime_verdict_t(bp.v_all, bp.mods_op, pass_t=verdict)),
+        ("lincomb", "lincomb_kernel", int(share_cols.shape[1]), "candidates", lambda: eng.shamir_lincomb_t(share_cols, coeffs, prime_p)),
+    ]
+    return cases, (bp, dw, cands_t, share_cols, sieve_out, jac_out, verdict, msg, status)
+
+
+def leg_short_kernels(eng, torch, reps: int = 8) -> dict:
+    counts = _load_json(SHORT_KERNELS) or {}
+    cases, keep_alive = short_kernel_cases(eng, torch)
+    eng.set_priority_aux(False)
+    out = {}
+    for name, kernel, units, unit, fn in cases:
+        fn()
+        torch.cuda.synchronize()
+        t0, t1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        t0.record()
+        for _ in range(reps):
+            fn()
+        t1.record()
+        torch.cuda.synchronize()
+        ms = t0.elapsed_time(t1) / reps
+        row = {"kernel": kernel, "ms_per_launch": ms, "value": units / (ms * 1e-3), "unit": f"{unit}/s", "units_per_launch": units}
+        c = counts.get(name)
+        if c and c.get("units_per_launch") == units:
+            instr = c["valu_instructions_per_launch"]
+            row["roofline"] = {
+                "bound": "valu-issue", "instructions_per_launch": instr, "waves_per_launch": c.get("waves_per_launch"),
+                "achieved": instr / (ms * 1e-3) / 1e9, "unit": "G VALU wave-instructions/s",
+                # the instruction mix of these kernels is not calibrated per class: the plain-VALU issue rate (2.28 cycles per
+                # instruction and SIMD) is the roof of a multiply-free stream, the multiply issue rate (4.19) that of a pure
+                # multiply stream; the roof of the real mix lies between the two
+                "peak": PLAIN_ISSUE_PEAK / 1e9, "frac": instr / (ms * 1e-3) / PLAIN_ISSUE_PEAK,
+                "frac_if_all_multiplies": instr / (ms * 1e-3) / MAC_ISSUE_PEAK,
+                "kernel_ms_in_counter_pass": c.get("kernel_ms"), "source": SHORT_KERNELS.name,
+            }
+        out[name] = row
+    del keep_alive
+    torch.cuda.empty_cache()
+    return out
+
+
+# ---------------------------------------------------------------------------------------------------
 # The result: ONE compact JSON line on stdout (the driver keeps the last 8 KB of stdout and parses the last line;
 # round 3's 31.6 KB line left BENCH_r03.parsed null), every detail in bench_extras.json beside this file.
 # ---------------------------------------------------------------------------------------------------
@@ -1117,8 +1196,19 @@ def compact_result(out: dict) -> dict:
         summary[name] = _leg_summary(leg)
         if isinstance(leg, dict) and leg.get("n_gpus", 1) > 1:
             summary[name]["n_gpus"] = leg["n_gpus"]
+    sk = out.get("short_kernels")
+    if isinstance(sk, dict):
+        summary["short_kernels"] = ({"error": str(sk["error"])[:80]} if "error" in sk else
+                                    {name: _leg_summary(row) for name, row in sk.items()})
     if summary:
         line["extra_summary"] = summary
+    # north_star's second target (biprimality-test modexps/s >= 10x gmpy2) as flat top-level scalars: the driver's record
+    # keeps top-level fields, not the nested summaries
+    bp = (out.get("extra") or {}).get("biprime_k2048")
+    if isinstance(bp, dict) and "error" not in bp:
+        line["biprime_modexps_per_s"] = _num(bp.get("value"), 5)
+        line["biprime_roofline_frac"] = _num((bp.get("roofline") or {}).get("frac"), 4)
+        line["biprime_cpu_baseline_modexps_per_s"] = _num((bp.get("cpu_baseline") or {}).get("value"), 5)
     line["details"] = EXTRAS_FILE.name
     return line
 
@@ -1128,10 +1218,10 @@ def result_line(out: dict) -> str:
     not fit — it never exceeds LINE_LIMIT."""
     line = compact_result(out)
     text = json.dumps(line, separators=(",", ":"))
-    for drop in (("extra_summary",), ("distributed",)):
+    for drop in (("extra_summary",), ("distributed",), ("biprime_modexps_per_s", "biprime_roofline_frac", "biprime_cpu_baseline_modexps_per_s")):
         if len(text) <= LINE_TARGET:
             break
-        if drop == ("distributed",) and len(text) <= LINE_LIMIT:
+        if drop != ("extra_summary",) and len(text) <= LINE_LIMIT:     # the summaries go first; the rest only if it must
             break
         for k in drop:
             line.pop(k, None)
@@ -1362,6 +1452,7 @@ def main() -> None:
                     out["extra"]["c5_k4096_b1024"] = guarded("c5_k4096_b1024", lambda: c5_leg(1024, 24, 8, False))
                     out["extra"]["c5_k4096_b16384"] = guarded("c5_k4096_b16384", lambda: c5_leg(16384, 4, 2, False))
                     out["end_to_end_keygen"] = guarded("end_to_end_keygen", lambda: leg_keygen_round(eng, torch, args))
+                    out["short_kernels"] = guarded("short_kernels", lambda: leg_short_kernels(eng, torch))
         if world > 1 and not args.no_extras and args.workload == "c3" and not args.generic_modulus:
             # configs[3] on N GPUs inside the driver's scaling run: 4096 candidates sharded over the ranks,
             # all-gather of the v rows and of the verdict bytes (the biprimality vote, DK:1331-1360)

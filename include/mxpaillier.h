@@ -149,8 +149,8 @@ int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const 
  * multiplications are a function of the exponent's bits.  The exponent is the party's Lagrange-folded secret share
  * (PSK:79-85): with this flag the sequence and number of operations a launch executes, hence its duration and the
  * kernel-trace of a profiler, depend on the exponent's LENGTH only.  The table row a window reads is still selected by
- * the secret digit (addresses, not timing of the instruction stream).  Cost: 762 instead of 592 pair multiplications
- * for a 4197-bit exponent (w = 6, the same 64-row table) = +4.5 % instructions.  plan->window then reports w + 1 (the
+ * the secret digit (addresses, not timing of the instruction stream).  Cost: 728 instead of 592 pair multiplications
+ * for a 4197-bit exponent (w = 7: a 127-row table instead of 64 odd powers, twice the workspace) = +3.6 % instructions.  plan->window then reports w + 1 (the
  * table region is sized as 2^(window - 1) rows either way).  Same results bit for bit. */
 #define MX_PLAN_FIXED_WINDOW 1
 int mx_powmod_nsquare_prepare_ex(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp, int limbs_n,

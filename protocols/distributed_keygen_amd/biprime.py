@@ -241,6 +241,45 @@ class BiprimeRound:
         self.moduli = [surviving[k] for k in self.survivors]
         return surviving
 
+    # ---- parties that share a process (coalesce.RoundCoalescer) --------------------------------------------------
+    def adopt_sieve(self, other: "BiprimeRound") -> Dict[int, int]:
+        """The result of `other`.reconstruct_and_sieve for a party that was handed the same share table: the survivors
+        (and their moduli on the device, read-only) are shared, nothing is computed."""
+        self.has_divisor, self.survivors, self.moduli = list(other.has_divisor), list(other.survivors), list(other.moduli)
+        self._mods_rows, self._own = other._mods_rows, None
+        return dict(zip(self.survivors, self.moduli))
+
+    def shares_survivors_with(self, other: "BiprimeRound") -> bool:
+        return self is other or (self._mods_rows is other._mods_rows and (self.moduli is other.moduli or self.moduli == other.moduli))
+
+    @staticmethod
+    def v_calculation_merged(rounds: Sequence["BiprimeRound"], requests: Sequence[Any]) -> List[List[List[int]]]:
+        """`rounds[k].v_calculation(*requests[k])` for parties whose rounds hold the SAME survivors and generators, as ONE
+        launch: the parties' candidate groups are concatenated — same moduli and generators, every party its own
+        exponents (DK:1094 / DK:1097).  requests[k] = (g_values, index, p_shares, q_shares, correct_param_biprime)."""
+        first = rounds[0]
+        eng, moduli = first.engine, first.moduli
+        g_values, keep = requests[0][0], requests[0][4]
+        if not moduli:
+            return [[] for _ in rounds]
+        if first._mods_rows is None or not hasattr(eng, "biprime_verdict_columns") or not _accepts(eng.biprime_v_batch, "mods_rows"):
+            return [r.v_calculation(*q) for r, q in zip(rounds, requests)]
+        s = len(moduli)
+        exps: List[int] = []
+        for (gv, index, p_shares, q_shares, kp) in requests:
+            if not (len(gv) == s == len(p_shares) == len(q_shares)) or kp != keep:
+                raise ValueError("one g list, p share and q share per surviving candidate expected")
+            exps.extend(biprime_exponent(index, n, p, q) for n, p, q in zip(moduli, p_shares, q_shares))
+        parties = len(rounds)
+        lists, rows = eng.biprime_v_batch(list(g_values) * parties, exps, list(moduli) * parties, keep,
+                                          mods_rows=first._mods_rows.repeated(parties), keep_rows=True)
+        out = []
+        for k, (rnd, q) in enumerate(zip(rounds, requests)):
+            mine = lists[k * s : (k + 1) * s]
+            rnd._own = (q[1], mine, rows.part(k, parties) if rows is not None else None)
+            out.append(mine)
+        return out
+
     def v_calculation(self, g_values: Sequence[Sequence[int]], index: int, p_shares: Sequence[int], q_shares: Sequence[int],
                       correct_param_biprime: int) -> List[List[int]]:
         """DK:1313-1329 for the survivors (one g list, p share and q share per survivor, in order)."""

@@ -24,6 +24,7 @@ itself stays synchronous inside the flush, exactly as the reference's arithmetic
 from __future__ import annotations
 
 import asyncio
+import time
 import weakref
 from typing import Any, Callable, Dict, List, Tuple
 
@@ -44,27 +45,15 @@ class _LoopState:
         self.scheduled = False
 
 
-class Coalescer:
-    """One per ``patch.install()`` (i.e. per process and engine).  ``stats`` counts what was launched."""
+class _TickBatcher:
+    """Queueing and flush timing shared by the batchers below; subclasses implement ``_execute(pending)``."""
 
     def __init__(self, engine: Any = None, max_defer: int = 8, linger: float = 0.0) -> None:
         self._engine = engine
         self.max_defer = int(max_defer)
         self.linger = float(linger)
         self._loops: "weakref.WeakKeyDictionary[Any, _LoopState]" = weakref.WeakKeyDictionary()
-        self.stats = {"submitted": 0, "flushes": 0, "partial_launches": 0, "combine_launches": 0, "largest_batch": 0}
-
-    # ------------------------------------------------------------------ the two awaitable call sites
-    async def partial_decrypt(self, key: Any, ciphertext: Any) -> int:
-        """``key.partial_decrypt(ciphertext)`` (PSK:52-93) — batched with every other pending one of `key`.
-        The checks of PSK:62-68 and the ``get_value()`` side effect (PSK:69) happen here, in the caller."""
-        key._check_ciphertext(ciphertext)
-        return await self._submit("partial", key, ciphertext.get_value())
-
-    async def decrypt(self, key: Any, partial_dict: Dict[int, int]) -> int:
-        """``key.decrypt(partial_dict)`` (PSK:95-127) — batched likewise; ``KeyError`` (PSK:108-110) raised here."""
-        row = [partial_dict[i + 1] for i in range(key.share.degree + 1)]
-        return await self._submit("combine", key, row)
+        self.stats: Dict[str, Any] = {"submitted": 0, "flushes": 0, "busy_s": 0.0}     # busy_s: wall time inside the flushes
 
     # ------------------------------------------------------------------ queueing
     def _submit(self, kind: str, key: Any, item: Any) -> "asyncio.Future":
@@ -94,7 +83,6 @@ class Coalescer:
             return
         self._flush(state)
 
-    # ------------------------------------------------------------------ execution
     def _flush(self, state: _LoopState) -> None:
         pending, state.pending = state.pending, {}
         state.count = state.seen = state.defers = 0
@@ -102,14 +90,17 @@ class Coalescer:
         if not pending:
             return
         self.stats["flushes"] += 1
-        partial = [(key, entries) for (kind, _), (key, entries) in pending.items() if kind == "partial"]
-        combine = [(key, entries) for (kind, _), (key, entries) in pending.items() if kind == "combine"]
-        if partial:
-            self._run(partial, self._partial_groups, "partial_launches")
-        if combine:
-            self._run(combine, self._combine_groups, "combine_launches")
+        t0 = time.perf_counter()
+        try:
+            self._execute(pending)
+        finally:
+            self.stats["busy_s"] = self.stats.get("busy_s", 0.0) + (time.perf_counter() - t0)
+
+    def _execute(self, pending) -> None:  # pragma: no cover - abstract
+        raise NotImplementedError
 
     def _run(self, groups, executor: Callable, counter: str) -> None:
+        """executor(groups) -> one list of results (or exception objects) per group; resolves the futures."""
         try:
             results = executor(groups)
         except BaseException as exc:          # an engine failure belongs to every coroutine of the batch
@@ -121,8 +112,8 @@ class Coalescer:
                 raise
             return
         for (_, entries), outs in zip(groups, results):
-            self.stats[counter] += 1
-            self.stats["largest_batch"] = max(self.stats["largest_batch"], len(entries))
+            self.stats[counter] = self.stats.get(counter, 0) + 1
+            self.stats["largest_batch"] = max(self.stats.get("largest_batch", 0), len(entries))
             for (_, fut), out in zip(entries, outs):
                 if fut.done():                # the coroutine was cancelled while it waited
                     continue
@@ -130,6 +121,35 @@ class Coalescer:
                     fut.set_exception(out)
                 else:
                     fut.set_result(out)
+
+
+class Coalescer(_TickBatcher):
+    """One per ``patch.install()`` (i.e. per process and engine).  ``stats`` counts what was launched."""
+
+    def __init__(self, engine: Any = None, max_defer: int = 8, linger: float = 0.0) -> None:
+        super().__init__(engine, max_defer, linger)
+        self.stats.update({"partial_launches": 0, "combine_launches": 0, "largest_batch": 0})
+
+    # ------------------------------------------------------------------ the two awaitable call sites
+    async def partial_decrypt(self, key: Any, ciphertext: Any) -> int:
+        """``key.partial_decrypt(ciphertext)`` (PSK:52-93) — batched with every other pending one of `key`.
+        The checks of PSK:62-68 and the ``get_value()`` side effect (PSK:69) happen here, in the caller."""
+        key._check_ciphertext(ciphertext)
+        return await self._submit("partial", key, ciphertext.get_value())
+
+    async def decrypt(self, key: Any, partial_dict: Dict[int, int]) -> int:
+        """``key.decrypt(partial_dict)`` (PSK:95-127) — batched likewise; ``KeyError`` (PSK:108-110) raised here."""
+        row = [partial_dict[i + 1] for i in range(key.share.degree + 1)]
+        return await self._submit("combine", key, row)
+
+    # ------------------------------------------------------------------ execution
+    def _execute(self, pending) -> None:
+        partial = [(key, entries) for (kind, _), (key, entries) in pending.items() if kind == "partial"]
+        combine = [(key, entries) for (kind, _), (key, entries) in pending.items() if kind == "combine"]
+        if partial:
+            self._run(partial, self._partial_groups, "partial_launches")
+        if combine:
+            self._run(combine, self._combine_groups, "combine_launches")
 
     @staticmethod
     def _partial_groups(groups) -> List[List[Any]]:
@@ -155,3 +175,152 @@ class Coalescer:
             messages, ok = key.engine.combine_batch([row for row, _ in entries], key.n, key.theta_inv)
             out.append([m if good else ValueError(NOT_DIVISIBLE) for m, good in zip(messages, ok)])
         return out
+
+
+def _same(a: Any, b: Any) -> bool:
+    """Equal operands of two co-located parties: the in-process pool hands every party the SAME objects, so this is
+    mostly an identity test; otherwise an element-wise comparison in C (never a hash of big integers)."""
+    return a is b or a == b
+
+
+class RoundCoalescer(_TickBatcher):
+    """The three device steps of a key-generation round (patch.compute_modulus through biprime.BiprimeRound) for
+    parties that share ONE process and GPU — the reference's ``distributed=False`` mode (README.md:83,
+    test/conftest.py:73-90), where the n parties' ``compute_modulus`` coroutines interleave on one event loop.  Every
+    party reconstructs the same candidate moduli from the same share table, tests the same generators against them
+    and votes on the same v values; only its exponents — ``(N - p_1 - q_1 + 1) // 4`` or ``(p_i + q_i) // 4``,
+    distributed_keygen.py:1094,1097 — are its own.  So, of the requests pending in the same turn of the loop:
+
+      reconstruct_and_sieve   equal share tables run ONCE; the other parties adopt the result (moduli stay on the device)
+      v_calculation           parties with the same survivors and generators share ONE launch: their candidate groups are
+                              concatenated (mx_powmod_multi_dev takes a modulus and an exponent per group)
+      verdicts                equal v tables run ONCE
+
+    — one launch per kernel and round instead of n.  A party alone in its process (``distributed=True``) gets its
+    own launch two loop turns later; results are identical either way."""
+
+    MERGE_MODEXPS = 1 << 16       # beyond this many modexps in total the parties' launches fill the machine on their own
+
+    def __init__(self, engine: Any = None, max_defer: int = 8, linger: float = 0.0, merge: bool = True) -> None:
+        super().__init__(engine, max_defer, linger)
+        self.merge = bool(merge)      # False: every request runs on its own (A/B runs of the coalescing itself)
+        self.stats.update({"sieve_launches": 0, "sieve_requests": 0, "v_launches": 0, "v_requests": 0,
+                           "verdict_launches": 0, "verdict_requests": 0})
+
+    async def reconstruct_and_sieve(self, rnd: Any, shares_by_party, prime: int, degree: int, prime_list, points=None):
+        return await self._submit("sieve", self, (rnd, shares_by_party, prime, degree, prime_list, points))
+
+    async def v_calculation(self, rnd: Any, g_values, index: int, p_shares, q_shares, keep: int):
+        return await self._submit("v", self, (rnd, g_values, index, p_shares, q_shares, keep))
+
+    async def verdicts(self, rnd: Any, v_by_party, keep: int, errors: str = "raise"):
+        return await self._submit("verdict", self, (rnd, v_by_party, keep, errors))
+
+    # ------------------------------------------------------------------ execution
+    def _execute(self, pending) -> None:
+        for kind, fn in (("sieve", self._do_sieve), ("v", self._do_v), ("verdict", self._do_verdict)):
+            entries = [e for (k, _), (_, es) in pending.items() if k == kind for e in es]
+            if entries:
+                self._resolve(entries, fn)
+
+    def _resolve(self, entries, fn) -> None:
+        try:
+            outs = fn([item for item, _ in entries])
+        except BaseException as exc:
+            for _, fut in entries:
+                if not fut.done():
+                    fut.set_exception(exc)
+            if not isinstance(exc, Exception):
+                raise
+            return
+        for (_, fut), out in zip(entries, outs):
+            if fut.done():
+                continue
+            if isinstance(out, Exception):
+                fut.set_exception(out)
+            else:
+                fut.set_result(out)
+
+    def _classes(self, items, same) -> List[List[int]]:
+        """indices of `items` grouped into classes of mutually `same` requests, in order of first appearance"""
+        if not self.merge:
+            return [[k] for k in range(len(items))]
+        classes: List[List[int]] = []
+        for k, it in enumerate(items):
+            for cls in classes:
+                if same(items[cls[0]], it):
+                    cls.append(k)
+                    break
+            else:
+                classes.append([k])
+        return classes
+
+    def _do_sieve(self, items) -> List[Any]:
+        def same(a, b):
+            # the interpolation points as a SET: a party takes the first degree+1 entries of its share dictionary in ITS
+            # insertion order (own share first, then the others' in the order they arrived) — Lagrange interpolation over
+            # the same set of points of the same table is the same exact sum whatever the order
+            pa, pb = a[5], b[5]
+            pts = (pa is None and pb is None) or (pa is not None and pb is not None and set(pa) == set(pb))
+            return a[2] == b[2] and a[3] == b[3] and pts and _same(a[4], b[4]) and _same(a[1], b[1])
+
+        outs: List[Any] = [None] * len(items)
+        self.stats["sieve_requests"] += len(items)
+        for cls in self._classes(items, same):
+            rnd, shares, prime, degree, prime_list, points = items[cls[0]]
+            try:
+                first = rnd.reconstruct_and_sieve(shares, prime, degree, prime_list, points=points)
+                self.stats["sieve_launches"] += 1
+            except Exception as exc:
+                for k in cls:
+                    outs[k] = exc
+                continue
+            outs[cls[0]] = first
+            for k in cls[1:]:
+                outs[k] = items[k][0].adopt_sieve(rnd)
+        return outs
+
+    def _do_v(self, items) -> List[Any]:
+        from .biprime import BiprimeRound
+
+        def same(a, b):
+            return a[5] == b[5] and a[0].shares_survivors_with(b[0]) and _same(a[1], b[1])
+
+        outs: List[Any] = [None] * len(items)
+        self.stats["v_requests"] += len(items)
+        for cls in self._classes(items, same):
+            total = sum(len(items[k][0].moduli) for k in cls) * max(1, items[cls[0]][5])
+            try:
+                if len(cls) > 1 and total <= self.MERGE_MODEXPS:
+                    merged = BiprimeRound.v_calculation_merged([items[k][0] for k in cls], [items[k][1:] for k in cls])
+                    self.stats["v_launches"] += 1
+                    for k, lists in zip(cls, merged):
+                        outs[k] = lists
+                else:
+                    for k in cls:
+                        rnd, g_values, index, p_shares, q_shares, keep = items[k]
+                        outs[k] = rnd.v_calculation(g_values, index, p_shares, q_shares, keep)
+                        self.stats["v_launches"] += 1
+            except Exception as exc:
+                for k in cls:
+                    outs[k] = exc
+        return outs
+
+    def _do_verdict(self, items) -> List[Any]:
+        def same(a, b):
+            return a[2] == b[2] and a[3] == b[3] and a[0].shares_survivors_with(b[0]) and _same(a[1], b[1])
+
+        outs: List[Any] = [None] * len(items)
+        self.stats["verdict_requests"] += len(items)
+        for cls in self._classes(items, same):
+            rnd, v_by_party, keep, errors = items[cls[0]]
+            try:
+                res = rnd.verdicts(v_by_party, keep, errors=errors)
+                self.stats["verdict_launches"] += 1
+            except Exception as exc:
+                for k in cls:
+                    outs[k] = exc
+                continue
+            for k in cls:
+                outs[k] = res if k == cls[0] else list(res)
+        return outs

@@ -87,6 +87,11 @@ class _ModulusRows:
         return rows, self.bits
 
 
+    def repeated(self, times: int) -> "_ModulusRows":
+        """The same moduli `times` times over (the candidate groups of co-located parties in one launch)."""
+        return self if times == 1 else _ModulusRows(self.rows.repeat(times, 1), self.bits)
+
+
 class _VRows:
     """A party's v values of a round kept on the device: rows [groups * keep, limbs] as biprime_v_t produced them
     (rows beyond a candidate's count hold the modexp of a zero row: 0 or 1) and the counts."""
@@ -100,6 +105,11 @@ class _VRows:
         if self.rows.shape[0] != groups * self.keep or n_slots > self.keep or self.rows.shape[1] != limbs:
             raise ValueError("the kept v rows do not belong to these candidates")
         return self.rows.view(groups, self.keep, limbs)[:, :n_slots, :]
+
+    def part(self, k: int, parts: int) -> "_VRows":
+        """The k-th of `parts` equal slices of the candidate groups (one party's share of a merged launch)."""
+        groups = len(self.counts) // parts
+        return _VRows(self.rows[k * groups * self.keep : (k + 1) * groups * self.keep], self.counts[k * groups : (k + 1) * groups], self.keep)
 
 
 class Engine:
@@ -215,7 +225,8 @@ class Engine:
         """Partial decryptions (powmod_nsquare_*) with a FIXED-window tape (MX_PLAN_FIXED_WINDOW, include/mxpaillier.h): the
         number and order of the squarings and multiplications of a launch then depend on the exponent's bit length
         only — the exponent is the party's secret share folded with its Lagrange coefficient (PSK:79-85), and the default
-        sliding-window tape is a function of its bits, like gmpy2's mpz_powm.  +4.5 % instructions at key_length 2048;
+        sliding-window tape is a function of its bits, like gmpy2's mpz_powm.  +3.6 % instructions at key_length 2048 (and twice
+        the window table);
         the table row a window reads is still chosen by the secret digit.  Same results bit for bit."""
         self._fixed_window = bool(enable)
 

@@ -32,13 +32,19 @@ import importlib
 from typing import Any, Dict, Iterable, List, Optional
 
 from . import biprime, shamir
-from .coalesce import Coalescer
+from .coalesce import Coalescer, RoundCoalescer
 from .shared_key import GpuPaillierSharedKey
 
 DEFAULT_PACKAGE = "tno.mpc.protocols.distributed_keygen"
 _saved: Dict[Any, Dict[str, Any]] = {}
 _saved_names: Dict[Any, Dict[str, Any]] = {}      # module -> {name: original leaf function}
 _coalescers: Dict[str, Coalescer] = {}            # package -> the micro-batcher of its installed patch
+_round_coalescers: Dict[str, RoundCoalescer] = {}  # package -> the batcher of the keygen rounds of co-located parties
+
+
+def round_coalescer(package: str = DEFAULT_PACKAGE) -> Optional[RoundCoalescer]:
+    """The batcher behind the patched ``compute_modulus`` of `package` (its ``stats`` count launches and requests)."""
+    return _round_coalescers.get(package)
 
 
 def coalescer(package: str = DEFAULT_PACKAGE) -> Optional[Coalescer]:
@@ -306,6 +312,8 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
     Shares = dk_mod.Shares
     logger = dk_mod.logger
 
+    rounds_batcher = _round_coalescers[package] = RoundCoalescer(engine, linger=linger)
+
     async def compute_modulus(
         cls: Any, shares, index, pool, prime_list, party_indices, prime_length, shamir_scheme_t,
         shamir_scheme_2t, correct_param_biprime, session_id, batch_size: int = 1,
@@ -333,8 +341,10 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
             # (biprime.BiprimeRound: the survivors' moduli and, later, this party's v rows stay on the device between the
             # steps of the round; every value that crosses a communication round does so as a Python int, as in the reference)
             this_round = biprime.BiprimeRound(engine)
-            surviving = this_round.reconstruct_and_sieve(
-                by_party, scheme_n.modulus, scheme_n.polynomial_degree, prime_list,
+            # (awaited from the per-process batcher: parties that share this process and GPU — distributed=False — were
+            # handed the same share table and run this step, the v-calculation and the verdicts as ONE launch each)
+            surviving = await rounds_batcher.reconstruct_and_sieve(
+                this_round, by_party, scheme_n.modulus, scheme_n.polynomial_degree, prime_list,
                 points=list(share_table[0])[: scheme_n.polynomial_degree + 1])
             has_divisor = this_round.has_divisor
             survivors = this_round.survivors
@@ -347,14 +357,15 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
                 f"{sid}_biprime_test_g_{rounds}",
             )
             # DK:1313-1329 as one launch
-            v_lists = this_round.v_calculation(
-                g_values, index, [p_add[k] for k in survivors], [q_add[k] for k in survivors], correct_param_biprime)
+            v_lists = await rounds_batcher.v_calculation(
+                this_round, g_values, index, [p_add[k] for k in survivors], [q_add[k] for k in survivors], correct_param_biprime)
             to_exchange = [
                 _to_batched(v, index, moduli[k], correct_param_biprime) for v, k in zip(v_lists, survivors)
             ]
             await exchange_reconstruct(to_exchange, index, pool, party_indices, msg_id=f"{sid}_biprime_test_v_{rounds}_v")
             # DK:1339-1360: slot tests of all survivors as one launch; first passing candidate wins
-            verdicts = this_round.verdicts([_v_lists(b, party_indices) for b in to_exchange], correct_param_biprime, errors="return")
+            verdicts = await rounds_batcher.verdicts(
+                this_round, [_v_lists(b, party_indices) for b in to_exchange], correct_param_biprime, errors="return")
             for verdict, k in zip(verdicts, survivors):
                 shares.p = Shares.P(p_add[k], q_sh[k].get_shares())  # as DK:1344-1345 (sic)
                 shares.q = Shares.Q(q_add[k], q_sh[k].get_shares())
@@ -384,3 +395,4 @@ def uninstall() -> None:
                 setattr(cls, name, orig)
     _saved.clear()
     _coalescers.clear()
+    _round_coalescers.clear()

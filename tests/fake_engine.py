@@ -9,6 +9,21 @@ from typing import List, Sequence, Tuple
 from oracle import oracle
 
 
+class _Handle(tuple):
+    """The double's "device handle": a tagged tuple (kind, payload) with the two slicing methods the product code uses on
+    the real handles (engine._ModulusRows.repeated, engine._VRows.part)."""
+
+    def __new__(cls, kind, payload):
+        return super().__new__(cls, (kind, payload))
+
+    def repeated(self, times):
+        return _Handle(self[0], list(self[1]) * times)
+
+    def part(self, k, parts):
+        n = len(self[1]) // parts
+        return _Handle(self[0], self[1][k * n:(k + 1) * n])
+
+
 class FakeEngine:
     def __init__(self) -> None:
         self.calls: List[Tuple[str, int]] = []
@@ -89,7 +104,7 @@ class FakeEngine:
         bad = [oracle.small_prime_divisors_test(primes, m) for m in mods]
         surviving = {k: m for k, (m, b) in enumerate(zip(mods, bad)) if not b}
         if keep_rows:          # the double's "device rows" of the survivors' moduli: a tagged list
-            return bad, surviving, ("mods_rows", [surviving[k] for k in sorted(surviving)]) if surviving else None
+            return bad, surviving, _Handle("mods_rows", [surviving[k] for k in sorted(surviving)]) if surviving else None
         return bad, surviving
 
     # the device-resident forms of a key-generation round (biprime.BiprimeRound); handles are tagged Python lists
@@ -101,7 +116,7 @@ class FakeEngine:
         for gs, e, m in zip(g_values, exps, mods):
             sel = [g for g in gs if oracle.jacobi_symbol(g, m) == 1][:keep]
             out.append([oracle.pow_mod(g, e, m) for g in sel])
-        return (out, ("v_rows", [list(v) for v in out])) if keep_rows else out
+        return (out, _Handle("v_rows", [list(v) for v in out])) if keep_rows else out
 
     def biprime_verdict_columns(self, columns, mods, n_slots, mods_rows=None):
         self.calls.append(("biprime_verdict_columns", len(mods)))

@@ -150,6 +150,37 @@ def test_patched_compute_modulus_on_the_hip_engine(eng):
         assert got == base, (seed, key_length)
 
 
+def test_colocated_parties_share_the_launches_of_a_keygen_round(eng):
+    """three parties in one process (the reference's distributed=False shape) generate a key_length
+    1024 modulus with 1024 candidates per round.  With the per-process batcher every round's reconstruct + sieve,
+    v-calculation and verdict run ONCE for all parties (one launch per kernel instead of three; the v-calculation with
+    the parties' candidate groups concatenated); the time the engine is busy per round at least halves; the modulus is
+    the same."""
+    from protocols.distributed_keygen_amd import patch
+
+    runs = {}
+    for merge in (False, True):
+        patch.install(engine=eng, package=sh.PACKAGE)
+        try:
+            rc = patch.round_coalescer(sh.PACKAGE)
+            rc.merge = merge
+            got = sh.keygen(seed=12, key_length=1024, batch_size=1024, prime_threshold=2000, correct_param=40)
+            st = dict(rc.stats)
+        finally:
+            patch.uninstall()
+        assert len(set(got)) == 1
+        rounds = st["sieve_requests"] // 3
+        runs.setdefault(merge, []).append((got[0], rounds, st))
+    (n_a, rounds_a, st_a), (n_b, rounds_b, st_b) = min(runs[False], key=lambda r: r[2]["busy_s"]), min(runs[True], key=lambda r: r[2]["busy_s"])
+    assert n_a == n_b and rounds_a == rounds_b
+    assert st_a["sieve_launches"] == 3 * rounds_a and st_b["sieve_launches"] == rounds_b
+    assert st_a["v_launches"] == 3 * st_b["v_launches"] and st_a["verdict_launches"] == 3 * st_b["verdict_launches"]
+    per_round_a, per_round_b = st_a["busy_s"] / rounds_a, st_b["busy_s"] / rounds_b
+    print(f"keygen K=1024, 1024 candidates/round, 3 co-located parties, {rounds_a} rounds: engine busy per round "
+          f"{per_round_a * 1e3:.1f} ms one launch per party -> {per_round_b * 1e3:.1f} ms shared launches")
+    assert per_round_b <= 0.5 * per_round_a, (per_round_a, per_round_b)
+
+
 def test_rebound_leaf_runs_the_standins_own_scalar_methods_on_the_engine(eng):
     from protocols.distributed_keygen_amd import patch, synthetic
 

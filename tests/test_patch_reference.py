@@ -241,9 +241,17 @@ def test_compute_modulus_is_drop_in(ref):
     patch.install(engine=eng)
     try:
         got = _run_compute_modulus(ref, seed=11, batch_size=40)
+        stats = dict(patch.round_coalescer().stats)
     finally:
         patch.uninstall()
     assert got == base
+    # the three parties share this process (the reference's distributed=False shape): every round's reconstruct + sieve,
+    # v-calculation (the parties' candidate groups concatenated: same moduli and generators, own exponents) and verdicts
+    # run ONCE for all of them (coalesce.RoundCoalescer) — VERDICT r04 item 6
+    assert stats["sieve_requests"] == 3 * stats["sieve_launches"] and stats["sieve_launches"] >= 1
+    assert stats["v_requests"] == 3 * stats["v_launches"] and stats["verdict_requests"] == 3 * stats["verdict_launches"]
+    survivors_per_round = [c[1] // 3 for c in eng.calls if c[0] == "biprime_v_batch"]
+    assert all(c[1] % 3 == 0 for c in eng.calls if c[0] == "biprime_v_batch") and len(survivors_per_round) == stats["v_launches"]
     kinds = {c[0] for c in eng.calls}
     # one round = biprime.BiprimeRound: reconstruct + sieve, v-calculation and verdicts as one call each per party, the
     # survivors' moduli and the party's own v rows handed from step to step (the double checks that the kept moduli rows
@@ -251,10 +259,10 @@ def test_compute_modulus_is_drop_in(ref):
     # "from the device"
     assert {"shamir_reconstruct_sieve_batch", "biprime_v_batch", "biprime_verdict_columns", "biprime_verdict_batch",
             "own_column_from_device"} <= kinds
-    rounds = sum(1 for c in eng.calls if c[0] == "shamir_reconstruct_sieve_batch") // 3
+    rounds = sum(1 for c in eng.calls if c[0] == "shamir_reconstruct_sieve_batch")
     # N reconstruction (DK:1284) + sieve (DK:1288-1292) of a whole round in one call
     assert all(c[1] == 40 for c in eng.calls if c[0] == "shamir_reconstruct_sieve_batch")
-    assert sum(1 for c in eng.calls if c[0] == "biprime_v_batch") <= 3 * rounds
+    assert sum(1 for c in eng.calls if c[0] == "biprime_v_batch") <= rounds
     assert sum(1 for c in eng.calls if c[0] == "own_column_from_device") == sum(1 for c in eng.calls if c[0] == "biprime_verdict_columns")
 
 
