@@ -218,7 +218,7 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
   constexpr int S = M_t::S;
   constexpr int WIDE = M_t::LDS_WORDS;            // words: input row staging / output limbs (reuses the scratch)
   constexpr int GROUP_WORDS = M_t::LDS_WORDS;
-  static_assert(WIDE == 2 * S + 8, "row staging");
+  static_assert(WIDE >= 2 * S + 8, "row staging");
   extern __shared__ u32 smem[];
   constexpr int GPW = 64 / K;
   const int lane = threadIdx.x;
