@@ -70,8 +70,9 @@ int mx_powmod_multi(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_
 
 /* mx_powmod_shared with the lane geometry as an argument: limbs_per_lane 9 (narrow: more lanes per
  * element), 18 (wide: fewer, busier lanes), 3 (latency: many lanes per element, the exponentiation's products modulo
- * the friendly multiple of N — for launches that leave SIMDs idle, moduli up to 5533 bits) or 0 = automatic from the
- * batch size: 3 while the launch brings at most two such wavefronts per SIMD, else 9 or 18 by instruction count.
+ * the friendly multiple of N — for launches that leave SIMDs idle, moduli up to 5533 bits), 6 (the bipartite latency form:
+ * 3 limbs per lane, every product on two wavefronts, mx_powmod_launch_form) or 0 = automatic from an estimate of the
+ * launch's duration: 6 while the launch leaves SIMDs idle, 3 up to about two such wavefronts per SIMD, else 9 or 18.
  * The same argument of mx_powmod_multi_dev and mx_powmod_geometry_for. */
 int mx_powmod_shared_lpl(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* h_mod, const uint32_t* h_exp,
                          int limbs, int exp_limbs, int64_t batch, int limbs_per_lane, void* d_workspace,
@@ -296,7 +297,7 @@ int mx_selftest_lanes(void* stream);
  * segment): 0 = where the estimate favours it, 1 = never, 2 = always, 16 + r = always, with r
  * workgroups per CU (r = 1..3).  MX_KNOB_N2_FRIENDLY_1W: 1 = the one-wavefront wide kernel never takes its
  * friendly-modulus instances (A/B runs against the plain ones).  MX_KNOB_GENERIC_LATENCY: 1 = the automatic geometry of
- * the generic-modulus modexp never takes the 3-limb latency instances.  MX_KNOB_N2_SPLIT: mx_nsquare_launch_split
+ * the generic-modulus modexp never takes the 3-limb latency instances (one or two wavefronts), 2 = never the bipartite form.  MX_KNOB_N2_SPLIT: mx_nsquare_launch_split
  * 1 = never reports a split, 2 = whenever one exists.  These are the ONLY process-wide settings the library has (ABI 4.0
  * dropped mx_set_limbs_per_lane: launch shapes are call arguments, the entry points without one leave the choice to the
  * library); each is an atomic integer, so flipping one while another thread launches is well defined (that launch sees
@@ -378,6 +379,15 @@ int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, in
  * caller did not pass; protocols/distributed_keygen_amd/engine.py follows this hint for lone launches. */
 int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first_rows, int* first_lpl, int* first_wpg,
                             int* rest_lpl, int* rest_wpg);
+/* Launch form of a generic-modulus modexp (mx_powmod_shared_lpl / mx_powmod_multi_dev) for this limbs_per_lane (0 = the
+ * library's choice): *wavefronts_per_group = 1, or 2 for the BIPARTITE latency form (limbs_per_lane 6 = "3 limbs per lane on
+ * two wavefronts", csrc/mx_bimont.hpp): every modular product is split at a pivot — *pivot multiplier limbs on a wavefront that
+ * runs least-significant-first Montgomery steps, the rest on a second wavefront that runs most-significant-first steps with a
+ * fold of the overflow — so that a product costs half the dependent limb steps plus a hand-over through LDS.  For launches that
+ * leave SIMDs idle (a key-generation round at the reference's batch sizes: a few dozen to a thousand modexps,
+ * distributed_keygen.py:1313-1329): such a launch lasts as long as one wavefront's dependent chain whatever its size.  Fixed
+ * windows; moduli up to 5359 bits; mx_powmod_geometry_for reports its lanes per element with limbs_per_lane_out = 3. */
+int mx_powmod_launch_form(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* wavefronts_per_group, int* pivot);
 int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* lanes_per_element,
                            int* limbs_per_lane_out, int* limb_bits, int* blocks);
 

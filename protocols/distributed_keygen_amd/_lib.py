@@ -66,6 +66,7 @@ SYMBOLS = {
     "mx_jacobi_dev_range": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int64, c_int64, c_int, c_int, c_void_p, c_int, c_void_p]),
     "mx_nsquare_geometry_for": (c_int, [c_int, c_int64, c_int, *_P4]),
     "mx_powmod_geometry_for": (c_int, [c_int, c_int64, c_int64, c_int, *_P4]),
+    "mx_powmod_launch_form": (c_int, [c_int, c_int64, c_int64, c_int, POINTER(c_int), POINTER(c_int)]),
     "mx_modinv_workspace_bytes": (c_int64, [c_int]),
     "mx_modinv": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int64, c_void_p, c_int64, c_void_p]),
     "mx_field_workspace_bytes": (c_int64, [c_int, c_int]),

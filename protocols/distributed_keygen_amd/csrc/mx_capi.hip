@@ -10,6 +10,7 @@
 #include "mx_setup.hpp"
 #include "mx_field.hpp"
 #include "mx_modinv.hpp"
+#include "mx_bimont.hpp"
 #include <cstring>
 #include <algorithm>
 
@@ -32,7 +33,7 @@ struct PowmodPlan {
   Geometry geo;
   int win = 1;
   int64_t nblocks = 0, nlanes = 0;
-  int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_ops = 0, off_table = 0, total = 0;
+  int64_t off_mods = 0, off_rmodn = 0, off_exps = 0, off_ops = 0, off_table = 0, off_bi = 0, total = 0;
 };
 
 }  // namespace
@@ -40,9 +41,13 @@ struct PowmodPlan {
 namespace mxl {
 int launch_powmod_lat(int K, const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s);
 int launch_rmodn_lat(int K, const mx::RmodnArgs& a, hipStream_t s);
+int launch_powmod_bi(int K, const mx::PowmodBiArgs& a, int64_t nblocks, hipStream_t s);
+int launch_bisetup(int K, const mx::BiSetupArgs& a, hipStream_t s);
 }
 namespace {
-inline bool generic_lpl_ok(int lpl) { return lpl == 0 || lpl == LIMBS_PER_LANE || lpl == LIMBS_PER_LANE_WIDE || lpl == LIMBS_PER_LANE_LAT; }
+inline bool generic_lpl_ok(int lpl) {
+  return lpl == 0 || lpl == LIMBS_PER_LANE || lpl == LIMBS_PER_LANE_WIDE || lpl == LIMBS_PER_LANE_LAT || lpl == LIMBS_PER_LANE_BI;
+}
 
 // Geometry when the caller leaves the choice to the library: the shape with the shortest estimated duration of ONE launch
 // on an idle GPU.  A wavefront of the 3- / 9- / 18-limb instances carries 64 / K elements through the whole exponentiation
@@ -57,8 +62,16 @@ double generic_estimate(int mod_bits, int64_t batch, int lpl) {
   Geometry g;
   if (!choose_geometry(mod_bits, g, lpl)) return -1.0;
   if (lpl == LIMBS_PER_LANE_WIDE && g.K > 32) return -1.0;          // no <64, 18> instance
-  const int64_t waves = (batch * g.K + 63) / 64;
   const int64_t simds = (int64_t)4 * mx_device_cus();
+  if (g.bi) {
+    // two wavefronts per 64 / K elements, each with about half the limb steps of the one-wavefront latency instance plus the
+    // hand-over of every product (tools/sweep_generic.py: 0.62 of its time alone on the SIMDs; a further pair per SIMD adds
+    // most of that again, so the form only pays while the launch leaves SIMDs idle)
+    const int64_t waves = 2 * ((batch * g.K + 63) / 64);
+    const int64_t per_simd = (waves + simds - 1) / simds;
+    return 0.62 * (1.0 + 0.9 * (double)(per_simd - 1));
+  }
+  const int64_t waves = (batch * g.K + 63) / 64;
   const int64_t per_simd = (waves + simds - 1) / simds;
   const double t1 = lpl == LIMBS_PER_LANE_LAT ? 1.0 : lpl == LIMBS_PER_LANE ? 1.43 : 2.12;
   const double more = lpl == LIMBS_PER_LANE_LAT ? 0.6 : lpl == LIMBS_PER_LANE ? 0.8 : 0.96;
@@ -68,8 +81,9 @@ int auto_limbs_per_lane(int mod_bits, int64_t batch, int64_t groups) {
   (void)groups;
   int best = LIMBS_PER_LANE;
   double best_t = -1.0;
-  for (int lpl : {LIMBS_PER_LANE, LIMBS_PER_LANE_WIDE, LIMBS_PER_LANE_LAT}) {
+  for (int lpl : {LIMBS_PER_LANE, LIMBS_PER_LANE_WIDE, LIMBS_PER_LANE_LAT, LIMBS_PER_LANE_BI}) {
     if (lpl == LIMBS_PER_LANE_LAT && g_knob_generic_latency == 1) continue;
+    if (lpl == LIMBS_PER_LANE_BI && g_knob_generic_latency != 0) continue;      // 1: no latency instances at all, 2: no bipartite form
     const double t = generic_estimate(mod_bits, batch, lpl);
     if (t > 0 && (best_t < 0 || t < best_t * 0.999)) { best_t = t; best = lpl; }
   }
@@ -90,6 +104,8 @@ bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t 
   p.off_exps = o;  o += align256((int64_t)groups * exp_limbs * 4);
   p.off_ops = o;   o += align256((int64_t)MAX_SLIDING_OPS * 4);
   p.off_table = o; o += align256(((int64_t)1 << p.win) * p.geo.L * p.nlanes * 4);
+  p.off_bi = o;
+  if (p.geo.bi) o += align256((int64_t)groups * mx::BI_ROWS * p.geo.L * p.geo.K * 4);
   p.total = o;
   return true;
 }
@@ -151,9 +167,24 @@ int launch_rmodn(const Geometry& g, const u32* d_mods, u32* d_rmodn, int limbs, 
 int powmod_launch(const uint32_t* d_bases, uint32_t* d_out, const u32* d_mods, const u32* d_exps, const u32* h_exp0,
                   int limbs, int exp_limbs, int max_ebits, int64_t groups, int64_t group_size, const PowmodPlan& p,
                   char* ws, hipStream_t s) {
-  MX_TRY(launch_rmodn(p.geo, d_mods, (u32*)(ws + p.off_rmodn), limbs, groups, s));
   int ndigits = (max_ebits + p.win - 1) / p.win;
   if (ndigits < 1) ndigits = 1;
+  if (p.geo.bi) {
+    // the bipartite latency form (mx_bimont.hpp): its own setup kernel (fold constants and the conversion factor of every
+    // modulus), fixed windows only, two wavefronts per workgroup
+    mx::BiSetupArgs sa;
+    sa.mods = d_mods; sa.consts = (u32*)(ws + p.off_bi); sa.groups = groups; sa.limbs = limbs;
+    sa.nblk = p.geo.nblk; sa.pd = p.geo.L * p.geo.nblk; sa.h_lo = p.geo.h_lo;
+    MX_TRY(mxl::launch_bisetup(p.geo.K, sa, s));
+    mx::PowmodBiArgs b;
+    b.bases = d_bases; b.out = d_out; b.mods = d_mods; b.exps = d_exps; b.consts = (const u32*)(ws + p.off_bi);
+    b.table = (u32*)(ws + p.off_table);
+    b.batch = groups * group_size; b.group_size = group_size;
+    b.limbs = limbs; b.elimbs = exp_limbs; b.ndigits = ndigits; b.win = p.win;
+    b.nblk = p.geo.nblk; b.pd = sa.pd; b.h_lo = p.geo.h_lo;
+    return mxl::launch_powmod_bi(p.geo.K, b, p.nblocks, s);
+  }
+  MX_TRY(launch_rmodn(p.geo, d_mods, (u32*)(ws + p.off_rmodn), limbs, groups, s));
   mx::PowmodArgs a;
   a.bases = d_bases; a.out = d_out;
   a.mods = d_mods;
@@ -298,7 +329,7 @@ int mx_debug_knob(int knob, int value) {
     case MX_KNOB_N2_TIMESLICE: if (value > 2 && (value < 17 || value > 19)) return MX_ERR_ARG; g_knob_n2_timeslice = value; return MX_OK;
     case MX_KNOB_JACOBI_MAX_BATCHES: g_knob_jacobi_max_batches = value; return MX_OK;
     case MX_KNOB_N2_FRIENDLY_1W: if (value > 1) return MX_ERR_ARG; g_knob_n2_friendly_1w = value; return MX_OK;
-    case MX_KNOB_GENERIC_LATENCY: if (value > 1) return MX_ERR_ARG; g_knob_generic_latency = value; return MX_OK;
+    case MX_KNOB_GENERIC_LATENCY: if (value > 2) return MX_ERR_ARG; g_knob_generic_latency = value; return MX_OK;
     case MX_KNOB_N2_SPLIT: if (value > 2) return MX_ERR_ARG; g_knob_n2_split = value; return MX_OK;
   }
   return MX_ERR_ARG;
@@ -352,6 +383,8 @@ int64_t mx_powmod_workspace_bytes(int limbs, int exp_limbs, int64_t batch, int64
   // widest one it takes)
   const int lat_bits = std::min(sizing_bits(limbs), LIMB_BITS * LIMBS_PER_LANE_LAT * 64 - 4 - LIMB_BITS - 2);
   if (plan_powmod(lat_bits, limbs, exp_limbs, batch, groups, q, LIMBS_PER_LANE_LAT) && q.total > most) most = q.total;
+  const int bi_bits = std::min(sizing_bits(limbs), LIMB_BITS * LIMBS_PER_LANE_LAT * 62 - 35);
+  if (plan_powmod(bi_bits, limbs, exp_limbs, batch, groups, q, LIMBS_PER_LANE_BI) && q.total > most) most = q.total;
   return most;
 }
 
@@ -399,6 +432,18 @@ int mx_powmod_geometry_for(int mod_bits, int64_t batch, int64_t groups, int limb
   if (!choose_geometry(mod_bits, g, limbs_per_lane ? limbs_per_lane : auto_limbs_per_lane(mod_bits, batch, groups)))
     return MX_ERR_SIZE;
   *k = g.K; *l = g.L; *w = g.W; *blocks = g.nblk;
+  return MX_OK;
+}
+
+int mx_powmod_launch_form(int mod_bits, int64_t batch, int64_t groups, int limbs_per_lane, int* wavefronts_per_group,
+                          int* pivot) {
+  if (!wavefronts_per_group || batch <= 0 || groups <= 0) return MX_ERR_ARG;
+  if (!generic_lpl_ok(limbs_per_lane)) return MX_ERR_ARG;
+  Geometry g;
+  if (!choose_geometry(mod_bits, g, limbs_per_lane ? limbs_per_lane : auto_limbs_per_lane(mod_bits, batch, groups)))
+    return MX_ERR_SIZE;
+  *wavefronts_per_group = g.bi ? 2 : 1;
+  if (pivot) *pivot = g.h_lo;
   return MX_OK;
 }
 

@@ -7,6 +7,7 @@
 #include "mx_upload.hpp"
 #include "mx_powmod.hpp"
 #include "mx_setup.hpp"
+#include "mx_bimont.hpp"
 
 namespace mxl {
 template <int K>
@@ -32,6 +33,32 @@ static int launch_rmodn(const mx::RmodnArgs& a, hipStream_t s) {
   return MX_OK;
 }
 
+// bipartite form (mx_bimont.hpp): two wavefronts per workgroup, groups of 4 .. 64 lanes
+template <int K>
+static int launch_bi(const mx::PowmodBiArgs& a, int64_t nblocks, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE_LAT, LIMB_BITS, true, false>;
+  const size_t lds = (size_t)(64 / K) * (3 * (LIMBS_PER_LANE_LAT * K + 4) + M_t::LDS_WORDS) * 4;
+  MxKernelTimer timer(s);
+  hipLaunchKernelGGL((mx::powmod_bi_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(128), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+template <int K>
+static int launch_bis(const mx::BiSetupArgs& a, hipStream_t s) {
+  using M_t = mx::Mont<K, LIMBS_PER_LANE_LAT, LIMB_BITS, true>;
+  const int gpw = 64 / K;
+  const int64_t nblocks = (a.groups + gpw - 1) / gpw;
+  hipLaunchKernelGGL((mx::bisetup_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(64), (size_t)gpw * M_t::LDS_WORDS * 4, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+#define MX_BI_CASES(FN, ...) \
+  switch (K) {               \
+    case 4: return FN<4>(__VA_ARGS__); case 8: return FN<8>(__VA_ARGS__); case 16: return FN<16>(__VA_ARGS__); \
+    case 32: return FN<32>(__VA_ARGS__); case 64: return FN<64>(__VA_ARGS__);                                  \
+  }                                                                                                            \
+  return MX_ERR_SIZE;
+
 #define MX_LAT_CASES(FN, ...) \
   switch (K) {                \
     case 1: return FN<1>(__VA_ARGS__); case 2: return FN<2>(__VA_ARGS__); case 4: return FN<4>(__VA_ARGS__);     \
@@ -42,4 +69,6 @@ static int launch_rmodn(const mx::RmodnArgs& a, hipStream_t s) {
 
 int launch_powmod_lat(int K, const mx::PowmodArgs& a, int64_t nblocks, hipStream_t s) { MX_LAT_CASES(launch_powmod, a, nblocks, s) }
 int launch_rmodn_lat(int K, const mx::RmodnArgs& a, hipStream_t s) { MX_LAT_CASES(launch_rmodn, a, s) }
+int launch_powmod_bi(int K, const mx::PowmodBiArgs& a, int64_t nblocks, hipStream_t s) { MX_BI_CASES(launch_bi, a, nblocks, s) }
+int launch_bisetup(int K, const mx::BiSetupArgs& a, hipStream_t s) { MX_BI_CASES(launch_bis, a, s) }
 }  // namespace mxl

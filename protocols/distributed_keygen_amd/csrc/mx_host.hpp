@@ -18,12 +18,17 @@ constexpr int LIMB_BITS = 29;   // W
 constexpr int LIMBS_PER_LANE = 9;   // L of the narrow geometry (more lanes per element)
 constexpr int LIMBS_PER_LANE_WIDE = 18;   // L of the wide geometry (fewer, busier lanes)
 constexpr int LIMBS_PER_LANE_LAT = 3;     // L of the latency geometry (many lanes per element: launches that leave SIMDs idle)
+// limbs_per_lane value of the BIPARTITE latency form of the generic modexp (mx_bimont.hpp): 3 limbs per lane, every product
+// split over two wavefronts (half the multiplier's limbs each) — "3 x 2"
+constexpr int LIMBS_PER_LANE_BI = 6;
 
 struct Geometry {
   int K = 0;      // lanes per element
   int L = LIMBS_PER_LANE;
   int W = LIMB_BITS;
   int nblk = 0;   // Montgomery R = 2^(W*L*nblk)
+  int bi = 0;     // 1: the bipartite form (two wavefronts per group of elements); Pd = L * nblk data positions
+  int h_lo = 0;   // bipartite: the pivot (multiplier limbs [0, h_lo) on wavefront L)
 };
 
 // R = 2^(W*L*nblk) must be >= 16 N (lazy reduction bound, mx_mont.hpp), nblk <= K.
@@ -31,6 +36,22 @@ struct Geometry {
 constexpr int MAX_MOD_BITS = LIMB_BITS * LIMBS_PER_LANE * 64 - 4;
 inline bool choose_geometry(int mod_bits, Geometry& g, int limbs_per_lane = LIMBS_PER_LANE) {
   if (mod_bits < 2 || mod_bits > MAX_MOD_BITS) return false;
+  g.bi = 0; g.h_lo = 0;
+  if (limbs_per_lane == LIMBS_PER_LANE_BI) {
+    // tools/bimont_model.py Geometry: Pd = 3 * nblk data positions with W * Pd >= bits + 35, wavefront H needs Pd / 3 + 2 lanes
+    g.L = LIMBS_PER_LANE_LAT;
+    const int per = g.W * g.L;
+    g.nblk = (mod_bits + 35 + per - 1) / per;
+    int k = 4;
+    while (k < g.nblk + 2) k <<= 1;
+    if (k > 64) return false;
+    g.K = k;
+    g.bi = 1;
+    const int steps = g.L * g.nblk + g.L;                  // multiplier limbs Pd + 2 .. 0
+    g.h_lo = g.L * ((steps + 6) / (2 * g.L));              // wavefront H carries ~6 steps' worth of epilogue per product
+    if (g.h_lo > steps - g.L) g.h_lo = steps - g.L;        // (tiny moduli: at least one block for wavefront H)
+    return true;
+  }
   g.L = limbs_per_lane;
   // 3 limbs per lane (the pair kernel's latency instances) reduce modulo a multiple of N that is LIMB_BITS bits
   // longer (mx_mont.hpp: F_FRIENDLY) and keep two more bits of head room for the lazy bound

@@ -191,9 +191,10 @@ class Engine:
         """Lane geometry of this engine's modexp launches: 0 = automatic (from the batch size), 9 =
         narrow, 18 = wide, 3 = the latency geometry (the N^2 pair kernel: two wavefronts per group, any key
         length; the generic-modulus kernels: moduli up to 5533 bits, wider ones fall back to the automatic
-        choice).  Passed with every call (no process-wide state)."""
-        if limbs_per_lane not in (0, 3, 9, 18):
-            raise ValueError("limbs_per_lane must be 0, 3, 9 or 18")
+        choice), 6 = the generic kernels' bipartite latency form (3 limbs per lane, every product on two wavefronts:
+        moduli up to 5359 bits; the N^2 pair kernel reads it as 3).  Passed with every call (no process-wide state)."""
+        if limbs_per_lane not in (0, 3, 6, 9, 18):
+            raise ValueError("limbs_per_lane must be 0, 3, 6, 9 or 18")
         self._lpl = int(limbs_per_lane)
 
     def set_wavefronts_per_group(self, wavefronts: int) -> None:
@@ -213,7 +214,24 @@ class Engine:
         powmod_batch, say) to the library's automatic choice instead of failing with MX_ERR_SIZE."""
         if self._lpl == 3 and mod_bits > self.GENERIC_LATENCY_MAX_BITS:
             return 0
-        return self._lpl if self._lpl in (3, 9, 18) else 0
+        if self._lpl == 6 and mod_bits > self.GENERIC_BIPARTITE_MAX_BITS:
+            return 0
+        return self._lpl if self._lpl in (3, 6, 9, 18) else 0
+
+    GENERIC_BIPARTITE_MAX_BITS = 29 * 3 * 62 - 35        # 5359: wavefront H needs Pd / 3 + 2 <= 64 lanes (mx_host.hpp)
+
+    def _lpl_n2(self) -> int:
+        """... as the N^2 pair kernel takes it: 6 (the generic kernel's bipartite latency form) is its latency geometry 3."""
+        return 3 if self._lpl == 6 else self._lpl
+
+    def generic_launch_form(self, mod_bits: int, batch: int = 1, groups: int = 1) -> Tuple[int, int]:
+        """(wavefronts per group of elements, pivot) of a generic-modulus modexp launch with this engine's settings:
+        (2, hL) for the bipartite latency form (include/mxpaillier.h: mx_powmod_launch_form), else (1, 0)."""
+        import ctypes
+
+        waves, pivot = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.mx_powmod_launch_form(mod_bits, batch, groups, self._lpl_generic(mod_bits), waves, pivot), "mx_powmod_launch_form")
+        return waves.value, pivot.value
 
     def set_segments(self, segments: int) -> None:
         """Launches one mx_powmod_nsquare_run exponentiation is cut into (0 = automatic, 1..64)."""
@@ -338,7 +356,7 @@ class Engine:
         import ctypes
 
         k, l, w, b, wv = (ctypes.c_int() for _ in range(5))
-        _lib.check(self.lib.mx_nsquare_launch_shape(n_bits, batch, self._lpl, self._wpg, k, l, w, b, wv), "mx_nsquare_launch_shape")
+        _lib.check(self.lib.mx_nsquare_launch_shape(n_bits, batch, self._lpl_n2(), self._wpg, k, l, w, b, wv), "mx_nsquare_launch_shape")
         return k.value, l.value, w.value, b.value, wv.value
 
     def saturating_shape(self, n_bits: int, total: int) -> Tuple[int, int]:
@@ -351,12 +369,12 @@ class Engine:
         import ctypes
 
         k, l, w, b, wv = (ctypes.c_int() for _ in range(5))
-        if not (self._lpl and self._wpg) and self.lib.mx_nsquare_launch_shape(n_bits, total, self._lpl or 18, self._wpg or 1, k, l, w, b, wv) == 0:
+        if not (self._lpl and self._wpg) and self.lib.mx_nsquare_launch_shape(n_bits, total, self._lpl_n2() or 18, self._wpg or 1, k, l, w, b, wv) == 0:
             simds = 4 * self.torch.cuda.get_device_properties(self.device).multi_processor_count
             if wv.value == 1 and l.value == 18 and total * k.value // 64 >= 15 * simds // 8:
                 return (18, 1)
         _, l_, _, _, w_ = self.nsquare_launch_shape(n_bits, total)
-        return (self._lpl or l_, self._wpg or w_)
+        return (self._lpl_n2() or l_, self._wpg or w_)
 
     def nsquare_launch_split(self, n_bits: int, batch: int) -> Optional[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
         """(rows of the first launch, its shape, the shape of the rest) when ONE powmod_nsquare batch of this size is
@@ -378,7 +396,7 @@ class Engine:
         import ctypes
 
         r, u = ctypes.c_int(), ctypes.c_int()
-        _lib.check(self.lib.mx_nsquare_launch_timesliced(n_bits, batch, self._lpl, self._wpg, r, u), "mx_nsquare_launch_timesliced")
+        _lib.check(self.lib.mx_nsquare_launch_timesliced(n_bits, batch, self._lpl_n2(), self._wpg, r, u), "mx_nsquare_launch_timesliced")
         return r.value, u.value
 
     def _mods_operand(self, mods, limbs: int, odd_only: bool = True):
@@ -562,7 +580,7 @@ class Engine:
             ws = self._workspace(self.lib.mx_powmod_nsquare_run_workspace_bytes(plan.desc, batch))
             rc = self.lib.mx_powmod_nsquare_run(
                 plan.desc, bases_t.data_ptr(), out_t.data_ptr(), limbs2, batch,
-                self._lpl if shape is None else int(shape[0]), self._wpg if shape is None else int(shape[1]),
+                self._lpl_n2() if shape is None else int(shape[0]), self._wpg if shape is None else int(shape[1]),
                 self._segments if segments is None else int(segments), ws.data_ptr(), ws.numel(), self._stream_ptr(),
             )
         _lib.check(rc, "mx_powmod_nsquare_run")

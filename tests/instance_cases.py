@@ -68,6 +68,13 @@ GENERIC_CASES = [
 GENERIC_CASES += [(kind, bits, 3, batch, ebits) for kind in ("shared", "multi") for bits, batch, ebits in
                   ((50, 70, 40), (130, 67, 100), (300, 35, 130), (600, 19, 130), (1027, 9, 130), (2051, 5, 130), (4100, 3, 96))]
 
+# the bipartite latency form of the generic kernel (limbs_per_lane 6: 3 limbs per lane, every product on two wavefronts,
+# csrc/mx_bimont.hpp): K = 4, 4, 8, 16, 16, 32, 64, 64 (the last at the widest modulus the form takes); fixed windows for
+# one exponent and for per-group exponents alike; batches that leave the last workgroup ragged
+GENERIC_CASES += [(kind, bits, 6, batch, ebits) for kind in ("shared", "multi") for bits, batch, ebits in
+                  ((50, 70, 40), (130, 67, 100), (300, 35, 130), (600, 19, 130), (1027, 9, 130), (2051, 5, 130), (4100, 3, 96),
+                   (5359, 2, 64))]
+
 ALL_CASES = N2_CASES + GENERIC_CASES
 
 
@@ -95,14 +102,28 @@ def _instance(lib, bits, batch, lpl, wpg, ts_knob=0):
 
 def case_instance(lib, case):
     """The template instance a case runs: ("n2", K, L, wavefronts per group, friendly, time-sliced) or
-    ("generic-sliding" | "generic-fixed", K, L)."""
+    ("generic-sliding" | "generic-fixed", K, L) / ("generic-bi", K, 3)."""
     kind, bits, lpl, batch = case[:4]
     if kind == "n2":
         g = _instance(lib, bits, batch, lpl, case[5], case[6] if len(case) > 6 else 0)
         return None if g is None else ("n2",) + g
     groups = 1 if kind == "shared" else 3
-    g = _geom(lib.mx_powmod_geometry_for, bits, batch * groups, groups, lpl)
-    return None if g is None else ("generic-sliding" if kind == "shared" else "generic-fixed",) + g
+    return _generic_instance(lib, bits, batch * groups, groups, lpl)
+
+
+def _generic_instance(lib, bits, batch, groups, lpl):
+    """("generic-sliding" | "generic-fixed", K, L) for the one-wavefront kernel, ("generic-bi", K, 3) for the bipartite form
+    (mx_powmod_launch_form reports two wavefronts per group of elements)."""
+    import ctypes
+
+    g = _geom(lib.mx_powmod_geometry_for, bits, batch, groups, lpl)
+    if g is None:
+        return None
+    waves, pivot = ctypes.c_int(), ctypes.c_int()
+    assert lib.mx_powmod_launch_form(bits, batch, groups, lpl, waves, pivot) == 0
+    if waves.value == 2:
+        return ("generic-bi",) + g
+    return ("generic-sliding" if groups == 1 else "generic-fixed",) + g
 
 
 def reachable_instances(lib):
@@ -122,9 +143,9 @@ def reachable_instances(lib):
                         out.add(("n2",) + g)
             if coarse:
                 continue
-            for lpl in (0, 3, 9, 18):
-                for groups, name in ((1, "generic-sliding"), (max(2, batch // 40), "generic-fixed")):
-                    g = _geom(lib.mx_powmod_geometry_for, bits, max(batch, groups), groups, lpl)
+            for lpl in (0, 3, 6, 9, 18):
+                for groups in (1, max(2, batch // 40)):
+                    g = _generic_instance(lib, bits, max(batch, groups), groups, lpl)
                     if g is not None:
-                        out.add((name,) + g)
+                        out.add(g)
     return out

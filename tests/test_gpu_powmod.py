@@ -391,3 +391,34 @@ def test_fixed_window_tape_is_bit_identical_and_secret_independent_in_shape(eng)
         assert eng.powmod_nsquare_batch(cts, e, key_n) == [pow(c, e, key_n * key_n) for c in cts]
     finally:
         eng.set_fixed_window(False)
+
+
+@pytest.mark.parametrize("bits", [50, 131, 300, 600, 1029, 2050, 2053, 4100, 5359])
+def test_bipartite_latency_form(eng, bits):
+    """The bipartite form of the generic kernel (limbs_per_lane 6, csrc/mx_bimont.hpp: every product split over two
+    wavefronts, least-significant-first Montgomery steps on one, most-significant-first steps with a fold on the other):
+    bit-exact against pow() on special and random moduli, bases and exponents, per-group and shared exponents, ragged
+    batches, and the biprimality-test shape (40 bases per candidate)."""
+    rng = random.Random(bits * 31)
+    eng.set_limbs_per_lane(6)
+    try:
+        assert eng.generic_launch_form(bits, 80, 2)[0] == 2
+        specials = [(1 << bits) - 1, (1 << (bits - 1)) + 1, ((1 << bits) - 1) ^ (1 << (bits // 2)), (1 << bits) - (1 << (bits // 3)) - 1]
+        mods = [m | 1 for m in specials] + [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(3)]
+        exps = [(1 << min(bits, 70)) - 1, 1 << min(bits - 1, 60), 0, 1, 2, rng.getrandbits(min(bits, 150)) | 1, rng.getrandbits(bits)]
+        pat29 = lambda m: sum(((1 << 29) - 1) << (29 * k) for k in range(0, bits // 29 + 1, 2)) % m
+        rows = [[0, 1, m - 1, m // 2, pat29(m), (m - pat29(m)) % m] + [rng.randrange(m) for _ in range(5)] for m in mods]
+        assert eng.powmod_batch_multi(rows, exps, mods) == [[pow(b, e, m) for b in r] for r, e, m in zip(rows, exps, mods)]
+        # one exponent for the whole launch (mx_powmod_shared_lpl), a ragged batch
+        m, e = mods[-1], rng.getrandbits(min(bits, 200)) | 1
+        bases = [rng.randrange(m) for _ in range(13)] + [0, 1, m - 1]
+        assert eng.powmod_batch(bases, e, m) == [pow(b, e, m) for b in bases]
+        if bits in (1029, 2053):
+            # the shape it exists for: a keygen round's survivors, 40 bases each, full-length and half-length exponents
+            cands = [rng.getrandbits(bits) | (1 << (bits - 1)) | 1 for _ in range(7)]
+            gens = [[rng.randrange(c) for _ in range(40)] for c in cands]
+            for ebits in (bits - 2, bits // 2 + 3):
+                ex = [rng.getrandbits(ebits) | (1 << (ebits - 1)) for _ in cands]
+                assert eng.powmod_batch_multi(gens, ex, cands) == [[pow(g, e, c) for g in gs] for gs, e, c in zip(gens, ex, cands)]
+    finally:
+        eng.set_limbs_per_lane(0)

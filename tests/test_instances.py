@@ -42,6 +42,7 @@ def test_every_reachable_instance_has_a_parity_case():
         assert {k for kd, k, l, *w in reachable if kd == kind and l == 9} == {1, 2, 4, 8, 16, 32, 64}
         assert {k for kd, k, l, *w in reachable if kd == kind and l == 18} == {1, 2, 4, 8, 16, 32}
         assert {k for kd, k, l, *w in reachable if kd == kind and l == 3} == {1, 2, 4, 8, 16, 32, 64}       # latency instances
+    assert {k for kd, k, l, *w in reachable if kd == "generic-bi"} == {4, 8, 16, 32, 64}                   # bipartite form (round 5)
 
 
 def test_auto_launch_shapes_match_the_measured_crossovers():
