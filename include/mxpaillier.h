@@ -308,6 +308,8 @@ int mx_selftest_lanes(void* stream);
 #define MX_KNOB_N2_FRIENDLY_1W 4
 #define MX_KNOB_GENERIC_LATENCY 5
 #define MX_KNOB_N2_SPLIT 6
+#define MX_KNOB_LAT_LANES 8         /* 3-limb latency forms of the generic kernel: at least this many lanes per element (0 = the smallest group that holds the number) */
+#define MX_KNOB_BI_PIVOT 7          /* bipartite form of the generic kernel: multiplier limbs on the Montgomery wavefront (0 = the library's pivot) */
 int mx_debug_knob(int knob, int value);
 /* Enqueues a kernel of ONE wavefront that idles for `microseconds` (0..1 000 000) on `stream` and touches no
  * memory.  A concurrency probe: two streams that the HIP runtime has mapped to the same hardware queue run

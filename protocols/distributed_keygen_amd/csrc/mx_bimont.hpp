@@ -119,6 +119,7 @@ struct BiHi {
   int addr[L];        // LDS index of this lane's positions (clamped to 0 where the lane lies below the number)
   int waddr[L];       // ... for writes: a spare word behind the row instead
   u32 pos_ok[L];      // ~0 where the position exists
+  u32 data_ok[L];     // ~0 where it is a data position (0 <= position < Pd)
 
   __device__ __forceinline__ void init(int pd) {
     p = LN::pos();
@@ -139,6 +140,7 @@ struct BiHi {
       addr[j] = pos >= 0 ? pos : 0;
       waddr[j] = pos >= 0 ? pos : L * K;
       pos_ok[j] = pos >= 0 ? ~0u : 0u;
+      data_ok[j] = (pos >= 0 && pos < pd) ? ~0u : 0u;
     }
   }
 
@@ -220,13 +222,14 @@ struct BiHi {
     r[1] += (u32)(w >> W);
   }
 
-  // t (this half) + TL (wavefront L's half) -> the product: final fold of positions Pd .. Pd+5, limbs to C and to ar
-  __device__ __forceinline__ void tail(u64 (&t)[L], const u32* TL, u32* C, u32 (&ar)[L]) const {
-#pragma unroll
-    for (int j = 0; j < L; ++j) t[j] += (u64)(TL[addr[j]] & pos_ok[j]);
+  // The end of a product, in two parts around the hand-over.
+  // BEFORE it (wavefront L may still be working): sweep this half — the lazy columns hold up to 2^61, afterwards what stands
+  // at positions >= Pd is its true top —, clear those six positions and fold five of them (Pd+1 .. Pd+5: wavefront L's half
+  // has nothing there) back in; the sixth digit, position Pd, waits for L's limb there.  Returns that digit's own part.
+  __device__ __forceinline__ u32 pre(u64 (&t)[L]) const {
     u32 r[L];
-    sweep<true>(r, t);       // the lazy columns hold up to 2^61: after this what stands at positions >= Pd is the number's true top
-    // six digits: lane 0 holds positions Pd+5, Pd+4, Pd+3, lane 1 Pd+2, Pd+1, Pd
+    sweep<true>(r, t);
+    // lane 0 holds positions Pd+5, Pd+4, Pd+3, lane 1 Pd+2, Pd+1, Pd
     u32 dg[6];
     dg[5] = LN::bcast0(r[0]); dg[4] = LN::bcast0(r[1]); dg[3] = LN::bcast0(r[2]);
     dg[2] = LN::bcast0(LN::from_next_raw(r[0])); dg[1] = LN::bcast0(LN::from_next_raw(r[1])); dg[0] = LN::bcast0(LN::from_next_raw(r[2]));
@@ -234,13 +237,29 @@ struct BiHi {
     for (int j = 0; j < L; ++j) {
       u64 s = (u64)(r[j] & low_keep);
 #pragma unroll
-      for (int k = 0; k < 6; ++k) {
+      for (int k = 1; k < 6; ++k) {
         u32 f = fin[k][j];
         asm volatile("" : "+v"(f));            // a 32-bit multiplicand, not a hoisted register pair (see half())
         s += (u64)f * dg[k];
       }
       t[j] = s;
     }
+    return dg[0];
+  }
+
+  // AFTER it: + wavefront L's half (TL, position-indexed; its limb at Pd joins the last digit), fold that digit, sweep,
+  // publish the product's limbs in C and keep them in ar
+  __device__ __forceinline__ void post(u64 (&t)[L], u32 dg0, const u32* TL, u32* C, u32 (&ar)[L], int pd) const {
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] += (u64)(TL[addr[j]] & data_ok[j]);
+    const u32 d = dg0 + TL[pd];                // every lane reads the same word
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      u32 f = fin[0][j];
+      asm volatile("" : "+v"(f));
+      t[j] += (u64)f * d;
+    }
+    u32 r[L];
     sweep<false>(r, t);
 #pragma unroll
     for (int j = 0; j < L; ++j) {
@@ -311,6 +330,7 @@ __global__ void __launch_bounds__(128) powmod_bi_kernel(PowmodBiArgs A) {
   auto product = [&](auto sq_tag, const u32* B) {
     constexpr bool SQ = decltype(sq_tag)::value;
     u64 t[L];
+    u32 dg0 = 0;
     if (role == 0) {
       u32 r[L];
       M.lds = const_cast<u32*>(B);
@@ -319,9 +339,10 @@ __global__ void __launch_bounds__(128) powmod_bi_kernel(PowmodBiArgs A) {
       for (int j = 0; j < L; ++j) TL[p * L + j] = r[j];
     } else {
       H.template half<SQ>(t, a, B, A.pd, A.h_lo);
+      dg0 = H.pre(t);
     }
     __syncthreads();
-    if (role == 1) H.tail(t, TL, C, a);
+    if (role == 1) H.post(t, dg0, TL, C, a, A.pd);
     __syncthreads();
     if (role == 0) {
 #pragma unroll

@@ -22,6 +22,8 @@ Knob g_knob_n2_friendly_1w;
 Knob g_knob_generic_latency;
 Knob g_knob_n2_split;
 Knob g_knob_jacobi_max_batches;
+Knob g_knob_bi_pivot;
+Knob g_knob_lat_lanes;
 }
 MxProfile g_mx_profile;
 
@@ -64,12 +66,17 @@ double generic_estimate(int mod_bits, int64_t batch, int lpl) {
   if (lpl == LIMBS_PER_LANE_WIDE && g.K > 32) return -1.0;          // no <64, 18> instance
   const int64_t simds = (int64_t)4 * mx_device_cus();
   if (g.bi) {
-    // two wavefronts per 64 / K elements, each with about half the limb steps of the one-wavefront latency instance plus the
-    // hand-over of every product (tools/sweep_generic.py: 0.62 of its time alone on the SIMDs; a further pair per SIMD adds
-    // most of that again, so the form only pays while the launch leaves SIMDs idle)
-    const int64_t waves = 2 * ((batch * g.K + 63) / 64);
-    const int64_t per_simd = (waves + simds - 1) / simds;
-    return 0.62 * (1.0 + 0.9 * (double)(per_simd - 1));
+    // One workgroup = two wavefronts per 64 / K elements.  Alone on its compute unit a product costs the longer half plus
+    // the hand-over (tools/bi_pivot_sweep.py, tools/sweep_generic.py; profiles/r05_*): relative to the one-wavefront latency
+    // instance 0.5 + 20 / steps — 0.98 at key_length 1024 (42 steps: no gain), 0.77 at 2048 (75 steps), and 0.93 for groups
+    // of 64 lanes (key_length 3072 / 4096: the hand-over costs them more).  A second workgroup on a compute unit adds most of
+    // that again, so the form only pays while the launch leaves compute units idle.
+    const int steps = g.L * g.nblk + g.L;
+    const int64_t wgs = (batch * g.K + 63) / 64;
+    const int64_t cus = mx_device_cus();
+    const int64_t per_cu = (wgs + cus - 1) / cus;
+    const double t1 = g.K == 64 ? 0.93 : 0.5 + 20.0 / (double)steps;
+    return t1 * (1.0 + 0.9 * (double)(per_cu - 1));
   }
   const int64_t waves = (batch * g.K + 63) / 64;
   const int64_t per_simd = (waves + simds - 1) / simds;
@@ -331,6 +338,8 @@ int mx_debug_knob(int knob, int value) {
     case MX_KNOB_N2_FRIENDLY_1W: if (value > 1) return MX_ERR_ARG; g_knob_n2_friendly_1w = value; return MX_OK;
     case MX_KNOB_GENERIC_LATENCY: if (value > 2) return MX_ERR_ARG; g_knob_generic_latency = value; return MX_OK;
     case MX_KNOB_N2_SPLIT: if (value > 2) return MX_ERR_ARG; g_knob_n2_split = value; return MX_OK;
+    case MX_KNOB_BI_PIVOT: if (value > 192) return MX_ERR_ARG; g_knob_bi_pivot = value; return MX_OK;
+    case MX_KNOB_LAT_LANES: if (value > 64) return MX_ERR_ARG; g_knob_lat_lanes = value; return MX_OK;
   }
   return MX_ERR_ARG;
 }

@@ -22,6 +22,25 @@ constexpr int LIMBS_PER_LANE_LAT = 3;     // L of the latency geometry (many lan
 // split over two wavefronts (half the multiplier's limbs each) — "3 x 2"
 constexpr int LIMBS_PER_LANE_BI = 6;
 
+// Limbs per lane (3 latency / 9 narrow / 18 wide) and the other launch-shape choices are per-call ARGUMENTS of the
+// entry points; the entry points without such an argument leave the choice to the library.  The library reads NO
+// environment variable and keeps no tuning state that a production caller can set: what remains process-wide are the
+// developer knobs below (explicit mx_debug_knob calls, for A/B runs and for tests that must reach a fallback path), held
+// in atomics so that a knob flipped by one thread while another launches is a defined read of the old or the new value.
+struct Knob {
+  std::atomic<int> v{0};
+  operator int() const { return v.load(std::memory_order_relaxed); }
+  Knob& operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
+};
+extern Knob g_knob_n2_segments;        // MX_KNOB_N2_SEGMENTS: 0 = automatic
+extern Knob g_knob_n2_timeslice;       // MX_KNOB_N2_TIMESLICE: 0 = automatic, 1 = never, 2 = always (two-wavefront launches)
+extern Knob g_knob_n2_friendly_1w;     // MX_KNOB_N2_FRIENDLY_1W: 0 = friendly-modulus instances of the one-wavefront wide kernel where they exist, 1 = never
+extern Knob g_knob_n2_split;           // MX_KNOB_N2_SPLIT: 0 = mx_nsquare_launch_split reports a split where it pays, 1 = never, 2 = whenever a split exists
+extern Knob g_knob_generic_latency;    // MX_KNOB_GENERIC_LATENCY: 0 = the automatic choice may take the 3-limb instances of the generic kernel, 1 = never
+extern Knob g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
+extern Knob g_knob_lat_lanes;          // MX_KNOB_LAT_LANES: 0 = the smallest group that holds the number, v = at least v lanes per element for the 3-limb latency forms of the generic kernel
+extern Knob g_knob_bi_pivot;           // MX_KNOB_BI_PIVOT: 0 = the library's pivot of the bipartite form, v = v multiplier limbs on wavefront L (rounded down to a multiple of 3)
+
 struct Geometry {
   int K = 0;      // lanes per element
   int L = LIMBS_PER_LANE;
@@ -43,13 +62,22 @@ inline bool choose_geometry(int mod_bits, Geometry& g, int limbs_per_lane = LIMB
     const int per = g.W * g.L;
     g.nblk = (mod_bits + 35 + per - 1) / per;
     int k = 4;
-    while (k < g.nblk + 2) k <<= 1;
+    while (k < g.nblk + 2 || k < (int)g_knob_lat_lanes) k <<= 1;
     if (k > 64) return false;
     g.K = k;
     g.bi = 1;
     const int steps = g.L * g.nblk + g.L;                  // multiplier limbs Pd + 2 .. 0
-    g.h_lo = g.L * ((steps + 6) / (2 * g.L));              // wavefront H carries ~6 steps' worth of epilogue per product
+    // the pivot: a step of wavefront H costs 1.4 x a step of wavefront L (40 against 28-29 ns at key_length 2048: its fold
+    // digit feeds every multiply-add of the step) and H carries the end of the product, so L takes ~0.6 of the steps
+    // (tools/bi_pivot_sweep.py, profiles/r05_bi_pivot_sweep.txt: 27 of 42 at key_length 1024, 45 of 75 at 2048; groups of 64
+    // lanes — one element per wavefront pair, moduli beyond 2600 bits — are best at 0.45: 66 of 147 at key_length 4096)
+    g.h_lo = g.K == 64 ? g.L * ((45 * steps + 150) / (100 * g.L)) : g.L * ((61 * steps + 150) / (100 * g.L));
+    if (g_knob_bi_pivot > 0) g.h_lo = g.L * ((int)g_knob_bi_pivot / g.L);
     if (g.h_lo > steps - g.L) g.h_lo = steps - g.L;        // (tiny moduli: at least one block for wavefront H)
+    if (g.h_lo < g.L) g.h_lo = g.L;
+    // the factor that leaves the domain, 2^(W * (Pd - hL)), is a Montgomery operand of the epilogue: it must be below N
+    const int lo_min = g.L * ((g.L * g.nblk - (mod_bits - 2) / g.W + g.L - 1) / g.L);
+    if (g.h_lo < lo_min) g.h_lo = lo_min;
     return true;
   }
   g.L = limbs_per_lane;
@@ -59,7 +87,7 @@ inline bool choose_geometry(int mod_bits, Geometry& g, int limbs_per_lane = LIMB
   int per_blk = g.W * g.L;
   g.nblk = (need + per_blk - 1) / per_blk;
   int k = 1;
-  while (k < g.nblk) k <<= 1;
+  while (k < g.nblk || (limbs_per_lane == 3 && k < (int)g_knob_lat_lanes)) k <<= 1;
   if (k > 64) return false;
   g.K = k;
   return true;
@@ -215,23 +243,6 @@ inline std::vector<u32> pack_sliding_ops(const std::vector<SlidingOp>& ops) {
   }
   return out;
 }
-
-// Limbs per lane (3 latency / 9 narrow / 18 wide) and the other launch-shape choices are per-call ARGUMENTS of the
-// entry points; the entry points without such an argument leave the choice to the library.  The library reads NO
-// environment variable and keeps no tuning state that a production caller can set: what remains process-wide are the
-// developer knobs below (explicit mx_debug_knob calls, for A/B runs and for tests that must reach a fallback path), held
-// in atomics so that a knob flipped by one thread while another launches is a defined read of the old or the new value.
-struct Knob {
-  std::atomic<int> v{0};
-  operator int() const { return v.load(std::memory_order_relaxed); }
-  Knob& operator=(int x) { v.store(x, std::memory_order_relaxed); return *this; }
-};
-extern Knob g_knob_n2_segments;        // MX_KNOB_N2_SEGMENTS: 0 = automatic
-extern Knob g_knob_n2_timeslice;       // MX_KNOB_N2_TIMESLICE: 0 = automatic, 1 = never, 2 = always (two-wavefront launches)
-extern Knob g_knob_n2_friendly_1w;     // MX_KNOB_N2_FRIENDLY_1W: 0 = friendly-modulus instances of the one-wavefront wide kernel where they exist, 1 = never
-extern Knob g_knob_n2_split;           // MX_KNOB_N2_SPLIT: 0 = mx_nsquare_launch_split reports a split where it pays, 1 = never, 2 = whenever a split exists
-extern Knob g_knob_generic_latency;    // MX_KNOB_GENERIC_LATENCY: 0 = the automatic choice may take the 3-limb instances of the generic kernel, 1 = never
-extern Knob g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
 
 inline int64_t align256(int64_t x) { return (x + 255) & ~(int64_t)255; }
 

@@ -8,7 +8,8 @@ runtime initialises, so this process calls configure_hw_queues(16) before anythi
 
 what = "nsquare": powmod_nsquare at key_length 2048 with a full-length exponent in every launch shape (one- and
 two-wavefront groups, 3 / 9 / 18 limbs per lane, time-sliced), 4 x 10 000 rows = 4 x 625 wavefronts of the 18-limb shape
-on 1024 SIMDs; "biprime": biprime_v_t (Jacobi filter, selection, generic fixed-window modexps) at key_length 2048;
+on 1024 SIMDs; "biprime": biprime_v_t (Jacobi filter, selection, generic fixed-window modexps in every lane geometry incl. the
+bipartite latency form) at key_length 2048;
 "jacobi8192": the 257-word Jacobi instance; "k4096": the K = 16 friendly and time-sliced shapes at key_length 4096.
 Every row of every stream is compared with CPython pow() / the oracle computed on the host cores.  Prints "ok <what>"."""
 import multiprocessing as mp
@@ -104,7 +105,7 @@ def main() -> None:
                 jobs.extend((0, e, m) for _ in range(keep - len(sel)))          # unselected rows: modexp of a zero row
             want = pool.starmap(pow, jobs, chunksize=16)
             want_t = eng.to_device(L.pack(want, limbs))
-            for lpl in (9, 18):
+            for lpl in (9, 18, 3, 6):       # narrow, wide, and the latency instances on one and on two wavefronts (bipartite)
                 eng.set_limbs_per_lane(lpl)
                 in_flight(lambda: eng.biprime_v_t(g_t, mods_op, exps_op, gens, keep)[0], want_t, (what, lpl))
             cnt = eng.biprime_v_t(g_t, mods_op, exps_op, gens, keep)[1].cpu().tolist()

@@ -153,8 +153,8 @@ def test_four_streams_at_once_key4096_shapes():
 
 @pytest.mark.timeout(1200)
 def test_four_streams_at_once_biprime_v():
-    """biprime_v_t (Jacobi filter -> selection -> generic fixed-window modexps, both lane geometries) from four streams
-    at once: 4 x 600 candidates x 40 modexps at key_length 2048."""
+    """biprime_v_t (Jacobi filter -> selection -> generic fixed-window modexps: narrow, wide, latency and bipartite-latency
+    instances) from four streams at once: 4 x 600 candidates x 40 modexps at key_length 2048."""
     _worker("biprime", 600)
 
 

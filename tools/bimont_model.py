@@ -36,8 +36,10 @@ class Geometry:
             k <<= 1
         self.K = k
         steps = self.Pd + L                              # multiplier limbs Pd + 2 .. 0 (the top two are zero: alignment to L)
-        if not h_lo:                                     # balance: H carries ~6 steps' worth of epilogue
-            h_lo = min(L * ((steps + 6) // (2 * L)), steps - L)
+        if not h_lo:
+            # (the library's rule, mx_host.hpp choose_geometry: ~0.61 of the steps on wavefront L, 0.45 for groups of 64 lanes)
+            h_lo = min(L * (((45 if self.K == 64 else 61) * steps + 150) // (100 * L)), steps - L)
+        h_lo = max(h_lo, L, L * (-(-(self.Pd - (nbits - 2) // W) // L)))      # the factor that leaves the domain stays below N
         self.h_lo, self.h_hi = h_lo, steps - h_lo
         assert self.h_lo % L == 0 and self.h_hi % L == 0 and self.h_hi > 0
 
@@ -164,13 +166,9 @@ def half_hi_and_sum(geo: Geometry, cst: Constants, a, B, t_lo, square: bool, tra
                 w = sq_weight(geo.pos_hi(p, j), i) if square else 1
                 t[p][j] += ar[p][j] * bi * w + rf[p][j] * v
                 assert t[p][j] < U64
-    # + t_lo
-    for p in range(K):
-        for j in range(L):
-            t[p][j] += at(t_lo, p, j)
     def sweep(cols):
         """carry sweep towards the more significant end: column 2 -> 1 -> 0 inside a lane, then ONE hop to the lane above
-        (the mirror image of mx_mont.hpp normalize_weak): value preserved, every limb < 2^W + 2^7 afterwards"""
+        (the mirror image of mx_mont.hpp normalize_weak): value preserved, every limb < 2^W + 2^8 afterwards"""
         r = [[0] * L for _ in range(K)]
         cs = []
         for p in range(K):
@@ -193,21 +191,35 @@ def half_hi_and_sum(geo: Geometry, cst: Constants, a, B, t_lo, square: bool, tra
             assert max(r[p]) < (1 << W) + (1 << 8)
         return r
 
-    # the lazy columns hold up to 2^61: sweep first, so that what stands at positions >= Pd is the number's true top
+    # ---- BEFORE the hand-over (while wavefront L may still be working): sweep this half, so that what stands at
+    # positions >= Pd is its true top, and fold the five positions Pd+1 .. Pd+5 (wavefront L's half has nothing there)
     t = sweep(t)
-    # final fold: everything at positions >= Pd (lanes 0 and 1), six digits of at most W bits and a little
+    fin = [[[at(cst.rfin[k], p, j) for j in range(L)] for p in range(K)] for k in range(6)]
     digits = {}
     for p in range(2):
         for j in range(L):
             k = geo.pos_hi(p, j) - Pd
             assert 0 <= k < 6
-            digits[k] = t[p][j]
-            t[p][j] = 0
-    fin = [[[at(cst.rfin[k], p, j) for j in range(L)] for p in range(K)] for k in range(6)]
+            if k >= 1:
+                digits[k] = t[p][j]
+                t[p][j] = 0
     for p in range(K):
         for j in range(L):
-            for k in range(6):
+            for k in range(1, 6):
                 t[p][j] += fin[k][p][j] * digits[k]
+    # ---- AFTER the hand-over: + wavefront L's half; position Pd (this half's limb + L's limb there, 0 or 1) is the last
+    # digit; fold it, sweep, publish
+    for p in range(K):
+        for j in range(L):
+            t[p][j] += at(t_lo, p, j)
+    p0, j0 = 1, L - 1                                   # position Pd = Ptop - 5 lives in lane 1, column 2
+    assert geo.pos_hi(p0, j0) == Pd
+    digits[0] = t[p0][j0]
+    assert digits[0] < (1 << W) + (1 << 9)
+    t[p0][j0] = 0
+    for p in range(K):
+        for j in range(L):
+            t[p][j] += fin[0][p][j] * digits[0]
             assert t[p][j] < U64, t[p][j].bit_length()
     r = sweep(t)
     out = [0] * (L * K)

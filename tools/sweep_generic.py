@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """Duration of ONE launch of the generic-modulus modexp (per-candidate moduli and exponents, 40 bases per candidate: the
 biprimality-test shape, distributed_keygen.py:1084-1099) for every lane geometry over candidate counts — the data the
-automatic geometry of mx_powmod_multi_dev is chosen from (profiles/r04_sweep_generic.txt).
+automatic geometry of mx_powmod_multi_dev is chosen from (profiles/r05_sweep_generic.txt; L3x2 = limbs_per_lane 6, the
+bipartite latency form: 3 limbs per lane, every product on two wavefronts).
 usage: sweep_generic.py [key_length ...]"""
 import os
 import random
@@ -28,10 +29,10 @@ for key_length in [int(a) for a in sys.argv[1:]] or [1024, 2048]:
         mods_t = eng.to_device(L.pack(mods, limbs))
         exps_t = eng.to_device(L.pack(exps, L.limbs_for_bits(ebits)))
         print(f"key_length {key_length}, {what}: ms per launch of candidates x 40 modexps, one launch on an idle GPU")
-        print("candidates   L3      L9      L18     auto -> (K, L)")
+        print("candidates   L3     L3x2     L9      L18     auto -> (K, L, wavefronts per group)")
         for c in counts:
             row = []
-            for lpl in (3, 9, 18, 0):
+            for lpl in (3, 6, 9, 18, 0):
                 eng.set_limbs_per_lane(lpl)
                 best = 1e9
                 for rep in range(3):
@@ -41,9 +42,9 @@ for key_length in [int(a) for a in sys.argv[1:]] or [1024, 2048]:
                     torch.cuda.synchronize()
                     best = min(best, time.perf_counter() - t0)
                 row.append(best * 1e3)
-                if lpl == 3 and c <= 5:      # spot check
+                if lpl in (3, 6) and c <= 5:      # spot check
                     got = L.unpack(eng.to_host(out[:3]))
                     assert got == [pow(g[k], exps[0], mods[0]) for k in range(3)]
             eng.set_limbs_per_lane(0)
-            geo = eng.geometry(bits, 40 * c, c)
-            print(f"{c:9d} {row[0]:7.2f} {row[1]:7.2f} {row[2]:7.2f} {row[3]:7.2f}  -> {geo[:2]}", flush=True)
+            geo = eng.geometry(bits, 40 * c, c)[:2] + eng.generic_launch_form(bits, 40 * c, c)[:1]
+            print(f"{c:9d} {row[0]:7.2f} {row[1]:7.2f} {row[2]:7.2f} {row[3]:7.2f} {row[4]:7.2f}  -> {geo}", flush=True)
