@@ -64,8 +64,8 @@ SIMDS, NOMINAL_HZ = 1024, 2.4e9
 MAC_CYCLES, OTHER_CYCLES = 4.19, 2.28       # v_mad_u64_u32 (accumulator form) / plain VALU, >= 2 wavefronts per SIMD
 GUIDE_VECTOR_PEAK = SIMDS * NOMINAL_HZ / 2  # wave-instructions per second if every instruction issued in 2 cycles
 MAC_ISSUE_PEAK = SIMDS * NOMINAL_HZ / MAC_CYCLES
-INSTR_MODEL = ROOT / "profiles" / "r04_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits) + digest of the kernel sources
-HBM_MEASURED = ROOT / "profiles" / "r04_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
+INSTR_MODEL = ROOT / "profiles" / "r05_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits) + digest of the kernel sources
+HBM_MEASURED = ROOT / "profiles" / "r05_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def parse() -> argparse.Namespace:
@@ -202,7 +202,7 @@ def valu_roofline(kernel: str, instr_per_launch, launches: int, elapsed: float, 
         "kernel_ms": kernel_ms, "concurrent_launches": concurrent,
         "instructions_per_launch": instr_per_launch,
         "instructions_basis": "n_waves x (n_sqr x I_sqr + n_mul x I_mul + F): squarings/multiplications from the "
-                              "exponent's tape, per-instance constants fitted to SQ_INSTS_VALU (profiles/r04_instr_model.json, "
+                              "exponent's tape, per-instance constants fitted to SQ_INSTS_VALU (profiles/r05_instr_model.json, "
                               "refused when the digest of the kernel sources it records no longer matches)",
         "peak_basis": (f"{SIMDS} SIMDs x {NOMINAL_HZ / 1e9} GHz / (mac_share x {MAC_CYCLES} + (1 - mac_share) x {OTHER_CYCLES}) cycles: issue costs measured "
                        "on this chip with independent streams, wall clock and SQ_INSTS_VALU (profiles/r03_ubench_valu_peak.txt): integer "

@@ -1,7 +1,7 @@
 # usage (in the build container, after `gpurun -- bash tools/gpu_session.sh <tag> profile` merged gpurun_out/prof_<tag>):
 #   bash tools/collect_profiles.sh <tag>
 # Copies the outputs of tools/profile_round.sh into profiles/ under the names profiles/README.md lists.
-tag=${1:-r04}
+tag=${1:-r05}
 O=gpurun_out/prof_$tag; P=profiles
 [ -d $O ] || { echo "no $O"; exit 1; }
 for f in $O/bench_*.json; do cp $f $P/${tag}_$(basename $f); done
@@ -18,4 +18,7 @@ cp $O/summary_c3_single_stream_counters.txt $P/${tag}_c3_single_stream_counters_
 cp $O/summary_c3_saturated_issue_counters.txt $P/${tag}_c3_saturated_issue_counters_summary.txt
 cp $O/sweep_shapes.txt $P/${tag}_sweep_shapes.txt
 cp $O/small_batch_latency.txt $P/${tag}_small_batch_latency.txt
+cp $O/sweep_generic.txt $P/${tag}_sweep_generic.txt
+cp $O/bi_pivot_sweep.txt $P/${tag}_bi_pivot_sweep.txt
+cp $O/short_kernels.txt $P/${tag}_short_kernels.txt; cp $O/${tag}_short_kernels.json $P/
 ls $P | grep -c "^${tag}_"

@@ -2,7 +2,7 @@
 # Runs the bench lines and rocprofv3 passes whose summaries are copied into profiles/ (tools/prof_summary.py,
 # tools/hbm_traffic.py, tools/calibrate_instr.py, tools/sweep_shapes.py).  The library reads no environment; the
 # bench opts into 16 HIP hardware queues itself (protocols.distributed_keygen_amd.configure_hw_queues).
-tag=${1:-r04}
+tag=${1:-r05}
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=gpurun_out/prof_$tag; mkdir -p $O
@@ -28,6 +28,8 @@ MX_BENCH_FORCE_DIST=1 python bench.py --no-cpu-baseline --no-extras --steps 20 -
 MX_BENCH_FORCE_DIST=1 python bench.py --workload biprime --no-cpu-baseline > $O/bench_biprime_rccl_single_rank.json 2>/dev/null
 MX_BENCH_BACKEND=gloo python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29541 bench.py --gpus 2 --steps 8 --warmup 2 --no-cpu-baseline > $O/bench_two_ranks_gloo_one_gpu.json 2> $O/bench_two_ranks_gloo_one_gpu.err
 python tools/sweep_shapes.py 2048 4096 1024 > $O/sweep_shapes.txt 2>&1
+python tools/sweep_generic.py 1024 2048 > $O/sweep_generic.txt 2>&1
+python tools/bi_pivot_sweep.py 1024 2048 4096 > $O/bi_pivot_sweep.txt 2>&1
 python tools/latency_probe.py > $O/small_batch_latency.txt 2>&1
 # ---- kernel traces of the same commands
 cd /tmp
@@ -59,7 +61,12 @@ C5="python3 $R/bench.py --workload c5 --no-cpu-baseline --no-extras --streams 1 
 rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $R/$O/pmc_c5_sq -- $C5 > /dev/null 2>&1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_c5_fetch -- $C5 > /dev/null 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $R/$O/pmc_c5_write -- $C5 > /dev/null 2>&1
+# ---- the short kernels: instruction counts (one counter pass) and durations (one trace pass) of bench.short_kernel_cases
+rocprofv3 --pmc SQ_INSTS_VALU SQ_WAVES --kernel-trace --output-format csv -d $R/$O/sk_pmc -- python3 $R/tools/short_kernels.py run > /dev/null 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $R/$O/sk_trace -- python3 $R/tools/short_kernels.py run > /dev/null 2>&1
 cd $R
+python tools/short_kernels.py fit $O/sk_pmc $O/sk_trace profiles/${tag}_short_kernels.json > $O/short_kernels.txt 2>&1
+cp profiles/${tag}_short_kernels.json $O/
 python tools/hbm_traffic.py n2_k2048_b10000_L18 "powmod_n2_kernel" $O/pmc_c3_fetch $O/pmc_c3_write 6 2 > /dev/null
 python tools/hbm_traffic.py n2_k2048_b10000_L9 "powmod_n2_split_kernel" $O/pmc_split_fetch $O/pmc_split_write 6 > /dev/null
 python tools/hbm_traffic.py biprime_b2053_c4096_L18 "mx::powmod_kernel" $O/pmc_biprime_fetch $O/pmc_biprime_write 3 > /dev/null
@@ -73,5 +80,5 @@ python tools/prof_summary.py $O/summary_c3_single_stream_counters.txt $O/pmc_c3_
 python tools/prof_summary.py $O/summary_c3_saturated_issue_counters.txt $O/pmc_sat_a $O/pmc_sat_a $O/pmc_sat_b $O/pmc_sat_c > /dev/null
 for f in trace_driver_flags trace_single_batch trace_biprime trace_c5; do cp $(find $O/$f -name "*_kernel_stats.csv" | head -1) $O/${f}_kernel_stats.csv; done
 for f in pmc_c3_sq pmc_split_sq pmc_sat_a pmc_sat_b pmc_sat_c; do g=$(find $O/$f -name "*counter_collection.csv" | head -1); [ -n "$g" ] && gzip -c $g > $O/${f}_raw_counters.csv.gz; done
-rm -rf $O/trace_*/ $O/pmc_*/
+rm -rf $O/trace_*/ $O/pmc_*/ $O/sk_pmc $O/sk_trace
 ls $O | wc -l
