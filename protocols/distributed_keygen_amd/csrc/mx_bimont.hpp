@@ -183,20 +183,40 @@ struct BiHi {
   __device__ __forceinline__ void half(u64 (&t)[L], const u32 (&ar)[L], const u32* B, int pd, int h_lo) const {
 #pragma unroll
     for (int j = 0; j < L; ++j) t[j] = 0;
-    u32 n2 = B[pd + 2], n1 = B[pd + 1], n0 = B[pd];
     u32 al[L], rl[L], one = onev, one2 = onev;
 #pragma unroll
     for (int j = 0; j < L; ++j) { al[j] = ar[j]; rl[j] = rf[j]; }
-    for (int i = pd + 2; i >= h_lo; i -= 3) {
-      // loop-invariant 32-bit multiplicands: opaque once per block, or the compiler hoists their zero-extension out of the
-      // loop and multiplies register PAIRS (two multiply-adds per product; mx_mont.hpp mulx has the same guard)
+    // loop-invariant 32-bit multiplicands: opaque once per trip, or the compiler hoists their zero-extension out of the loop
+    // and multiplies register PAIRS (two multiply-adds per product; mx_mont.hpp mulx has the same guard)
+    auto opaque = [&]() {
 #pragma unroll
       for (int j = 0; j < L; ++j) { asm volatile("" : "+v"(al[j])); asm volatile("" : "+v"(rl[j])); }
       asm volatile("" : "+v"(one));
       asm volatile("" : "+v"(one2));
-      const u32 b2 = n2, b1 = n1, b0 = n0;
-      const int nx = i - 3 >= h_lo ? i - 3 : i;                      // the next block's limbs, fetched behind this block's work
-      n2 = B[nx]; n1 = B[nx - 1]; n0 = B[nx - 2];
+    };
+    int i = pd + 2;
+    // three blocks (nine limb steps) per trip — the loop control and address arithmetic of a one-block trip are a fifth of
+    // its instructions —, the next trip's multiplier limbs fetched behind this trip's work
+    if (i - 8 >= h_lo) {
+      u32 nb[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) nb[k] = B[i - k];
+      for (; i - 8 >= h_lo; i -= 9) {
+        opaque();
+        u32 b[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b[k] = nb[k];
+        const int nx = i - 17 >= h_lo ? i - 9 : i;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) nb[k] = B[nx - k];
+        step<SQ, 2>(t, al, rl, one, one2, b[0]); step<SQ, 1>(t, al, rl, one, one2, b[1]); step<SQ, 0>(t, al, rl, one, one2, b[2]);
+        step<SQ, 2>(t, al, rl, one, one2, b[3]); step<SQ, 1>(t, al, rl, one, one2, b[4]); step<SQ, 0>(t, al, rl, one, one2, b[5]);
+        step<SQ, 2>(t, al, rl, one, one2, b[6]); step<SQ, 1>(t, al, rl, one, one2, b[7]); step<SQ, 0>(t, al, rl, one, one2, b[8]);
+      }
+    }
+    for (; i >= h_lo; i -= 3) {
+      opaque();
+      const u32 b2 = B[i], b1 = B[i - 1], b0 = B[i - 2];
       step<SQ, 2>(t, al, rl, one, one2, b2);
       step<SQ, 1>(t, al, rl, one, one2, b1);
       step<SQ, 0>(t, al, rl, one, one2, b0);

@@ -68,14 +68,14 @@ double generic_estimate(int mod_bits, int64_t batch, int lpl) {
   if (g.bi) {
     // One workgroup = two wavefronts per 64 / K elements.  Alone on its compute unit a product costs the longer half plus
     // the hand-over (tools/bi_pivot_sweep.py, tools/sweep_generic.py; profiles/r05_*): relative to the one-wavefront latency
-    // instance 0.5 + 20 / steps — 0.98 at key_length 1024 (42 steps: no gain), 0.77 at 2048 (75 steps), and 0.93 for groups
-    // of 64 lanes (key_length 3072 / 4096: the hand-over costs them more).  A second workgroup on a compute unit adds most of
+    // instance 0.42 + 22 / steps — 0.94 at key_length 1024 (42 steps), 0.71 at 2048 (75 steps) — and 0.84 for groups of 64
+    // lanes (key_length 3072 / 4096: the hand-over costs them more).  A second workgroup on a compute unit adds most of
     // that again, so the form only pays while the launch leaves compute units idle.
     const int steps = g.L * g.nblk + g.L;
     const int64_t wgs = (batch * g.K + 63) / 64;
     const int64_t cus = mx_device_cus();
     const int64_t per_cu = (wgs + cus - 1) / cus;
-    const double t1 = g.K == 64 ? 0.93 : 0.5 + 20.0 / (double)steps;
+    const double t1 = g.K == 64 ? 0.84 : 0.42 + 22.0 / (double)steps;
     return t1 * (1.0 + 0.9 * (double)(per_cu - 1));
   }
   const int64_t waves = (batch * g.K + 63) / 64;

@@ -67,11 +67,11 @@ inline bool choose_geometry(int mod_bits, Geometry& g, int limbs_per_lane = LIMB
     g.K = k;
     g.bi = 1;
     const int steps = g.L * g.nblk + g.L;                  // multiplier limbs Pd + 2 .. 0
-    // the pivot: a step of wavefront H costs 1.4 x a step of wavefront L (40 against 28-29 ns at key_length 2048: its fold
-    // digit feeds every multiply-add of the step) and H carries the end of the product, so L takes ~0.6 of the steps
-    // (tools/bi_pivot_sweep.py, profiles/r05_bi_pivot_sweep.txt: 27 of 42 at key_length 1024, 45 of 75 at 2048; groups of 64
-    // lanes — one element per wavefront pair, moduli beyond 2600 bits — are best at 0.45: 66 of 147 at key_length 4096)
-    g.h_lo = g.K == 64 ? g.L * ((45 * steps + 150) / (100 * g.L)) : g.L * ((61 * steps + 150) / (100 * g.L));
+    // the pivot: a step of wavefront H costs ~1.15 x a step of wavefront L (32 against 28 ns at key_length 2048) and H carries
+    // the end of the product, so L takes a little more than half of the steps (tools/bi_pivot_sweep.py,
+    // profiles/r05_bi_pivot_sweep.txt: best at 24 of 42 steps at key_length 1024, 39 of 75 at 2048; groups of 64 lanes — one
+    // element per wavefront pair, moduli beyond 2600 bits — at 54 of 147 at key_length 4096)
+    g.h_lo = g.K == 64 ? g.L * ((37 * steps + 150) / (100 * g.L)) : g.L * ((46 * steps + 600) / (100 * g.L));
     if (g_knob_bi_pivot > 0) g.h_lo = g.L * ((int)g_knob_bi_pivot / g.L);
     if (g.h_lo > steps - g.L) g.h_lo = steps - g.L;        // (tiny moduli: at least one block for wavefront H)
     if (g.h_lo < g.L) g.h_lo = g.L;

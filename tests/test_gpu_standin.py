@@ -103,8 +103,8 @@ def test_concurrent_single_decrypts_are_coalesced_on_the_hip_engine(eng):
             assert [e.value for e in got] == msgs * 3 and all(not c.fresh for c in cobjs)
         stats = patch.coalescer(sh.PACKAGE).stats
         assert stats["partial_launches"] == 12 and stats["combine_launches"] == 12          # <= 3 launches per party and burst
-        print(f"3 parties x {count} concurrent decrypt(): {[round(w * 1e3, 1) for w in walls]} ms per burst")
-        assert min(walls) < 0.060, walls
+        print(f"3 parties x {count} concurrent decrypt(): {[round(w * 1e3, 1) for w in walls]} ms per burst (inside the suite's process)")
+        assert min(walls) < 0.25, walls            # 768 lone launches would be ~10 s; the strict bound is checked in a fresh process below
         # per-coroutine errors: one tampered partial decryption on the wire poisons exactly the recombinations that use it
         victim_tag = bin(cts[7]).zfill(32)[2:34]
         hub = parties[0].pool.hub
@@ -178,7 +178,28 @@ def test_colocated_parties_share_the_launches_of_a_keygen_round(eng):
     per_round_a, per_round_b = st_a["busy_s"] / rounds_a, st_b["busy_s"] / rounds_b
     print(f"keygen K=1024, 1024 candidates/round, 3 co-located parties, {rounds_a} rounds: engine busy per round "
           f"{per_round_a * 1e3:.1f} ms one launch per party -> {per_round_b * 1e3:.1f} ms shared launches")
-    assert per_round_b <= 0.5 * per_round_a, (per_round_a, per_round_b)
+    assert per_round_b < per_round_a, (per_round_a, per_round_b)       # the factor is asserted in a fresh process below
+
+
+@pytest.mark.timeout(900)
+def test_coalescing_wall_clock_in_a_fresh_process():
+    """The two wall-clock claims of VERDICT r04 items 2 and 6, measured where a user would see them — a process of its own
+    (tests/coalesce_timing_worker.py; the suite's process has used dozens of streams and is time-sliced): 3 parties x 256
+    concurrent decrypt() in <= 60 ms per burst, and a co-located keygen round at <= 0.5 x the engine time."""
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+
+    worker = Path(__file__).resolve().parent / "coalesce_timing_worker.py"
+    r = subprocess.run([sys.executable, str(worker)], capture_output=True, text=True, timeout=800)
+    assert r.returncode == 0, f"rc={r.returncode}\n{r.stdout[-800:]}\n{r.stderr[-3000:]}"
+    lines = [json.loads(ln) for ln in r.stdout.splitlines() if ln.startswith("{")]
+    bursts = next(d["decrypt_bursts_ms"] for d in lines if "decrypt_bursts_ms" in d)
+    separate, shared = next(d["keygen_busy_ms_per_round"] for d in lines if "keygen_busy_ms_per_round" in d)
+    print(f"fresh process: decrypt bursts {bursts} ms; keygen engine time per round {separate} -> {shared} ms")
+    assert min(bursts) <= 60.0, bursts
+    assert shared <= 0.5 * separate, (separate, shared)
 
 
 def test_rebound_leaf_runs_the_standins_own_scalar_methods_on_the_engine(eng):

@@ -37,8 +37,9 @@ class Geometry:
         self.K = k
         steps = self.Pd + L                              # multiplier limbs Pd + 2 .. 0 (the top two are zero: alignment to L)
         if not h_lo:
-            # (the library's rule, mx_host.hpp choose_geometry: ~0.61 of the steps on wavefront L, 0.45 for groups of 64 lanes)
-            h_lo = min(L * (((45 if self.K == 64 else 61) * steps + 150) // (100 * L)), steps - L)
+            # (the library's rule, mx_host.hpp choose_geometry: a little more than half of the steps on wavefront L, 0.37 of
+            # them for groups of 64 lanes — fitted to tools/bi_pivot_sweep.py)
+            h_lo = min(L * ((37 * steps + 150) // (100 * L)) if self.K == 64 else L * ((46 * steps + 600) // (100 * L)), steps - L)
         h_lo = max(h_lo, L, L * (-(-(self.Pd - (nbits - 2) // W) // L)))      # the factor that leaves the domain stays below N
         self.h_lo, self.h_hi = h_lo, steps - h_lo
         assert self.h_lo % L == 0 and self.h_hi % L == 0 and self.h_hi > 0
