@@ -911,9 +911,10 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
 # one key-generation round, Python ints in -> verdicts out (distributed_keygen.py:1284-1360)
 # ---------------------------------------------------------------------------------------------------
 def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 5, t: int = 2,
-                     batch_sizes=(1024, 16384, 65536)) -> dict:
+                     batch_sizes=(100, 1024, 16384, 65536)) -> dict:
     """What patch.compute_modulus does per round (biprime.BiprimeRound), timed from Python ints to Python verdicts for
-    `batch_size` candidates: every party's Shamir shares of the candidate moduli -> reconstruct + sieve (one device
+    `batch_size` candidates (100 = the reference's default, distributed_keygen.py:102: ~2 survivors, whose 80 modexps run the
+    bipartite latency form): every party's Shamir shares of the candidate moduli -> reconstruct + sieve (one device
     pass; the survivors' moduli stay on the device) -> survivors' v values (Jacobi filter, selection, 40 modexps each;
     this party's rows stay on the device) -> verdicts (the peers' columns packed with one codec call per party).  The exchange rounds in between (shares,
     jointly random generators, the other parties' v values) are network traffic in the reference and are prepared
@@ -976,6 +977,10 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
             cur["total_s"] = sum(cur.values())
             if best is None or cur["total_s"] < best["total_s"]:
                 best = cur
+        if not surv:                                                          # a small round may leave no survivor
+            best.update({"batch_size": B, "survivors": 0, "candidates_per_s": B / best["total_s"], "modexps": 0, "biprimes_found": 0})
+            out["rounds"][f"b{B}"] = best
+            continue
         # spot checks against the definitions (CPython)
         k0 = surv[0]
         assert has_div[k0] is False and sum(1 for b in has_div if not b) == len(surv)
@@ -995,7 +1000,7 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
         best.update({"batch_size": B, "survivors": len(surv), "candidates_per_s": B / best["total_s"],
                      "modexps": 40 * len(surv), "biprimes_found": sum(1 for v in verdicts if v is True)})
         out["rounds"][f"b{B}"] = best
-        if sample_job is None:
+        if sample_job is None and B >= 1024:
             ns, nc = 3, 256
             sample_job = {"prime": hex(prime), "points": points, "columns": {str(i): [hex(v) for v in columns[i][:nc]] for i in points},
                           "prime_list": prime_list, "moduli_check": [hex(m) for m in mods[:8]],

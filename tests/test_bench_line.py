@@ -11,7 +11,7 @@ sys.path.insert(0, str(ROOT))
 
 CONTRACT = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
             "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline")
-CANNED = sorted((ROOT / "profiles").glob("r0[34]_bench_*.json"))
+CANNED = sorted((ROOT / "profiles").glob("r0[345]_bench_*.json"))
 
 
 @pytest.fixture(scope="module")
