@@ -1417,6 +1417,11 @@ def main() -> None:
                 out["single_batch"] = guarded("single_batch", lambda: leg_single_batch(eng, torch, wl, key_length))
                 out["latency"] = guarded("latency", lambda: leg_latency(eng, torch, wl, (out.get("cpu_baseline") or {}).get("single_core_value")))
                 out["end_to_end"] = guarded("end_to_end", lambda: leg_end_to_end(eng, torch, wl, out["value"]))
+                if args.workload == "c3" and key_length == 2048:
+                    # (before the legs that keep up to eight steps in flight: a process that has used dozens of streams is
+                    # time-sliced by the queue scheduler, and the small rounds of this leg — a 6 ms launch — then measure
+                    # that, 13.6 instead of 5.4 ms per v-calculation, not the engine: profiles/r05_keygen_round_small.txt)
+                    out["end_to_end_keygen"] = guarded("end_to_end_keygen", lambda: leg_keygen_round(eng, torch, args))
                 del wl
                 torch.cuda.empty_cache()
                 out["extra"] = {}
@@ -1456,7 +1461,6 @@ def main() -> None:
                     # profiles/r04_decrypt_lanes.txt — past four lanes the recombination shares the lane's stream)
                     out["extra"]["c5_k4096_b1024"] = guarded("c5_k4096_b1024", lambda: c5_leg(1024, 24, 8, False))
                     out["extra"]["c5_k4096_b16384"] = guarded("c5_k4096_b16384", lambda: c5_leg(16384, 4, 2, False))
-                    out["end_to_end_keygen"] = guarded("end_to_end_keygen", lambda: leg_keygen_round(eng, torch, args))
                     out["short_kernels"] = guarded("short_kernels", lambda: leg_short_kernels(eng, torch))
         if world > 1 and not args.no_extras and args.workload == "c3" and not args.generic_modulus:
             # configs[3] on N GPUs inside the driver's scaling run: 4096 candidates sharded over the ranks,
