@@ -1147,6 +1147,8 @@ class Engine:
         _lib.check(rc, "mx_select_first")
         return out_t, cnt_t
 
+    JACOBI_ONE_LAUNCH_SYMBOLS = 16384        # 256 wavefronts: a quarter of the SIMDs
+
     def biprime_v_t(self, g_t, mods, exps, group_size: int, keep: int):
         """Tensor-level v-calculation of DK:1084-1099 for many candidates, nothing leaving the device:
         g_t int32 [groups*group_size, limbs] (the jointly random generators, reduced) -> (v rows int32
@@ -1159,6 +1161,11 @@ class Engine:
         # half of them: the first 2.6 * keep generators yield `keep` ones for > 99 % of the candidates,
         # and the tail of the list is evaluated only for the candidates where they did not.
         head = min(group_size, (13 * keep + 4) // 5)
+        # ... unless the launch is so small that it lasts as long as ONE thread's symbol whatever its size (a round at the
+        # reference's batch sizes: 0.8 ms for 1 .. 20 candidates x 104 or x 160 symbols at key_length 2048,
+        # profiles/r05_keygen_round_small.txt): a second launch would only add its latency
+        if mods_op[0].shape[0] * group_size <= self.JACOBI_ONE_LAUNCH_SYMBOLS:
+            head = group_size
 
         def filter_and_select():
             j_t = self.jacobi_t(g_t, mods_op, group_size, first=0, count=head)

@@ -509,10 +509,17 @@ def test_biprime_v_two_phase_jacobi_selection(eng):
         assert len(gens[-1]) == 160
     p = [rng.getrandbits(510) for _ in mods]
     q = [rng.getrandbits(510) for _ in mods]
-    for index in (1, 2):
-        got = biprime.biprime_test_v_calculation_batch(gens, index, mods, p, q, 40, eng)
-        want = [oracle.biprime_test_v_calculation(g, index, m, pi, qi, 40) for g, m, pi, qi in zip(gens, mods, p, q)]
-        assert got == want
+    # (a launch this small evaluates all 160 symbols at once — a second launch would only add its latency —, so the
+    # two-phase path is forced for one pass: both must give the reference's selection)
+    for one_launch_below in (0, type(eng).JACOBI_ONE_LAUNCH_SYMBOLS):
+        eng.JACOBI_ONE_LAUNCH_SYMBOLS = one_launch_below
+        try:
+            for index in (1, 2):
+                got = biprime.biprime_test_v_calculation_batch(gens, index, mods, p, q, 40, eng)
+                want = [oracle.biprime_test_v_calculation(g, index, m, pi, qi, 40) for g, m, pi, qi in zip(gens, mods, p, q)]
+                assert got == want, (one_launch_below, index)
+        finally:
+            del eng.JACOBI_ONE_LAUNCH_SYMBOLS
     assert [len(w) for w in want] == [40, 40, 40, 40, 40, 40, 40, 40, 40, 39, 39, 10]
     # a short generator list (no tail at all) and keep larger than the list
     got = biprime.biprime_test_v_calculation_batch([g[:30] for g in gens], 1, mods, p, q, 40, eng)
