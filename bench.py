@@ -924,6 +924,12 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
 
     from protocols.distributed_keygen_amd import biprime, shamir, synthetic
 
+    # launch shapes: the library's own choice per launch, as a caller of patch.install() gets them (the headline leg leaves
+    # its explicit 18-limb shape on the engine: a small round then ran the WIDE generic kernel, 12.7 instead of 4.3 ms for
+    # its few dozen modexps — rounds 3 and 4 reported b1024 that way)
+    saved_shape = (eng._lpl, eng._wpg)
+    eng.set_limbs_per_lane(0)
+    eng.set_wavefronts_per_group(0)
     rng = random.Random(0xD15C0 + 77)
     half = key_length // 2
     degree = 2 * t
@@ -1035,6 +1041,8 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
                     res["v_calculation_s_per_survivor"] + res["verdict_s_per_survivor"])
                 base["rounds"][name] = {"cpu_round_s": cpu_s, "candidates_per_s": rd["batch_size"] / cpu_s, "gpu_speedup": cpu_s / rd["total_s"]}
             out["cpu_baseline"] = base
+    eng.set_limbs_per_lane(saved_shape[0])
+    eng.set_wavefronts_per_group(saved_shape[1])
     return out
 
 
