@@ -955,7 +955,7 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
     for B in batch_sizes:
         by_party = {i: columns[i][:B] for i in points}
         best = None
-        for rep in range(2):                                                 # the first pass warms allocations
+        for rep in range(2 if B > 1024 else 4):                              # the first pass warms allocations (small rounds: a few more)
             torch.cuda.synchronize()
             t0 = time.perf_counter()
             rnd = biprime.BiprimeRound(eng)                                      # what patch.compute_modulus runs per round
