@@ -20,7 +20,8 @@
 // mx_mont.hpp's does (towards lane 0, by the same DPP moves) and its fold digit is born where the quotient digit is (lane 0:
 // the same broadcast).  H then adds L's half (handed over through LDS), folds the six top positions, sweeps the carries and
 // publishes the product in LDS, position-indexed — which is at once the next multiplier (every lane of either wavefront reads
-// any limb of it) and the hand-over of the accumulator to L.  Two workgroup barriers per product.
+// any limb of it) and the hand-over of the accumulator to L.  Two workgroup barriers per product (a workgroup holds two such
+// pairs, which execute the same sequence of products).
 //
 // Width discipline (asserted by the model): columns are lazy 64-bit sums as in mx_mont.hpp; the words that cross lanes are a
 // W-bit limb and a carry word < 2^32; the fold digit is < 2^32 because the TWO most significant lanes of H take no products and
@@ -290,33 +291,39 @@ struct BiHi {
 };
 
 // ---- the kernel --------------------------------------------------------------------------------------------------------------
+// A workgroup is TWO such pairs — four wavefronts, one per SIMD of a compute unit (with one pair per workgroup the dispatcher
+// puts the wavefronts of a second workgroup on SIMDs the first already uses: 500 pairs took 6.0 ms where 250 take 4.3).
+constexpr int BI_PAIRS = 2;
+
 template <int K, int W>
-__global__ void __launch_bounds__(128) powmod_bi_kernel(PowmodBiArgs A) {
+__global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs A) {
   constexpr int L = 3, PW = L * K, GPW = 64 / K;
   using M_t = Mont<K, L, W, true, false>;        // wavefront-level fences only: the two wavefronts run different code
   using H_t = BiHi<K, W>;
   constexpr int ROW = PW + 4;                    // a position-indexed row + a spare word for wavefront H's out-of-range lanes
   constexpr int GROUP_WORDS = 3 * ROW + M_t::LDS_WORDS;
   extern __shared__ u32 smem[];
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 = wavefront L, 1 = wavefront H
+  const int role = __builtin_amdgcn_readfirstlane((int)((threadIdx.x >> 6) & 1));     // 0 = wavefront L, 1 = wavefront H
+  const int pair = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 7));           // which pair of the workgroup
   const int lane = threadIdx.x & 63;
   const int gw = lane / K;
-  u32* C = smem + gw * GROUP_WORDS;              // the accumulator, position-indexed: multiplier of a squaring, hand-over H -> L
+  u32* C = smem + (pair * GPW + gw) * GROUP_WORDS;   // the accumulator, position-indexed: multiplier of a squaring, hand-over H -> L
   u32* F = C + ROW;                              // multiplier of a multiplication (a table row)
   u32* TL = F + ROW;                             // wavefront L's half of a product, hand-over L -> H
   u32* ST = TL + ROW;                            // staging of Mont::load / store / mul (wavefront L only)
-  const i64 elem_raw = (i64)blockIdx.x * GPW + gw;
+  const i64 pair_id = (i64)blockIdx.x * BI_PAIRS + pair;
+  const i64 elem_raw = pair_id * GPW + gw;
   const bool valid = elem_raw < A.batch;
-  const i64 elem = valid ? elem_raw : A.batch - 1;
+  const i64 elem = valid ? elem_raw : A.batch - 1;       // surplus groups (and a surplus pair) redo the last element, no store
   const i64 grp = elem / A.group_size;
-  const i64 nlanes = (i64)gridDim.x * 64;
+  const i64 nlanes = (i64)gridDim.x * BI_PAIRS * 64;
   const u32* crow = A.consts + grp * BI_ROWS * PW;
   const int nblk_lo = A.h_lo / L;
 
   M_t M;
   H_t H;
   u32 a[L];                                      // the accumulator: L in its layout, H in the reversed one
-  u32* tbl = A.table + (i64)blockIdx.x * 64 + lane;
+  u32* tbl = A.table + pair_id * 64 + lane;
   const int p = lane & (K - 1);
 
   // ---- prologue: L converts the base and stages it, H collects its constants

@@ -72,7 +72,7 @@ double generic_estimate(int mod_bits, int64_t batch, int lpl) {
     // lanes (key_length 3072 / 4096: the hand-over costs them more).  A second workgroup on a compute unit adds most of
     // that again, so the form only pays while the launch leaves compute units idle.
     const int steps = g.L * g.nblk + g.L;
-    const int64_t wgs = (batch * g.K + 63) / 64;
+    const int64_t wgs = ((batch * g.K + 63) / 64 + mx::BI_PAIRS - 1) / mx::BI_PAIRS;      // four wavefronts each: one per SIMD of a CU
     const int64_t cus = mx_device_cus();
     const int64_t per_cu = (wgs + cus - 1) / cus;
     const double t1 = g.K == 64 ? 0.84 : 0.42 + 22.0 / (double)steps;
@@ -105,6 +105,10 @@ bool plan_powmod(int mod_bits, int limbs, int exp_limbs, int64_t batch, int64_t 
   int gpw = 64 / p.geo.K;
   p.nblocks = (batch + gpw - 1) / gpw;
   p.nlanes = p.nblocks * 64;
+  if (p.geo.bi) {                               // workgroups of BI_PAIRS wavefront pairs; the table has a column per lane of every pair
+    p.nblocks = (p.nblocks + mx::BI_PAIRS - 1) / mx::BI_PAIRS;
+    p.nlanes = p.nblocks * mx::BI_PAIRS * 64;
+  }
   int64_t o = 0;
   p.off_mods = o;  o += align256((int64_t)groups * limbs * 4);
   p.off_rmodn = o; o += align256((int64_t)groups * limbs * 4);

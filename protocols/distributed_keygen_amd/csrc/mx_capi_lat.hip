@@ -37,9 +37,9 @@ static int launch_rmodn(const mx::RmodnArgs& a, hipStream_t s) {
 template <int K>
 static int launch_bi(const mx::PowmodBiArgs& a, int64_t nblocks, hipStream_t s) {
   using M_t = mx::Mont<K, LIMBS_PER_LANE_LAT, LIMB_BITS, true, false>;
-  const size_t lds = (size_t)(64 / K) * (3 * (LIMBS_PER_LANE_LAT * K + 4) + M_t::LDS_WORDS) * 4;
+  const size_t lds = (size_t)mx::BI_PAIRS * (64 / K) * (3 * (LIMBS_PER_LANE_LAT * K + 4) + M_t::LDS_WORDS) * 4;
   MxKernelTimer timer(s);
-  hipLaunchKernelGGL((mx::powmod_bi_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(128), lds, s, a);
+  hipLaunchKernelGGL((mx::powmod_bi_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(128 * mx::BI_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());
   return MX_OK;
 }
