@@ -38,7 +38,7 @@ sys.path.insert(0, str(ROOT))
 
 W = 29
 WAVES = 4
-KERNEL_SOURCES = ["mx_lanes.hpp", "mx_mont.hpp", "mx_powmod.hpp", "mx_powmod_n2.hpp", "mx_powmod_n2_split.hpp", "mx_bimont.hpp"]
+KERNEL_SOURCES = ["mx_lanes.hpp", "mx_mont.hpp", "mx_powmod.hpp", "mx_powmod_n2.hpp", "mx_powmod_n2_split.hpp"]     # the sources of the MODELLED kernels (the bipartite form, mx_bimont.hpp, has no entry)
 
 
 def kernel_sources_digest() -> str:
