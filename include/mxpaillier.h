@@ -126,7 +126,8 @@ int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* 
  * 1..64, 0 = automatic (4 for long exponents on large batches, else 1).  Same result bit for bit.
  * A two-wavefront launch with somewhat more groups of elements than the GPU holds at once runs in the time-sliced
  * form (mx_nsquare_launch_timesliced): ONE launch of resident workgroups whose wavefront pairs take the segments of
- * all groups from a queue kept in the workspace; `segments` (at most 16 then) is the number of units per group. */
+ * all groups from queues kept in the workspace (the group with the most work left first); `segments` (at most 16 then)
+ * is the number of units per group. */
 typedef struct mx_nsquare_plan {
   const void* d_plan;     /* device block written by prepare */
   int64_t plan_bytes;
@@ -360,7 +361,8 @@ int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_lane, int w
 /* Whether mx_powmod_nsquare_run runs this launch in the time-sliced form of the two-wavefront kernel: a fixed number
  * of resident workgroups per CU that take (segment, group of elements) units from a queue in the workspace, chosen
  * when a lone launch has somewhat more groups than the GPU holds at once (e.g. 10 000 ciphertexts at key_length
- * 2048: 47 ms instead of 54).  *resident_per_cu = 0: the plain launch; otherwise the workgroups per CU and
+ * 2048: 41 ms instead of 52-60; 18 limbs per lane, one workgroup per CU, 8 units per group).  *resident_per_cu = 0:
+ * the plain launch; otherwise the workgroups per CU and
  * *units_per_group the segments each group is cut into when run is called with segments = 0. */
 int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                                  int* resident_per_cu, int* units_per_group);
@@ -375,10 +377,10 @@ int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, in
 /* For callers that own a second stream: whether ONE batch is better run as two launches side by side — the first
  * *first_rows elements in the shape (*first_lpl, *first_wpg), the rest in (*rest_lpl, *rest_wpg) on another stream at the
  * same time (each with its own workspace; mx_powmod_nsquare_run with explicit shapes).  *first_rows = 0: no split.
- * Reported above the capacity of the wide two-wavefront shape (one workgroup per CU: 8192 ciphertexts at key_length
- * 2048) where no single launch is as fast: 10 752 .. 12 288 ciphertexts (48.5 instead of 51-56 ms; below that the
- * time-sliced single launch is at least as good).  The library itself never uses a stream the
- * caller did not pass; protocols/distributed_keygen_amd/engine.py follows this hint for lone launches. */
+ * Since ABI 4.1 the library reports a split only when MX_KNOB_N2_SPLIT = 2 asks for it (then for every batch between
+ * one and two capacities of the wide two-wavefront shape — 8192 ciphertexts at key_length 2048): the time-sliced wide
+ * launch covers 8192 .. 12 288 ciphertexts in 36-48 ms, as fast as or faster than the split (48.5).  The library itself
+ * never uses a stream the caller did not pass; protocols/distributed_keygen_amd/engine.py follows this hint. */
 int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first_rows, int* first_lpl, int* first_wpg,
                             int* rest_lpl, int* rest_wpg);
 /* Launch form of a generic-modulus modexp (mx_powmod_shared_lpl / mx_powmod_multi_dev) for this limbs_per_lane (0 = the

@@ -51,9 +51,12 @@ NOP_COST = 4.0    # an inserted s_nop is taken when it aligns more than this man
 # Left alone: the instances with 3 limbs per lane (template arguments <K, 3, 29, ...>).  Their blocks are a few dozen
 # instructions on ONE dependent chain (the latency geometry); measured, s_nop insertion cost them 3-6 % (14.8 -> 15.3 ms
 # and 55.9 -> 59.5 ms per decrypt) and re-encoding alone changed nothing (14.87 -> 14.99, 55.9 -> 55.4).
-# ... and the time-sliced instances of the two-wavefront kernel (template argument PERSISTENT = true), which measured the
-# same with and without the pass (profiles/r03_asm_alignment_ab.txt).
-SKIP = re.compile(r"ELi3ELi29E|powmod_n2_split_kernelILi\d+ELi\d+ELi29ELb1E")
+# ... and the time-sliced instances of the two-wavefront kernel at 9 limbs per lane (template argument PERSISTENT = true):
+# they run two and three workgroups per CU, where an inserted s_nop costs an issue slot that a neighbour would have used
+# (10 000 ciphertexts, two per CU: 43.8 ms as compiled, 48.6 aligned; one per CU they gain, 46.5 -> 43.7, but that form
+# is not chosen anywhere).  The 18-limb time-sliced instances run one workgroup per CU — a wavefront alone on its SIMD —
+# and take the pass: 33.5 -> 32.4 ms for 8192 ciphertexts, 42.5 -> 41.1 for 10 000 (profiles/r05_ts_probe_2048*.txt).
+SKIP = re.compile(r"ELi3ELi29E|powmod_n2_split_kernelILi\d+ELi9ELi29ELb1E")
 # The pass only touches the kernels it was MEASURED to help: the two forms of the N^2 pair kernel at 9 and 18 limbs per
 # lane (lone launches -3 ... -14 %) and the generic modexp at 9 and 18 (lone launches -7 ... -9 %: 2.57 -> 2.38 ms for 256
 # candidates at key_length 1024, 13.9 -> 12.7 ms for one wide launch at 2048, profiles/r04_sweep_generic*.txt; +0.2 % at

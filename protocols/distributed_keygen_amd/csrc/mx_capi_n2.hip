@@ -31,7 +31,7 @@ inline int max_lanes(int lpl, int wpg) {
   return wpg == 2 ? 64 : 0;                 // L = 3 exists as a split kernel only
 }
 
-constexpr int N2_TIMESLICE_MAX_SEGMENTS = 16;      // units per group of a time-sliced launch, at most
+constexpr int N2_TIMESLICE_MAX_SEGMENTS = mx::N2_TS_LEVELS;      // units per group of a time-sliced launch, at most
 
 bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg, N2Shape& p) {
   if (geo_index(limbs_per_lane) < 0 || (wpg != 1 && wpg != 2)) return false;
@@ -43,7 +43,10 @@ bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg
   p.nslots = mx::N2_SLOT_TABLE + (1 << (window - 1));
   p.table_bytes = align256((int64_t)p.nslots * 2 * p.geo.L * p.nlanes * 4);
   p.groups = (batch + 64 / p.geo.K - 1) / (64 / p.geo.K);
-  p.sched_bytes = wpg == 2 ? align256((2 + p.groups * (N2_TIMESLICE_MAX_SEGMENTS - 1)) * 4) : 0;
+  p.sched_bytes = wpg == 2 ? align256((mx::N2_TS_HEADER + p.groups * (N2_TIMESLICE_MAX_SEGMENTS - 1)) * 4) : 0;
+#ifdef MX_TS_TRACE          // four words per unit behind the queues (mx_powmod_n2_split.hpp)
+  if (wpg == 2) p.sched_bytes += align256(p.groups * N2_TIMESLICE_MAX_SEGMENTS * 16);
+#endif
   return true;
 }
 
@@ -113,12 +116,11 @@ inline bool n2_friendly_instance(const Geometry& g, int wpg, int n_bits) {
 // fills the machine on its own (from ~24 000).  Callers that keep several launches in flight fill the machine
 // between them and should say so by passing limbs_per_lane = 18, wavefronts_per_group = 1 (bench.py's
 // steady-state leg does).
-// units per group of a time-sliced launch of r workgroups per CU unless the caller says
-inline int n2_timeslice_segments(int resident) { return resident == 1 ? 8 : 2; }
-struct N2Choice { int lpl, wpg, resident; };      // resident: workgroups per CU of the time-sliced form, 0 = plain launch
+struct N2Choice { int lpl, wpg, resident, units; };      // resident: workgroups per CU of the time-sliced form (0 = plain launch), units per group unless the caller says
 inline int device_cus() { return mx_device_cus(); }      // of the CURRENT device (mx_upload.hpp)
-double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = nullptr) {
+double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = nullptr, int* units = nullptr) {
   if (resident) *resident = 0;
+  if (units) *units = 0;
   N2Shape p;
   if (!shape_n2(n_bits, 1, batch, lpl, wpg, p)) return -1.0;
   const double L = p.geo.L, steps = (double)p.geo.nblk * p.geo.L;
@@ -126,8 +128,12 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   // the SIMD costs them 1.22x what the issue costs alone would say — 13.0 / 19.9 / 27.4 / 35.3 ms for 1 .. 4 per SIMD)
   const bool lat = lpl == LIMBS_PER_LANE_LAT;
   const double m = wpg == 2 ? 2 * L : (p.geo.L / 2 + 1) + 3 * L, o = lat ? 8.0 : wpg == 2 ? 11.0 : 20.0;
-  const double alone = steps * (5.3 * (m + o) + 80.0 / L);
-  const double shared = steps * (4.2 * m + 2.3 * o) * (lat ? 1.22 : wpg == 2 ? 1.0 : 1.17);     // one wavefront doing both passes overlaps less
+  // (round 5 refit, after the build's alignment pass: a lone 18-limb wavefront runs 3 % / 8 % faster than these counts
+  // say — 32.1 ms for 8192 ciphertexts on two wavefronts, 54.4 for 16 384 on one — and a second 9-limb pair on a SIMD
+  // costs 8 % more: 35.6 ms for 8192; profiles/r05_ts_probe_2048.txt)
+  const bool wide_geo = lpl == LIMBS_PER_LANE_WIDE;
+  const double alone = steps * (5.3 * (m + o) + 80.0 / L) * (wide_geo ? (wpg == 2 ? 0.967 : 0.924) : 1.0);
+  const double shared = steps * (4.2 * m + 2.3 * o) * (lat ? 1.22 : wpg == 2 ? (wide_geo ? 1.0 : 1.08) : 1.17);     // one wavefront doing both passes overlaps less
   const int cus = device_cus();
   const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
   const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;
@@ -155,10 +161,31 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   //     9 200..10 500 ciphertexts at key_length 2048;
   //   r = 1 with 8 segments, for launches just above one workgroup per CU (up to 1.25x): the fine grain costs ~13 %
   //     per operation (hand-overs on a SIMD that has nothing else to issue), still 12-23 % below the plain launch.
-  const bool sliceable = wpg == 2 && lpl == LIMBS_PER_LANE && p.geo.K <= 16;
+  const bool wide = lpl == LIMBS_PER_LANE_WIDE;
+  const bool sliceable = wpg == 2 && ((lpl == LIMBS_PER_LANE && p.geo.K <= 16) || (wide && (p.geo.K == 4 || p.geo.K == 8)));
   if (!sliceable || !resident || g_knob_n2_timeslice == 1) return plain;
   const bool forced = g_knob_n2_timeslice >= 2;
   double best = forced ? -1.0 : plain * 0.97;          // a time-sliced launch has to win by 3 %
+  int best_units = 0;
+  if (wide) {
+    // 18 limbs per lane (round 5): ONE workgroup per CU — a second one doubles what every SIMD carries — and the groups'
+    // units handed out most-work-left-first (mx_powmod_n2_split.hpp): the launch takes ceil(groups x units / pairs)
+    // rounds of 1 / units of a full launch, plus 0.4 % per unit for the hand-overs (key_length 2048: 8704 ciphertexts
+    // in 12 units 36.1 ms, 10 000 in 8 units 40.8, 11 264 in 8 units 45.2, 12 288 in 2 units 47.9 where the plain
+    // launches take 51-60; key_length 4096: 4352 in 12 units 141 ms, 5000 in 8 units 151, 5632 in 8 units 166 where they
+    // take 182; profiles/r05_ts_probe_*.txt).  Four units are not offered: 10 000 ciphertexts are 4.88 rounds of them, and
+    // whether the launch then takes five or six (42 or 49 ms) changed from build to build.
+    const int64_t pairs = (int64_t)cus * mx::N2_SPLIT_PAIRS;
+    if (p.groups > pairs || forced) {
+      for (int u : {2, 8, 12}) {
+        const int64_t rounds = (p.groups * u + pairs - 1) / pairs;
+        const double t = round(1) * (double)rounds / (double)u * (1.0 + 0.004 * u);
+        if (best < 0 || t < best) { best = t; best_units = u; *resident = 1; }
+      }
+    }
+    if (units) *units = best_units;
+    return *resident ? best : plain;
+  }
   for (int64_t r = 1; r <= 2; ++r) {
     int64_t rr = r;
     if (g_knob_n2_timeslice > 16) {               // developer: this many per CU
@@ -172,24 +199,26 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
     // the time-sliced instances run 5 % (shared SIMDs) to 11 % (alone) slower per operation than the plain ones since
     // the build aligns 64-bit instructions (asm_align.py: the plain instances gained, these did not), and one
     // workgroup per CU pays ~13 % for its hand-overs
-    const double t = load * round(rr) * (rr == 1 ? 1.28 : 1.05);
-    if (best < 0 || t < best) { best = t; *resident = (int)rr; }
+    // (two per CU, two units: 1.19-1.26 x a full launch for loads of 1.03-1.25 — 42-45 ms for 8448 .. 10 240 ciphertexts)
+    const double t = (rr == 2 ? std::max(load, 1.17) : load) * round(rr) * (rr == 1 ? 1.28 : 1.05);
+    if (best < 0 || t < best) { best = t; *resident = (int)rr; best_units = rr == 1 ? 8 : 2; }
   }
+  if (units) *units = best_units;
   return *resident ? best : plain;
 }
 N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
-  N2Choice best{LIMBS_PER_LANE, 1, 0};
+  N2Choice best{LIMBS_PER_LANE, 1, 0, 0};
   double best_t = -1.0;
   for (int l : N2_LPLS) {
     if (limbs_per_lane && l != limbs_per_lane) continue;
     for (int w : {1, 2}) {
       if (wpg && w != wpg) continue;
-      int resident = 0;
-      const double t = n2_estimate(n_bits, batch, l, w, &resident);
-      if (t > 0 && (best_t < 0 || t < best_t)) { best_t = t; best = N2Choice{l, w, resident}; }
+      int resident = 0, units = 0;
+      const double t = n2_estimate(n_bits, batch, l, w, &resident, &units);
+      if (t > 0 && (best_t < 0 || t < best_t)) { best_t = t; best = N2Choice{l, w, resident, units}; }
     }
   }
-  if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1, 0};   // reported as MX_ERR_SIZE by the caller
+  if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1, 0, 0};   // reported as MX_ERR_SIZE by the caller
   return best;
 }
 
@@ -279,7 +308,7 @@ extern "C" int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs
   N2Shape p;
   if (!shape_n2(n_bits, 1, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
   *resident_per_cu = ch.resident;
-  *units_per_group = ch.resident ? n2_timeslice_segments(ch.resident) : 0;
+  *units_per_group = ch.resident ? ch.units : 0;
   return MX_OK;
 }
 
@@ -304,10 +333,10 @@ extern "C" int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_p
 // one (256) on a CU but not beside another 9-limb one, so the dispatcher spreads the remainder one workgroup per CU.
 // Measured (tools/sweep_split.py, profiles/r04_split_launch.txt): a CU that hosts both takes 48-49 ms whatever the
 // share of such CUs — the two wavefronts of a SIMD add up almost fully (a lone wavefront already issues 83 % of what
-// its SIMD can) — so the split only beats the single launches where those take longer: above the range the time-sliced
-// form covers (44-48 ms up to 10 500), i.e. when the remainder needs more than MX_SPLIT_MIN_SHARE of the CUs: 10 752 ..
-// 12 288 ciphertexts at key_length 2048 (48.5 instead of 51-56 ms), 5376 .. 6144 at 4096 (182 instead of 191-196).
-constexpr double MX_SPLIT_MIN_SHARE = 0.62;
+// its SIMD can).  Rounds 3-4 took the split where the single launches were slower still (10 752 .. 12 288 ciphertexts at
+// key_length 2048: 48.5 instead of 51-56 ms).  Since round 5 the time-sliced 18-limb launch covers that range in 44-48 ms
+// (n2_estimate above): the library no longer proposes a split by itself; the developer knob still forces one (tests,
+// tools/sweep_split.py).
 extern "C" int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first_rows, int* first_lpl, int* first_wpg,
                                        int* rest_lpl, int* rest_wpg) {
   if (!first_rows || !first_lpl || !first_wpg || !rest_lpl || !rest_wpg || batch <= 0) return MX_ERR_ARG;
@@ -321,7 +350,7 @@ extern "C" int mx_nsquare_launch_split(int n_bits, int64_t batch, int64_t* first
   if (batch <= cap || batch >= 2 * cap) return MX_OK;
   const int64_t rest = batch - cap;
   const int64_t rest_wgs = (rest + per_wg_narrow - 1) / per_wg_narrow;
-  if ((double)rest_wgs <= MX_SPLIT_MIN_SHARE * cus && g_knob_n2_split != 2) return MX_OK;
+  if (g_knob_n2_split != 2) return MX_OK;
   if (rest_wgs > cus) return MX_OK;
   *first_rows = cap; *first_lpl = LIMBS_PER_LANE_WIDE; *first_wpg = 2; *rest_lpl = LIMBS_PER_LANE; *rest_wpg = 2;
   return MX_OK;
@@ -516,14 +545,14 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   MxKernelTimer timer(s);                        // one timed interval per exponentiation (all its segments)
   if (ch.resident > 0) {
     // time-sliced: one launch of resident workgroups, the segments are units of its own scheduler
-    nseg = segments > 0 ? segments : n2_timeslice_segments(ch.resident);
+    nseg = segments > 0 ? segments : ch.units;
     if (nseg > N2_TIMESLICE_MAX_SEGMENTS) nseg = N2_TIMESLICE_MAX_SEGMENTS;
     if (nseg > plan->n_sqr / 16) nseg = plan->n_sqr / 16;
     if (nseg < 1) nseg = 1;
     a.sched = (u32*)((char*)d_ws + p.table_bytes);
     a.sched_groups = (int)p.groups; a.sched_segments = nseg; a.sched_n_sqr = plan->n_sqr;
     a.first = a.last = 1; a.pos_begin = 0; a.pos_end = 0x7FFFFFFF;
-    MX_HIP(hipMemsetAsync(a.sched, 0, (size_t)(2 + p.groups * (nseg - 1)) * 4, s));
+    MX_HIP(hipMemsetAsync(a.sched, 0, (size_t)(mx::N2_TS_HEADER + p.groups * (nseg - 1)) * 4, s));
     // no more workgroups than there are groups for their pairs
     int64_t wgs = (int64_t)ch.resident * device_cus();
     if (wgs > p.nblocks) wgs = p.nblocks;

@@ -16,14 +16,17 @@ static int launch_form(const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s
   return MX_OK;
 }
 
-// no time-sliced instances at 18 limbs per lane.  Round 3: the unit loop pushed them over 256 registers (10-20 % more
-// per operation).  Round 4, with the opaque lane position per unit (239 registers, no scratch), one resident workgroup
-// per CU: 3.5 % (2 units per group) to 8 % (8 units) above the plain launch where that fits, 45.0-47.6 ms for 10 000
-// ciphertexts against 42.9 for the 9-limb form at two resident workgroups per CU, never ahead anywhere between 4608
-// and 24 576 (tools/ts_probe.py, profiles/r04_ts_probe_2048.txt): not built.
+// Time-sliced instances at 18 limbs per lane: groups of 4 and 8 lanes (key_length 2048 and 4096), one resident
+// workgroup per CU.  (Rounds 3 and 4 did not build them: first the unit loop pushed them over 256 registers, then — at
+// 239 registers, no scratch — they lost to the 9-limb form, 45.0-47.6 against 42.9 ms for 10 000 ciphertexts.  That was
+// the FIFO unit queue, not the instances: mx_powmod_n2_split.hpp, tools/ts_schedule_model.py.)
 template <int K>
 static int launch(bool ts, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s) {
-  if (ts) return MX_ERR_SIZE;
+  if constexpr (K == 4 || K == 8) {
+    if (ts) return launch_form<K, true>(a, nblocks, s);
+  } else {
+    if (ts) return MX_ERR_SIZE;
+  }
   return launch_form<K, false>(a, nblocks, s);
 }
 

@@ -59,14 +59,31 @@ constexpr size_t powmod_n2_split_lds_bytes(bool friendly = L == 3) {
   return ((size_t)N2_SPLIT_PAIRS * ((size_t)2 * (64 / K) * (2 * K * L + 8) + (size_t)2 * 2 * L * 64 + 4) + (size_t)(friendly ? 2 : 1) * K * L) * 4;
 }
 
-// Scheduling state of a time-sliced launch in device memory (zeroed by the host before the launch): the work queue
-// described at the unit loop below, 2 + groups x (segments - 1) words.
+// Scheduling state of a time-sliced launch in device memory (zeroed by the host before the launch): the work queues
+// described at the unit loop below, N2_TS_HEADER + groups x (segments - 1) words.
+constexpr int N2_TS_LEVELS = 16;       // units per group of a time-sliced launch, at most
+constexpr int N2_TS_HEADER = 2 * N2_TS_LEVELS;
 // Register budget: three workgroups per CU (168 registers) for the 9- and 3-limb instances, plain and time-sliced, two
 // (256) for the 18-limb ones.  No instance has a private segment (tools/scratch_report.py, tests/test_instances.py).
 // The time-sliced instances must NOT be given the whole register file: with 256 registers a launch of 2 x CUs resident
 // workgroups leaves no slot for anybody else, and four such launches started a few milliseconds apart took 4-38 SECONDS
 // for their first round (three of the four stalled until the scheduler's time slice came round; measured in round 4,
 // profiles/r04_timesliced_first_round.txt) — and were no faster than the plain launch (53 vs 47 ms for 10 000).
+// Agent-scope release / acquire of a wavefront's global stores for the hand-over of a group between pairs that may sit
+// on different XCDs (each XCD has its own L2): spelled out, not left to the atomics' memory orders.  The compiler's
+// sequence for `__hip_atomic_store(..., __ATOMIC_RELEASE, agent)` behind an atomic whose result had just been waited for
+// was  buffer_wbl2 sc1 ; s_waitcnt lgkmcnt(0) ; global_store sc1  — no wait for the WRITE-BACK before the flag (its
+// waitcnt pass does not count buffer_wbl2 as outstanding), and a pair that took the group the moment the flag appeared
+// read the previous segment's accumulator half-written: 1 group in ~1000 hand-overs wrong when takers were idle and
+// waiting (round 5, found when the scheduler below began to hand groups over hot; the FIFO of rounds 3-4 mostly
+// handed a group back to the pair that had pushed it).
+__device__ __forceinline__ void ts_release_agent() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_wbl2 sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+}
+__device__ __forceinline__ void ts_acquire_agent() {
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
+}
+
 #ifndef MX_TS_MIN_WAVES          // developer builds: tools/build_variant.py <name> -DMX_TS_MIN_WAVES=2 / -DMX_TS_NO_A_FENCE
 #define MX_TS_MIN_WAVES 3
 #endif
@@ -159,16 +176,19 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
   };
 
   // ---- the units of this pair: one (the launch's segment of its own group) in the plain form.  Time-sliced form:
-  // a work queue in device memory.  Unit = (segment, group), numbered segment-major; the first `groups` entries of
-  // the queue are the first segments of all groups (implicit), every further entry is written by the pair that
-  // finished the previous segment of that group.  A pair pops by taking the next index of `head` and waiting for
-  // that entry: it waits for the next COMPLETION on the device, whichever group it is, so the resident pairs stay
-  // busy as long as there are at least as many groups as pairs.  Every popped index below groups x segments does get
-  // written: its writer holds a lower index, i.e. is already running.
+  // work queues in device memory.  Unit = (segment, group), numbered segment-major.  There is one queue per LEVEL —
+  // level k holds the groups whose first k segments are done — and a free pair takes from the LOWEST level that has an
+  // entry: the group with the most work left goes first.  (Round 5.  The first form of this scheduler was one FIFO
+  // over all units: every group then advances at the same pace, the groups that start a round late — 113 of 625 at
+  // key_length 2048 on 512 resident pairs — also end a round late, and the launch ends with a few chains of several
+  // segments each and most pairs idle: 51 ms for 10 000 ciphertexts in 4 units per group where 625 x 4 / 512 units take
+  // 41.  A discrete-event model of both disciplines is tools/ts_schedule_model.py.)  Level 0 is implicit (every group,
+  // in order); an entry of level k >= 1 is written by the pair that finished segment k - 1 of that group.  A pair that
+  // finds every level empty sleeps and looks again until all groups x segments units have been claimed.
   const u32 groups = (u32)A.sched_groups, nseg = (u32)A.sched_segments;
-  u32* const q_head = A.sched;           // indices popped so far
-  u32* const q_tail = A.sched + 1;       // entries pushed so far (beyond the implicit ones)
-  u32* const q_ring = A.sched + 2;       // entry i - groups for index i >= groups: unit + 1, 0 = not yet pushed
+  u32* const q_head = A.sched;                               // [N2_TS_LEVELS] entries granted per level
+  u32* const q_tail = A.sched + N2_TS_LEVELS;                // [N2_TS_LEVELS] entries reserved by their writers per level (level 0 unused)
+  u32* const q_ring = A.sched + N2_TS_HEADER;                // level k >= 1, entry i at [(k - 1) * groups + i]: group + 1, 0 = not yet written
   for (;;) {
     // Time-sliced form: everything the prologue and the epilogue of a unit derive from the lane position (bit offsets,
     // masks and LDS addresses of the limb conversions: some fifty values) is invariant across units, and the compiler
@@ -180,6 +200,9 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
     i64 slot, nlanes;
     int first, last, pos_begin, pos_end;
     u32 g = 0, sg = 0;
+#ifdef MX_TS_TRACE
+    u64 trace_t0 = 0;
+#endif
     if constexpr (!PERSISTENT) {
       slot = (i64)blockIdx.x * N2_SPLIT_PAIRS + pair;
       nlanes = (i64)gridDim.x * N2_SPLIT_PAIRS * 64;
@@ -189,15 +212,45 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
       if (half == 0) {
         // B has taken everything of the previous unit (its last entry is the end token): the pair is free
         while (__hip_atomic_load(consumed, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) < seq) __builtin_amdgcn_s_sleep(2);
-        u32 idx = 0;
-        if (lane == 0) idx = __hip_atomic_fetch_add(q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        idx = (u32)__builtin_amdgcn_readfirstlane((int)idx);
-        u = idx;
-        if (idx >= groups && idx < groups * nseg) {
-          u32 v;
-          while ((v = __hip_atomic_load(q_ring + (idx - groups), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(16);
-          u = (u32)__builtin_amdgcn_readfirstlane((int)v) - 1u;
+        u = groups * nseg;                                   // "no unit left"
+        if (lane == 0) {
+          // Level 0 is taken with a fetch-and-add (1024 pairs start at once: with a compare-and-swap there the launch
+          // began with 12 ms of retries; the head may overshoot, an index beyond the groups is no claim).  The other
+          // levels need the EXACT test "granted < written" — a pair must not pass over a level that has an entry — and
+          // take with a compare-and-swap: pairs finish their units microseconds apart, a handful contend at a time.
+          // (Counting semaphores per level — decrement, give back on failure — are cheaper and not exact: while one
+          // pair's failed decrement is outstanding the level looks empty to the others, a few groups were passed over
+          // for a whole round and the launch ended with two chains running alone: 50 instead of 42 ms, traced with
+          // tools/ts_trace.py.)
+          for (;;) {
+            u32 claimed = groups;
+            bool got = false;
+            {
+              u32 h = __hip_atomic_load(q_head, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (h < groups) h = __hip_atomic_fetch_add(q_head, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (h < groups) { u = h; got = true; }           // the groups in order
+            }
+            for (u32 k = 1; k < nseg && !got; ++k) {
+              u32 h = __hip_atomic_load(q_head + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              const u32 t = __hip_atomic_load(q_tail + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              while (h < t && !got)
+                got = __hip_atomic_compare_exchange_strong(q_head + k, &h, h + 1u, __ATOMIC_RELAXED, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              if (got) {
+                // the writer reserved the entry before it wrote it: a moment at most
+                const u32* e = q_ring + (size_t)(k - 1u) * groups + h;
+                u32 g1;
+                while ((g1 = __hip_atomic_load(e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) == 0u) __builtin_amdgcn_s_sleep(4);
+                u = k * groups + (g1 - 1u);
+                break;
+              }
+              claimed += h;
+            }
+            if (got || claimed >= groups * nseg) break;       // (the heads only grow: their sum reaches the total once)
+            __builtin_amdgcn_s_sleep(127);                     // ~4 us: idle pairs must not crowd the queue words
+            __builtin_amdgcn_s_sleep(127);
+          }
         }
+        u = (u32)__builtin_amdgcn_readfirstlane((int)u);
         if (lane == 0) *unit_word = u;
         send_token();
       } else {
@@ -206,8 +259,11 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
       }
       if (u >= groups * nseg) break;
       g = u % groups; sg = u / groups;
+#ifdef MX_TS_TRACE          // developer builds (tools/ts_trace.py): when and where every unit ran, behind the queues
+      trace_t0 = __builtin_amdgcn_s_memrealtime();
+#endif
       // what the pair that pushed this unit stored (slots, accumulator) before its release of the entry
-      if (sg > 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      if (sg > 0) ts_acquire_agent();
       slot = (i64)g;
       nlanes = (i64)groups * 64;
       first = sg == 0;
@@ -412,16 +468,33 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
       // them back from this XCD's L2 — so A releases them at agent scope itself, before the token that lets B push.
       if (half == 0) {
 #ifndef MX_TS_NO_A_FENCE
-        if (!last) __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        if (!last) ts_release_agent();
 #endif
         send_token();
       } else {
         receive_token();
+#ifdef MX_TS_TRACE
+        if (lane == 0) {
+          u32* tr = q_ring + (size_t)groups * (N2_TS_LEVELS - 1) + ((size_t)sg * groups + g) * 4;
+          const u64 t1 = __builtin_amdgcn_s_memrealtime();
+          u32 hw;
+          asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(hw));
+          tr[0] = (u32)trace_t0; tr[1] = (u32)t1; tr[2] = (u32)(blockIdx.x * N2_SPLIT_PAIRS + pair); tr[3] = hw;
+        }
+#endif
         if (!last) {
-          u32 t = 0;
-          if (lane == 0) t = __hip_atomic_fetch_add(q_tail, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          t = (u32)__builtin_amdgcn_readfirstlane((int)t);
-          __hip_atomic_store(q_ring + t, (sg + 1) * groups + g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+          // (sg + 1 <= nseg - 1 < N2_TS_LEVELS)
+#ifndef MX_TS_COMPILER_RELEASE          // developer builds (tools/ts_handover_check.py): the sequence that lost groups
+          ts_release_agent();                                  // B's own stores; A released its own before the token
+#endif
+          if (lane == 0) {
+            const u32 t = __hip_atomic_fetch_add(q_tail + (sg + 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifndef MX_TS_COMPILER_RELEASE
+            __hip_atomic_store(q_ring + (size_t)sg * groups + t, g + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
+            __hip_atomic_store(q_ring + (size_t)sg * groups + t, g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+#endif
+          }
         }
       }
     }

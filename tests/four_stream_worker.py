@@ -63,8 +63,8 @@ def main() -> None:
         want = pool.starmap(pow, [(c, exp, n2) for c in cts], chunksize=8)
         limbs2 = L.limbs_for(n2)
         c_t, want_t = eng.to_device(L.pack(cts, limbs2)), eng.to_device(L.pack(want, limbs2))
-        shapes = (((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (3, 2, 0)) if what == "nsquare" else
-                  ((18, 1, 0), (9, 2, 0), (9, 2, 2), (18, 2, 0)))
+        shapes = (((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (18, 2, 2), (3, 2, 0)) if what == "nsquare" else
+                  ((18, 1, 0), (9, 2, 0), (9, 2, 2), (18, 2, 0), (18, 2, 2)))
         for lpl, wpg, sliced in shapes:
             eng.set_limbs_per_lane(lpl)
             eng.set_wavefronts_per_group(wpg)

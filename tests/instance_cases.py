@@ -46,6 +46,9 @@ N2_CASES = [
     # time-sliced instances of the two-wavefront kernel (L = 9, K = 1 .. 16; friendly and plain for K = 8 and 16)
     ("n2", 200, 9, 300, 130, 2, 2), ("n2", 400, 9, 67, 130, 2, 2), ("n2", 900, 9, 70, 130, 2, 2),
     ("n2", 2051, 9, 35, 200, 2, 2), ("n2", 2075, 9, 35, 200, 2, 2), ("n2", 4099, 9, 19, 96, 2, 2), ("n2", 4160, 9, 19, 96, 2, 2),
+    # ... and at L = 18, K = 4 and 8 (round 5: what a lone launch just above one workgroup per CU runs, e.g. 10 000 ciphertexts
+    # at key_length 2048); batches that leave the last group ragged, more groups than one workgroup's two pairs
+    ("n2", 2051, 18, 70, 200, 2, 2), ("n2", 2075, 18, 37, 200, 2, 2), ("n2", 4099, 18, 35, 96, 2, 2),
     # the library's choice: a handful of elements -> the latency geometry on two wavefronts
     ("n2", 2051, 0, 7, 64, 0),
 ]

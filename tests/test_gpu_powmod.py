@@ -309,8 +309,8 @@ def test_exponent_with_a_very_long_run_of_zero_bits(eng):
 
 def test_powmod_nsquare_split_launch_is_bit_identical(eng):
     """One batch above the capacity of the wide two-wavefront shape runs as two launches side by side on the engine's
-    companion stream (mx_nsquare_launch_split): same rows as the single launch and as pow(), for the automatic range and
-    with the split forced on a ragged remainder; explicit shapes never split."""
+    companion stream (mx_nsquare_launch_split; since round 5 only when the developer knob asks — the time-sliced wide
+    launch is as fast): same rows as the single launch and as pow(), also on a ragged remainder; explicit shapes never split."""
     import torch
 
     from protocols.distributed_keygen_amd import limbs as L, synthetic
@@ -322,8 +322,10 @@ def test_powmod_nsquare_split_launch_is_bit_identical(eng):
     eng.set_wavefronts_per_group(0)
     try:
         assert eng.nsquare_launch_split(n.bit_length(), 8192) is None and eng.nsquare_launch_split(n.bit_length(), 10000) is None
+        assert eng.nsquare_launch_split(n.bit_length(), 11264) is None and eng.nsquare_launch_split(n.bit_length(), 12288) is None
+        eng.debug_knob("n2_split", 2)
         assert eng.nsquare_launch_split(n.bit_length(), 11264) == (8192, (18, 2), (9, 2))
-        for batch, knob in ((11264, 0), (8192 + 333, 2)):
+        for batch, knob in ((11264, 2), (8192 + 333, 2)):
             cts = synthetic.random_ciphertexts(key, batch, seed=batch)
             rows = eng.to_device(L.pack(cts, L.limbs_for(n2)))
             eng.debug_knob("n2_split", knob)

@@ -36,7 +36,8 @@ def test_every_reachable_instance_has_a_parity_case():
     # the friendly-modulus and the time-sliced instances are instances of their own (VERDICT r03 "weak" 1b)
     assert {(k, l, w) for _, k, l, w, fr, ts in n2 if fr and l != 3} == {(8, 9, 2), (16, 9, 2), (4, 18, 1), (8, 18, 1)}
     assert {(k, l, w, fr) for _, k, l, w, fr, ts in n2 if ts} >= {(8, 9, 2, 1), (8, 9, 2, 0), (16, 9, 2, 1)}
-    assert all(l == 9 and w == 2 and k <= 16 for _, k, l, w, fr, ts in n2 if ts)
+    assert all(w == 2 and ((l == 9 and k <= 16) or (l == 18 and k in (4, 8))) for _, k, l, w, fr, ts in n2 if ts)
+    assert {(k, l) for _, k, l, w, fr, ts in n2 if ts and l == 18} == {(4, 18), (8, 18)}          # round 5
     assert all(fr for _, k, l, w, fr, ts in n2 if l == 3)
     for kind in ("generic-sliding", "generic-fixed"):
         assert {k for kd, k, l, *w in reachable if kd == kind and l == 9} == {1, 2, 4, 8, 16, 32, 64}
@@ -46,17 +47,17 @@ def test_every_reachable_instance_has_a_parity_case():
 
 
 def test_auto_launch_shapes_match_the_measured_crossovers():
-    """The library's choice for ONE launch on an idle GPU follows the crossovers tools/sweep_shapes.py measured
-    (profiles/r03_sweep_shapes.txt): latency geometry on two wavefronts for a handful of ciphertexts, then 9 and 18
-    limbs per lane still on two wavefronts while that buys occupancy, the one-wavefront wide kernel once a launch
-    fills the machine on its own."""
+    """The library's choice for ONE launch on an idle GPU follows the crossovers tools/sweep_shapes.py and tools/ts_probe.py
+    measured (profiles/r03_sweep_shapes.txt, r05_ts_probe_*.txt): latency geometry on two wavefronts for a handful of
+    ciphertexts, then 9 and 18 limbs per lane still on two wavefronts while that buys occupancy — time-sliced just above
+    one workgroup per CU —, the one-wavefront wide kernel once a launch fills the machine on its own."""
     from protocols.distributed_keygen_amd import _lib
 
     lib = _lib.lib()
     shape = lambda bits, batch: ic.case_instance(lib, ("n2", bits, 0, batch, 0, 0))[:4]
     for batch, want in ((1, (32, 3, 2)), (64, (32, 3, 2)), (1000, (32, 3, 2)), (2000, (32, 3, 2)), (3000, (8, 9, 2)), (4096, (8, 9, 2)),
-                        (6144, (4, 18, 2)), (8192, (4, 18, 2)), (10000, (8, 9, 2)), (12288, (8, 9, 2)), (16384, (4, 18, 2)),
-                        (20000, (8, 9, 2)), (24576, (4, 18, 2)), (30000, (4, 18, 1))):
+                        (6144, (4, 18, 2)), (8192, (4, 18, 2)), (10000, (4, 18, 2)), (12288, (4, 18, 2)), (16384, (4, 18, 1)),
+                        (20000, (4, 18, 2)), (24576, (4, 18, 2)), (30000, (4, 18, 1))):
         assert shape(2051, batch) == ("n2",) + want, batch
     for batch, want in ((1, (64, 3, 2)), (512, (64, 3, 2)), (1024, (64, 3, 2)), (2048, (16, 9, 2)), (4096, (8, 18, 2)), (16000, (8, 18, 1))):
         assert shape(4099, batch) == ("n2",) + want, batch
@@ -66,14 +67,16 @@ def test_auto_launch_shapes_match_the_measured_crossovers():
     assert ic.case_instance(lib, ("n2", 2051, 0, 10, 0, 1)) == ("n2", 8, 9, 1, 0, 0)
     assert ic.case_instance(lib, ("n2", 2051, 18, 40000, 0, 1)) == ("n2", 4, 18, 1, 1, 0)        # friendly one-wavefront instance
     assert ic.case_instance(lib, ("n2", 2075, 18, 40000, 0, 1)) == ("n2", 4, 18, 1, 0, 0)        # no room: the plain one
-    assert ic.case_instance(lib, ("n2", 2051, 0, 10000, 0, 0)) == ("n2", 8, 9, 2, 1, 1)          # time-sliced, friendly
+    assert ic.case_instance(lib, ("n2", 2051, 0, 10000, 0, 0)) == ("n2", 4, 18, 2, 0, 1)         # time-sliced, wide (round 5)
+    assert ic.case_instance(lib, ("n2", 2051, 9, 10000, 0, 0)) == ("n2", 8, 9, 2, 1, 1)          # time-sliced, friendly
     assert ic.case_instance(lib, ("n2", 2051, 3, 10, 0, 1)) is None          # the latency geometry has no one-wavefront form
 
 
 def test_time_sliced_launches_where_they_were_measured_to_pay():
     """The time-sliced form of the two-wavefront kernel (resident workgroups taking segment units from a queue) is
     chosen just above a capacity step of a lone launch and nowhere else (tools/ts_probe.py,
-    profiles/r03_ts_probe_2048.txt, _4096.txt); an explicit one-wavefront or wide shape never is."""
+    profiles/r05_ts_probe_2048.txt, _4096.txt): at 18 limbs per lane, one workgroup per CU, in 8 or 12 units per group
+    (2 where three half-launches are the best there is); an explicit one-wavefront shape never is."""
     import ctypes
 
     from protocols.distributed_keygen_amd import _lib
@@ -85,13 +88,14 @@ def test_time_sliced_launches_where_they_were_measured_to_pay():
         assert lib.mx_nsquare_launch_timesliced(bits, batch, lpl, wpg, r, u) == 0
         return r.value, u.value
 
-    for batch in (1, 1000, 4096, 8192, 12288, 16384, 20000, 40000):
+    for batch in (1, 1000, 4096, 8192, 13312, 16384, 20000, 40000):
         assert sliced(2051, batch) == (0, 0), batch
-    for batch in (9216, 10000, 10240):
-        assert sliced(2051, batch) == (2, 2), batch
+    for batch in (9216, 10000, 10240, 11264):
+        assert sliced(2051, batch) == (1, 8), batch
+    assert sliced(2051, 8704) == (1, 12) and sliced(2051, 12288) == (1, 2)
     assert sliced(2051, 4608) == (1, 8)
-    assert sliced(4099, 5120) == (2, 2) and sliced(4099, 2304) == (1, 8) and sliced(4099, 2048) == (0, 0)
-    assert sliced(2051, 10000, 18, 0) == (0, 0) and sliced(2051, 10000, 0, 1) == (0, 0) and sliced(2051, 10000, 9, 2) == (2, 2)
+    assert sliced(4099, 5120) == (1, 8) and sliced(4099, 4352) == (1, 12) and sliced(4099, 2304) == (1, 8) and sliced(4099, 2048) == (0, 0)
+    assert sliced(2051, 10000, 18, 0) == (1, 8) and sliced(2051, 10000, 0, 1) == (0, 0) and sliced(2051, 10000, 9, 2) == (2, 2)
     assert sliced(8195, 3000) == (0, 0)                   # groups of 32 lanes have no time-sliced instance
     assert lib.mx_nsquare_launch_timesliced(2051, 0, 0, 0, ctypes.c_int(), ctypes.c_int()) == -1
 
