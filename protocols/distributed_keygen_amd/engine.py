@@ -374,6 +374,13 @@ class Engine:
             if wv.value == 1 and l.value == 18 and total * k.value // 64 >= 15 * simds // 8:
                 return (18, 1)
         _, l_, _, _, w_ = self.nsquare_launch_shape(n_bits, total)
+        if w_ == 1 and not self._wpg:
+            # One launch of the total would run one wavefront per group (a few per cent ahead of two once it has a
+            # wavefront for every SIMD), but the launches are `total` in PIECES: a piece with fewer wavefronts than SIMDs
+            # is stacked on the CUs of its neighbours, and the two-wavefront form has twice the wavefronts to spread
+            # (key_length 4096, 8 x 1024 in flight: 28.7 ms per step on two wavefronts per group, 42.2 on one)
+            if self.lib.mx_nsquare_launch_shape(n_bits, total, self._lpl_n2(), 2, k, l, w, b, wv) == 0:
+                return (self._lpl_n2() or l.value, 2)
         return (self._lpl_n2() or l_, self._wpg or w_)
 
     def nsquare_launch_split(self, n_bits: int, batch: int) -> Optional[Tuple[int, Tuple[int, int], Tuple[int, int]]]:
