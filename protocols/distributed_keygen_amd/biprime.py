@@ -167,29 +167,27 @@ def biprime_test_with_v_i_batch(
         # one flat column per party (candidate-major), packed with one codec call each; `own` = (party index, handle of
         # that party's values still on the device): taken from there instead of being packed again
         columns = [own[1] if own is not None and own[0] == i else _party_column(v_by_party, i, nslots) for i in order]
-        slot_pass = eng.biprime_verdict_columns(columns, list(moduli), nslots, mods_rows=mods_rows)
+        if _accepts(eng.biprime_verdict_columns, "as_array"):
+            slot_pass = eng.biprime_verdict_columns(columns, list(moduli), nslots, mods_rows=mods_rows, as_array=True)
+        else:
+            slot_pass = eng.biprime_verdict_columns(columns, list(moduli), nslots, mods_rows=mods_rows)
     else:
         # pad short candidates with zeros: their missing slots are never consulted unless reached
         v = [[[int(x) for x in vc[i][:nslots]] + [0] * (nslots - min(nslots, len(vc[i]))) for i in order] for vc in v_by_party]
         slot_pass = eng.biprime_verdict_batch(v, list(moduli))
-    out: List[bool] = []
-    for c, passes in enumerate(slot_pass):
-        verdict: Any = None
-        for k in range(correct_param_biprime):
-            if k >= avail[c]:
-                # reference: AdditiveVariable.get_share on an unset slot
-                if errors == "raise":
-                    raise KeyError(order[0])
-                verdict = KeyError(order[0])
-                break
-            if not passes[k]:
-                verdict = False
-                break
-            if k + 1 >= correct_param_biprime:
-                verdict = True
-                break
-        out.append(verdict if isinstance(verdict, Exception) else bool(verdict))
-    return out
+    # DK:1147-1172 per candidate, slots in order: False at the first failing slot, KeyError on reaching a slot some party
+    # has no value for, True after correct_param_biprime passing slots — as array operations (a round has tens of
+    # thousands of slots)
+    import numpy as np
+
+    passes = np.asarray(slot_pass, dtype=bool).reshape(len(moduli), nslots)
+    have = np.minimum(np.asarray(avail, dtype=np.int64), correct_param_biprime)
+    consulted = np.arange(nslots, dtype=np.int64)[None, :] < have[:, None]
+    fails = (~passes & consulted).any(axis=1)
+    missing = ~fails & (have < correct_param_biprime)
+    if errors == "raise" and missing.any():
+        raise KeyError(order[0])              # reference: AdditiveVariable.get_share on an unset slot
+    return [False if f else (KeyError(order[0]) if m else True) for f, m in zip(fails.tolist(), missing.tolist())]
 
 
 def biprime_test_with_v_i(

@@ -1266,7 +1266,7 @@ class Engine:
         v_t, cnt_t = self.biprime_v_t(g_t, mods_op, exps, gsize, keep)
         vals = self._fetched_ints("v", v_t)
         counts = cnt_t.cpu().numpy()
-        lists = [vals[g * keep : g * keep + int(counts[g])] for g in range(groups)]
+        lists = [vals[g * keep : g * keep + c] for g, c in enumerate(counts.tolist())]
         return (lists, _VRows(v_t, counts, keep)) if keep_rows else lists
 
     # ------------------------------------------------------------------ sieve
@@ -1404,12 +1404,13 @@ class Engine:
         return pass_t
 
     @_int_args
-    def biprime_verdict_columns(self, columns: Sequence[Any], mods: Sequence[int], n_slots: int, mods_rows: Any = None) -> List[List[bool]]:
+    def biprime_verdict_columns(self, columns: Sequence[Any], mods: Sequence[int], n_slots: int, mods_rows: Any = None,
+                                as_array: bool = False):
         """The slot tests DK:1147-1158 of many candidates from ONE COLUMN PER PARTY (party 1 first): a column is a flat
         list of groups * n_slots values (candidate-major; short candidates padded by the caller) — packed with one
         codec call — or the handle ``biprime_v_batch(..., keep_rows=True)`` returned for this party's own values,
         which are then taken from the device as they are.  `mods_rows` as in ``biprime_v_batch``.
-        Returns per candidate the per-slot verdicts, like ``biprime_verdict_batch``."""
+        Returns per candidate the per-slot verdicts, like ``biprime_verdict_batch`` (``as_array``: as one numpy array)."""
         groups = len(mods)
         if groups == 0:
             return []
@@ -1429,7 +1430,8 @@ class Engine:
                 parts.append(self._staged_rows(f"column{len(parts)}", col, limbs, mods).view(groups, n_slots, limbs))
         mods_op = mods_rows.operand(self, groups, limbs) if mods_rows is not None else mods
         pass_t = self.biprime_verdict_t(torch.stack(parts, dim=0), mods_op)
-        return pass_t.cpu().numpy().astype(bool).tolist()
+        arr = pass_t.cpu().numpy().astype(bool)
+        return arr if as_array else arr.tolist()        # as_array: bool [groups, n_slots] for callers that reduce it with numpy
 
     @_int_args
     def biprime_verdict_batch(self, v: Sequence[Sequence[Sequence[int]]], mods: Sequence[int]) -> List[List[bool]]:
