@@ -485,7 +485,8 @@ def decrypt_roofline(eng, wl: DecryptWorkload, steps: int, elapsed: float, kerne
     e_bits = wl.own_exp.bit_length()
     alg_bytes = batch * (2 * 4 * wl.limbs2) + 4 * wl.limbs2 + (e_bits + 7) // 8
     roof["traffic"] = None
-    roof["hbm"] = hbm_block(alg_bytes, kernel_ms, traffic_model, f"n2_k{key_length}_b{batch}_L{Lw}" if not wl.generic else "generic")
+    traffic_key = "generic" if wl.generic else f"n2_k{key_length}_b{batch}_L{Lw}" + ("x2" if roof.get("wavefronts_per_group") == 2 else "")
+    roof["hbm"] = hbm_block(alg_bytes, kernel_ms, traffic_model, traffic_key)
     roof["traffic"] = roof["hbm"]["traffic"]
     roof["hbm"]["note"] = ("bytes of ONE launch over its own duration; the path is integer-VALU bound (north_star: no MFMA) and "
                            "the window table of odd powers lives in HBM on purpose: its traffic is ~1 % of the HBM roof")

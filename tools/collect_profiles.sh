@@ -20,5 +20,6 @@ cp $O/sweep_shapes.txt $P/${tag}_sweep_shapes.txt
 cp $O/small_batch_latency.txt $P/${tag}_small_batch_latency.txt
 cp $O/sweep_generic.txt $P/${tag}_sweep_generic.txt
 cp $O/bi_pivot_sweep.txt $P/${tag}_bi_pivot_sweep.txt
+for f in ts_probe_2048 ts_probe_4096 lone_call_probe keygen_round_host_profile; do [ -f $O/$f.txt ] && grep -v "amdgpu.ids" $O/$f.txt > $P/${tag}_$f.txt; done
 cp $O/short_kernels.txt $P/${tag}_short_kernels.txt; cp $O/${tag}_short_kernels.json $P/
 ls $P | grep -c "^${tag}_"

@@ -31,6 +31,10 @@ python tools/sweep_shapes.py 2048 4096 1024 > $O/sweep_shapes.txt 2>&1
 python tools/sweep_generic.py 1024 2048 > $O/sweep_generic.txt 2>&1
 python tools/bi_pivot_sweep.py 1024 2048 4096 > $O/bi_pivot_sweep.txt 2>&1
 python tools/latency_probe.py > $O/small_batch_latency.txt 2>&1
+TS_SEGS=2,8,12 TS_SIZES=8192,8448,8704,9216,10000,10240,10752,11264,11776,12288,13312,16384 python tools/ts_probe.py 2048 > $O/ts_probe_2048.txt 2>&1
+TS_SEGS=2,8,12 TS_SIZES=4096,4352,4608,5000,5120,5632,6144,7000 python tools/ts_probe.py 4096 > $O/ts_probe_4096.txt 2>&1
+python tools/lone_call_probe.py 10000 0 3 30 > $O/lone_call_probe.txt 2>&1
+python tools/keygen_round_profile.py 65536 > $O/keygen_round_host_profile.txt 2>&1
 # ---- kernel traces of the same commands
 cd /tmp
 B="python3 $R/bench.py --no-cpu-baseline --no-extras --steps 20 --warmup 5"
@@ -68,7 +72,7 @@ cd $R
 python tools/short_kernels.py fit $O/sk_pmc $O/sk_trace profiles/${tag}_short_kernels.json > $O/short_kernels.txt 2>&1
 cp profiles/${tag}_short_kernels.json $O/
 python tools/hbm_traffic.py n2_k2048_b10000_L18 "powmod_n2_kernel" $O/pmc_c3_fetch $O/pmc_c3_write 6 2 > /dev/null
-python tools/hbm_traffic.py n2_k2048_b10000_L9 "powmod_n2_split_kernel" $O/pmc_split_fetch $O/pmc_split_write 6 > /dev/null
+python tools/hbm_traffic.py n2_k2048_b10000_L18x2 "powmod_n2_split_kernel" $O/pmc_split_fetch $O/pmc_split_write 6 > /dev/null
 python tools/hbm_traffic.py biprime_b2053_c4096_L18 "mx::powmod_kernel" $O/pmc_biprime_fetch $O/pmc_biprime_write 3 > /dev/null
 python tools/hbm_traffic.py n2_k4096_b4096_L18 "powmod_n2_kernel" $O/pmc_c5_fetch $O/pmc_c5_write 3 2 > /dev/null
 cp profiles/${tag}_hbm_traffic.json $O/
