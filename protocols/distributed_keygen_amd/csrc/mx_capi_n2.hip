@@ -130,10 +130,11 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   const double m = wpg == 2 ? 2 * L : (p.geo.L / 2 + 1) + 3 * L, o = lat ? 8.0 : wpg == 2 ? 11.0 : 20.0;
   // (round 5 refit, after the build's alignment pass: a lone 18-limb wavefront runs 3 % / 8 % faster than these counts
   // say — 32.1 ms for 8192 ciphertexts on two wavefronts, 54.4 for 16 384 on one — and a second 9-limb pair on a SIMD
-  // costs 8 % more: 35.6 ms for 8192; profiles/r05_ts_probe_2048.txt)
+  // costs 8 % more (35.6 ms for 8192), a second 18-limb pair 18 % more (59.5 ms for 16 384); profiles/r05_ts_probe_2048.txt,
+  // r05_sweep_shapes.txt)
   const bool wide_geo = lpl == LIMBS_PER_LANE_WIDE;
   const double alone = steps * (5.3 * (m + o) + 80.0 / L) * (wide_geo ? (wpg == 2 ? 0.967 : 0.924) : 1.0);
-  const double shared = steps * (4.2 * m + 2.3 * o) * (lat ? 1.22 : wpg == 2 ? (wide_geo ? 1.0 : 1.08) : 1.17);     // one wavefront doing both passes overlaps less
+  const double shared = steps * (4.2 * m + 2.3 * o) * (lat ? 1.22 : wpg == 2 ? (wide_geo ? 1.18 : 1.08) : 1.17);     // one wavefront doing both passes overlaps less
   const int cus = device_cus();
   const int64_t per_simd = wpg == 2 ? (p.nblocks + cus - 1) / cus : (p.nblocks + 4 * cus - 1) / (4 * cus);
   const int64_t fit = lpl == LIMBS_PER_LANE_WIDE ? 2 : lpl == LIMBS_PER_LANE ? 3 : 8;
