@@ -295,6 +295,9 @@ struct BiHi {
 // puts the wavefronts of a second workgroup on SIMDs the first already uses: 500 pairs took 6.0 ms where 250 take 4.3).
 constexpr int BI_PAIRS = 2;
 
+#ifdef MX_BI_TRACE
+__device__ u64 mx_bi_trace[16];
+#endif
 template <int K, int W>
 __global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs A) {
   constexpr int L = 3, PW = L * K, GPW = 64 / K;
@@ -354,27 +357,42 @@ __global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs 
   if (role == 1) H.gather(a, C);
 
   // one product: a <- a * B * theta (B = C: squaring), both wavefronts
+#ifdef MX_BI_TRACE          // developer builds (tools/bi_phase_probe.py): shader-clock cycles per phase of a product, pair 0 of workgroup 0
+  u64 trc[5] = {0, 0, 0, 0, 0};
+#define MX_BI_MARK(k) { const u64 now_ = __builtin_readcyclecounter(); trc[k] += now_ - mark_; mark_ = now_; }
+#else
+#define MX_BI_MARK(k)
+#endif
   auto product = [&](auto sq_tag, const u32* B) {
     constexpr bool SQ = decltype(sq_tag)::value;
     u64 t[L];
     u32 dg0 = 0;
+#ifdef MX_BI_TRACE
+    u64 mark_ = __builtin_readcyclecounter();
+#endif
     if (role == 0) {
       u32 r[L];
       M.lds = const_cast<u32*>(B);
       M.template mulx<M_t::F_FRIENDLY | M_t::F_STAGED | (SQ ? M_t::F_SQUARE : 0)>(r, a, a, a, a, a, nullptr, nullptr, nblk_lo);
 #pragma unroll
       for (int j = 0; j < L; ++j) TL[p * L + j] = r[j];
+      MX_BI_MARK(0)                                  // L: its half
     } else {
       H.template half<SQ>(t, a, B, A.pd, A.h_lo);
+      MX_BI_MARK(0)                                  // H: its half
       dg0 = H.pre(t);
+      MX_BI_MARK(1)                                  // H: sweep + fold of five top positions
     }
     __syncthreads();
+    MX_BI_MARK(2)                                    // waiting for the other half
     if (role == 1) H.post(t, dg0, TL, C, a, A.pd);
+    MX_BI_MARK(3)                                    // H: + L's half, last fold, sweep, publish (L: nothing)
     __syncthreads();
     if (role == 0) {
 #pragma unroll
       for (int j = 0; j < L; ++j) a[j] = C[p * L + j];
     }
+    MX_BI_MARK(4)                                    // second barrier (+ L reading the product)
   };
   using sq_t = std::integral_constant<bool, true>;
   using mul_t = std::integral_constant<bool, false>;
@@ -437,6 +455,11 @@ __global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs 
     M.cond_sub(res);
     M.store(A.out + elem * A.limbs, A.limbs, res, valid);
   }
+#ifdef MX_BI_TRACE
+  if (blockIdx.x == 0 && pair == 0 && lane == 0) {
+    for (int k = 0; k < 5; ++k) mx_bi_trace[role * 8 + k] = trc[k];
+  }
+#endif
 }
 
 }  // namespace mx

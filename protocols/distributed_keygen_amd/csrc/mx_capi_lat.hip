@@ -41,6 +41,15 @@ static int launch_bi(const mx::PowmodBiArgs& a, int64_t nblocks, hipStream_t s) 
   MxKernelTimer timer(s);
   hipLaunchKernelGGL((mx::powmod_bi_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(128 * mx::BI_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());
+#ifdef MX_BI_TRACE          // developer builds: cycles per phase of the products of pair 0 (tools/bi_phase_probe.py reads stderr)
+  {
+    unsigned long long h[16] = {};
+    MX_HIP(hipStreamSynchronize(s));
+    MX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(mx::mx_bi_trace), sizeof(h)));
+    fprintf(stderr, "bi_trace K=%d pivot=%d of %d: L half %llu wait %llu post-idle %llu barrier2+read %llu | H half %llu pre %llu wait %llu post %llu barrier2 %llu\n",
+            K, a.h_lo, 3 * a.nblk, h[0], h[2], h[3], h[4], h[8], h[9], h[10], h[11], h[12]);
+  }
+#endif
   return MX_OK;
 }
 template <int K>
