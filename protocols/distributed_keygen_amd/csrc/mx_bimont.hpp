@@ -32,7 +32,7 @@
 
 namespace mx {
 
-constexpr int BI_ROWS = 8;   // per group in PowmodBiArgs::consts: rows 0..5 = 2^(W*(Pd+k)) mod N, 6 = 2^(W*(Pd+6)) mod N, 7 = 2^(W*(hL+Pd)) mod N
+constexpr int BI_ROWS = 9;   // per group in PowmodBiArgs::consts: rows 0..5 = 2^(W*(Pd+k)) mod N, 6 = 2^(W*(Pd+6)) mod N, 7 = 2^(W*(hL+Pd)) mod N, 8 = 2^(W*(Pd-hL)) mod N
 
 struct PowmodBiArgs {
   const u32* bases;   // [batch][limbs]      device, radix 2^32 words
@@ -100,6 +100,30 @@ __global__ void __launch_bounds__(64) bisetup_kernel(BiSetupArgs A) {
   if (valid) {
 #pragma unroll
     for (int j = 0; j < L; ++j) rows[7 * PW + p * L + j] = kin[j];
+  }
+  // the factor that leaves the domain, theta * R = 2^(W*(Pd - hL)), REDUCED modulo this group's N.  (Round 5 first used the
+  // power of two as it is: the geometry keeps it below a modulus of the launch's bit length, but a launch has one geometry
+  // and every group its own modulus — for a modulus a few bits shorter than the longest the epilogue's two conditional
+  // subtractions then left N + 1 where 1 was due; found by tools/soak_round5.py, seed 19.)
+  u32 one[L], up[L], ko[L];
+#pragma unroll
+  for (int j = 0; j < L; ++j) {
+    pw[j] = (p * L + j == A.pd - A.h_lo) ? 1u : 0u;
+    one[j] = (p * L + j == 0) ? 1u : 0u;
+  }
+  M.mul(up, pw, r2);                           // 2^(W*(Pd-hL)) * R mod N
+  M.mul(ko, up, one);                          // ... / R: the power itself, lazy
+  {
+    u64 t[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] = ko[j];
+    M.normalize_full(ko, t);
+    M.cond_sub(ko);
+    M.cond_sub(ko);
+  }
+  if (valid) {
+#pragma unroll
+    for (int j = 0; j < L; ++j) rows[8 * PW + p * L + j] = ko[j];
   }
 }
 
@@ -445,7 +469,7 @@ __global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs 
     M.lds = ST;
     u32 kout[L], y[L], res[L];
 #pragma unroll
-    for (int j = 0; j < L; ++j) kout[j] = (p * L + j == A.pd - A.h_lo) ? 1u : 0u;      // theta * R = 2^(W*(Pd - hL)) < N
+    for (int j = 0; j < L; ++j) kout[j] = crow[8 * PW + p * L + j];                    // theta * R = 2^(W*(Pd - hL)) mod N (bisetup_kernel)
     M.mul(y, a, kout);
     u64 t[L];
 #pragma unroll

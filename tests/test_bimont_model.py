@@ -53,3 +53,27 @@ def test_library_launches_the_models_geometry():
     assert lib.mx_powmod_geometry_for(5360, 80, 2, 6, k, l, w, b) == -2          # MX_ERR_SIZE: the form ends at 5359 bits
     waves = ctypes.c_int()
     assert lib.mx_powmod_launch_form(2053, 80, 2, 9, waves, None) == 0 and waves.value == 1
+
+
+def test_leaving_the_domain_needs_the_factor_reduced_modulo_each_groups_modulus():
+    """The epilogue (one plain Montgomery product with theta * R, two conditional subtractions) for the largest lazy
+    accumulator a product can leave, with the launch's geometry taken from a LONGER modulus than the group's own: correct
+    with the factor reduced modulo the group's N (bisetup_kernel, row 8), and off by a multiple of N with the bare power
+    of two the first form of the kernel used (tools/soak_round5.py seed 19; tests/test_gpu_powmod.py has the GPU case)."""
+    import random
+
+    rng = random.Random(19)
+    broken = 0
+    for launch_bits in (91, 1029, 2053):
+        for shorter in (0, 1, 5, 17, launch_bits // 2):
+            nbits = launch_bits - shorter
+            n = rng.getrandbits(nbits) | (1 << (nbits - 1)) | 1
+            for h_lo in (3, 0):
+                geo = bm.Geometry(launch_bits, h_lo)
+                theta = pow(pow(2, bm.W * geo.h_lo, n), -1, n)
+                top = (1 << (bm.W * geo.Pd)) + (1 << (bm.W * geo.Pd - 20))          # < 2^(W*Pd) * (1 + tiny)
+                for r in (1, n - 1, rng.randrange(n)):
+                    acc = r + (top - r) // n * n                                      # the largest representative of r
+                    assert bm.leave_domain(acc, n, geo, reduced=True) == r * theta % n, (launch_bits, shorter, h_lo)
+                    broken += bm.leave_domain(acc, n, geo, reduced=False) != r * theta % n
+    assert broken > 0          # (the bare power of two is only safe for moduli of the launch's own length)

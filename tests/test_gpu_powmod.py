@@ -424,3 +424,42 @@ def test_bipartite_latency_form(eng, bits):
                 assert eng.powmod_batch_multi(gens, ex, cands) == [[pow(g, e, c) for g in gs] for gs, e, c in zip(gens, ex, cands)]
     finally:
         eng.set_limbs_per_lane(0)
+
+
+def test_bipartite_form_with_moduli_of_different_lengths_in_one_launch(eng):
+    """A launch has ONE geometry (from its longest modulus) and every group its own modulus: the factor that leaves the
+    domain must be reduced modulo EACH group's N.  The first form used the power of two 2^(W(Pd - pivot)) itself, which the
+    geometry keeps below a modulus of the launch's bit length only; for (m - 1)^even modulo a modulus five bits shorter
+    the epilogue then returned m + 1 (tools/soak_round5.py seed 19, reproduced below with the pivot it had), and with the
+    library's own pivot any modulus below about half the launch's length broke the same way."""
+    rng = random.Random(1905)
+    eng.set_limbs_per_lane(6)
+    try:
+        mods = [0x71fbad03ca2e35fc42df03f, 0x3ffffffffffffffbfffffff, 0x158572c1f2c53615402469d, 0x9a8a626a55a009bae63c6f,
+                0x7fb7e00a02f6bbf3437e4f, 0x2feaaa2629da259a2420d1, 0x1ffffffffffbffffffffff]
+        exps = [0xa4bc2ca7c8e97fdd, 1, 0xffffffffffffffff, 0, 1, 0xee202d3b477e5540, 0xffffffffffffffff]
+        rows = [[0], [1], [0xff926be0a485352718e705], [1], [1], [0x2feaaa2629da259a2420d0], [0x1ffffffffffbfffffffffe]]
+        for pivot in (3, 0):
+            eng.debug_knob("bi_pivot", pivot)
+            assert eng.powmod_batch_multi(rows, exps, mods) == [[pow(b, e, m) for b in r] for r, e, m in zip(rows, exps, mods)], pivot
+        # moduli from full length down to a few limbs in one launch, at the key lengths the form is chosen for, every pivot class
+        for bits in (1029, 2053):
+            lens = [bits, bits - 1, bits - 7, bits - 40, bits * 3 // 4, bits // 2 + 1, bits // 2 - 30, bits // 3, 200, 61, 3]
+            mods = [rng.getrandbits(b) | (1 << (b - 1)) | 1 for b in lens]
+            exps = [rng.getrandbits(rng.choice([bits - 2, 64, 300])) | 1 for _ in mods]
+            exps[0] &= ~1
+            rows = [[m - 1, 1, 0, rng.randrange(m), rng.randrange(m)] for m in mods]
+            want = [[pow(b, e, m) for b in r] for r, e, m in zip(rows, exps, mods)]
+            steps = 3 * (-(-(bits + 35) // 87)) + 3
+            for pivot in (0, 3, 3 * (steps // 6), steps - 6):
+                eng.debug_knob("bi_pivot", pivot)
+                assert eng.generic_launch_form(bits, 5 * len(mods), len(mods))[0] == 2
+                assert eng.powmod_batch_multi(rows, exps, mods) == want, (bits, pivot)
+            eng.debug_knob("bi_pivot", 0)
+            for lpl in (3, 9, 18, 0):                 # the same launch in the one-wavefront forms (and the library's choice)
+                eng.set_limbs_per_lane(lpl)
+                assert eng.powmod_batch_multi(rows, exps, mods) == want, (bits, lpl)
+            eng.set_limbs_per_lane(6)
+    finally:
+        eng.debug_knob("bi_pivot", 0)
+        eng.set_limbs_per_lane(0)

@@ -248,9 +248,28 @@ def bmul(geo: Geometry, cst: Constants, a, b, square: bool = False, track=None):
     return half_hi_and_sum(geo, cst, a, b, t_lo, square, track)
 
 
-def powmod(g: int, e: int, n: int, win: int = 5, h_lo: int = 0, track=None) -> int:
-    """g^e mod n the way powmod_bi_kernel computes it: fixed window, every product bipartite."""
-    geo = Geometry(n.bit_length(), h_lo)
+def leave_domain(acc_value: int, n: int, geo: Geometry, reduced: bool = True) -> int:
+    """The kernel's epilogue: one plain Montgomery product (radix 2^(W*Pd)) of the accumulator with theta * R =
+    2^(W*(Pd - h_lo)), then two conditional subtractions.  `reduced`: the factor modulo n (bisetup_kernel, row 8) — or the
+    power of two itself, as the first form of the kernel had it: below a modulus of the LAUNCH's bit length by the
+    geometry's clamp, but not below a shorter modulus of another group of the same launch."""
+    R = 1 << (W * geo.Pd)
+    kout = 1 << (W * (geo.Pd - geo.h_lo))
+    if reduced:
+        kout %= n
+    q = (-acc_value * kout * pow(n, -1, R)) % R
+    y = (acc_value * kout + q * n) // R
+    assert (acc_value * kout + q * n) % R == 0
+    for _ in range(2):
+        if y >= n:
+            y -= n
+    return y
+
+
+def powmod(g: int, e: int, n: int, win: int = 5, h_lo: int = 0, track=None, launch_bits: int = 0, reduced_exit: bool = True) -> int:
+    """g^e mod n the way powmod_bi_kernel computes it: fixed window, every product bipartite.  `launch_bits`: the bit
+    length the launch's geometry is derived from (the longest modulus of the launch; default: n's own)."""
+    geo = Geometry(max(launch_bits, n.bit_length()), h_lo)
     cst = Constants(n, geo)
     cnt = L * geo.K
     x = limbs_of(g % n * cst.theta_inv % n, cnt)        # into the domain (the kernel: one plain Montgomery product)
@@ -264,7 +283,9 @@ def powmod(g: int, e: int, n: int, win: int = 5, h_lo: int = 0, track=None) -> i
         for _ in range(win):
             acc = bmul(geo, cst, acc, acc, True, track)
         acc = bmul(geo, cst, acc, table[(e >> (win * d)) & ((1 << win) - 1)], False, track)
-    return value_of(acc) * cst.theta % n                # out of the domain (the kernel: one plain Montgomery product + cond_sub)
+    out = leave_domain(value_of(acc), n, geo, reduced_exit)                # out of the domain
+    assert not reduced_exit or out == value_of(acc) * cst.theta % n
+    return out
 
 
 if __name__ == "__main__":

@@ -43,12 +43,19 @@ def main():
             rows = [[rng.choice([0, 1, m - 1, rng.randrange(m)]) for _ in range(rng.randint(1, gsize))] for m in mods]
             eng.set_limbs_per_lane(6)
             steps = 3 * (-(-(bits + 35) // 87)) + 3
-            eng.debug_knob("bi_pivot", rng.choice([0, 0, 3 * rng.randint(1, max(1, steps // 3 - 1))]))
-            eng.debug_knob("lat_lanes", rng.choice([0, 0, 0, 16, 64]))
+            pivot_knob = rng.choice([0, 0, 3 * rng.randint(1, max(1, steps // 3 - 1))])
+            lanes_knob = rng.choice([0, 0, 0, 16, 64])
+            eng.debug_knob("bi_pivot", pivot_knob)
+            eng.debug_knob("lat_lanes", lanes_knob)
             assert eng.generic_launch_form(bits, sum(len(r) for r in rows) or 1, groups)[0] == 2
             got = eng.powmod_batch_multi(rows, exps, mods)
             want = pool.starmap(pow, [(b, e, m) for r, e, m in zip(rows, exps, mods) for b in r], chunksize=4)
             flat = [x for r in got for x in r]
+            if flat != want:
+                bad = [i for i, (x, y) in enumerate(zip(flat, want)) if x != y]
+                print("MISMATCH bipartite", {"round": rounds, "bits": bits, "groups": groups, "ebits": ebits, "pivot_knob": pivot_knob, "lanes_knob": lanes_knob,
+                                             "mods": [hex(m) for m in mods], "exps": [hex(e) for e in exps], "rows": [[hex(b) for b in r] for r in rows],
+                                             "bad": bad[:10], "got": [hex(flat[i]) for i in bad[:4]], "want": [hex(want[i]) for i in bad[:4]]}, flush=True)
             assert flat == want, ("bipartite", rounds, bits, groups, ebits)
             done["bipartite"] += len(flat)
             eng.debug_knob("bi_pivot", 0)
