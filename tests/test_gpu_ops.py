@@ -711,3 +711,51 @@ def test_latency_geometry_setting_falls_back_for_wide_generic_moduli(eng):
         assert eng.powmod_batch(bases[:3], exp, small) == [pow(b % small, exp, small) for b in bases[:3]]
     finally:
         eng.set_limbs_per_lane(0)
+
+
+@pytest.mark.gpu
+def test_round_kernels_with_moduli_of_very_different_lengths_in_one_launch(eng):
+    """One launch has one geometry — taken from its longest modulus — and every candidate its own modulus: the Jacobi
+    filter, the selection, the v modexps (every lane geometry incl. the bipartite form) and the verdict for candidates
+    from full length down to a few bits in ONE call, against the oracle.  (A keygen round's candidates differ by a bit
+    or two; round 5's soak found a group that came out as N + 1 when they differ by five, csrc/mx_bimont.hpp.)"""
+    from oracle import oracle
+    from protocols.distributed_keygen_amd import biprime
+
+    rng = random.Random(55)
+    n_parties, keep = 3, 6
+    for bits in (1029, 2053):
+        lens = [bits, bits - 1, bits - 6, bits - 33, bits * 2 // 3, bits // 2 + 2, bits // 3, 190, 64, 9]
+        mods, shares = [], []
+        for b in lens:
+            while True:
+                p = [rng.getrandbits(max(2, b // 2 - 2)) for _ in range(n_parties)]
+                q = [rng.getrandbits(max(2, b // 2 - 2)) for _ in range(n_parties)]
+                p[0] |= 3; q[0] |= 3
+                for i in range(1, n_parties):
+                    p[i] &= ~3; q[i] &= ~3
+                m = sum(p) * sum(q)
+                if m % 2 == 1 and m >= 9:
+                    break
+            mods.append(m); shares.append((p, q))
+        gens = [[rng.randrange(m) for _ in range(24)] for m in mods]
+        want_v = {i: [oracle.biprime_test_v_calculation(g, i, m, sh[0][i - 1], sh[1][i - 1], keep) for g, m, sh in zip(gens, mods, shares)]
+                  for i in range(1, n_parties + 1)}
+        try:
+            for lpl in (0, 3, 6, 9, 18):
+                eng.set_limbs_per_lane(lpl)
+                for i in (1, 2):
+                    got = biprime.biprime_test_v_calculation_batch(gens, i, mods, [sh[0][i - 1] for sh in shares], [sh[1][i - 1] for sh in shares], keep, eng)
+                    assert got == want_v[i], (bits, lpl, i)
+        finally:
+            eng.set_limbs_per_lane(0)
+        assert eng.jacobi_batch(gens, mods) == [[oracle.jacobi_symbol(g, m) for g in gs] for gs, m in zip(gens, mods)]
+        v_by = [{i: want_v[i][c] for i in want_v} for c in range(len(mods))]
+        want = []
+        for c, m in enumerate(mods):
+            try:
+                want.append(oracle.biprime_test_with_v_i(v_by[c], m, keep))
+            except KeyError as exc:
+                want.append(type(exc))
+        got = biprime.biprime_test_with_v_i_batch(v_by, mods, keep, eng, errors="return")
+        assert [type(g) if isinstance(g, Exception) else g for g in got] == want, bits

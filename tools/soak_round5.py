@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised differential soak of what round 5 added, against CPython pow on all host cores (GPU box):
   * the bipartite latency form of the generic kernel (limbs_per_lane 6) over random modulus lengths (every group width 4..64,
-    lengths around the geometry steps), special and random moduli, per-group moduli of different lengths, ragged groups,
+    lengths around the geometry steps), special and random moduli, per-group moduli of different — now and then VERY different — lengths, ragged groups,
     exponents 0 / 1 / all-ones / random, every pivot (developer knob) and more lanes per element than needed;
   * partial decryptions with the fixed-window tape in random launch shapes and segment counts.
 usage: soak_round5.py [seed] [seconds]"""
@@ -36,7 +36,9 @@ def main():
                                rng.randint(700, 2600), rng.randint(2600, 5359), rng.choice([52, 53, 139, 140, 313, 314, 2574, 2575, 5359])])
             groups = rng.choice([1, 2, 3, 7])
             special = lambda b: rng.choice([(1 << b) - 1, (1 << (b - 1)) + 1, ((1 << b) - 1) ^ (1 << (b // 2)), (1 << b) - (1 << (b // 3)) - 1]) | 1
-            mods = [max(3, special(max(2, bits - g)) if rng.random() < 0.25 else rng.getrandbits(max(2, bits - g)) | (1 << (max(2, bits - g) - 1)) | 1) for g in range(groups)]
+            wild = rng.random() < 0.2          # a launch has ONE geometry, from its longest modulus: groups with much shorter ones
+            glen = [max(2, bits - g) if not (wild and g) else rng.randint(2, bits) for g in range(groups)]
+            mods = [max(3, special(b) if rng.random() < 0.25 else rng.getrandbits(b) | (1 << (b - 1)) | 1) for b in glen]
             ebits = rng.choice([1, 2, 17, 64, 150, min(bits, 400)])
             exps = [rng.choice([0, 1, (1 << ebits) - 1, rng.getrandbits(ebits)]) for _ in mods]
             gsize = rng.choice([1, 3, 5, 16, 40]) if bits < 2600 else rng.choice([1, 3])
