@@ -358,6 +358,11 @@ int mx_nsquare_geometry_for(int n_bits, int64_t batch, int limbs_per_lane, int* 
 int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                             int* lanes_per_element, int* limbs_per_lane_out, int* limb_bits, int* blocks,
                             int* wavefronts_per_group_out);
+/* For callers that keep SEVERAL launches in flight which together process `total` elements (several streams, several
+ * keys): the shape to pass to each of them — the plain form with the lowest estimate for one launch of the total, never a
+ * time-sliced one (only a lone launch can be that).  Arguments as mx_nsquare_launch_shape; ABI 4.2. */
+int mx_nsquare_pieces_shape(int n_bits, int64_t total, int limbs_per_lane, int wavefronts_per_group,
+                            int* limbs_per_lane_out, int* wavefronts_per_group_out);
 /* Whether mx_powmod_nsquare_run runs this launch in the time-sliced form of the two-wavefront kernel: a fixed number
  * of resident workgroups per CU that take (segment, group of elements) units from a queue in the workspace, chosen
  * when a lone launch has somewhat more groups than the GPU holds at once (e.g. 10 000 ciphertexts at key_length

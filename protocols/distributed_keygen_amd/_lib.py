@@ -58,6 +58,7 @@ SYMBOLS = {
     "mx_nsquare_launch_instance": (c_int, [c_int, c_int64, c_int, c_int, *[POINTER(c_int)] * 5]),
     "mx_nsquare_launch_split": (c_int, [c_int, c_int64, POINTER(c_int64), *[POINTER(c_int)] * 4]),
     "mx_nsquare_launch_timesliced": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
+    "mx_nsquare_pieces_shape": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "mx_combine_plan_bytes": (c_int64, [c_int, c_int]),
     "mx_combine_prepare": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_combine_run": (c_int, [POINTER(CombinePlan), c_void_p, c_void_p, c_int, c_void_p, c_int, c_int64, c_void_p]),

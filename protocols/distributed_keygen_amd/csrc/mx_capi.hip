@@ -317,7 +317,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 401; }
+int mx_version(void) { return 402; }
 
 const char* mx_error_string(int code) {
   switch (code) {

@@ -300,6 +300,30 @@ extern "C" int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_
   return MX_OK;
 }
 
+// Shape for launches that are IN FLIGHT TOGETHER as pieces of `total` elements (several streams, several keys): the plain
+// form with the lowest estimate for one launch of the total — the pieces then resemble it — never a time-sliced one, which
+// only a lone launch can be (4 x 2500 ciphertexts at key_length 2048: 214 k/s at 9 limbs per lane on two wavefronts, 179 k/s
+// in the shape of the time-sliced choice for a lone 10 000).
+extern "C" int mx_nsquare_pieces_shape(int n_bits, int64_t total, int limbs_per_lane, int wavefronts_per_group,
+                                       int* limbs_per_lane_out, int* wavefronts_per_group_out) {
+  if (!limbs_per_lane_out || !wavefronts_per_group_out || total <= 0) return MX_ERR_ARG;
+  if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
+  double best_t = -1.0;
+  for (int l : N2_LPLS) {
+    if (limbs_per_lane && l != limbs_per_lane) continue;
+    for (int w : {1, 2}) {
+      if (wavefronts_per_group && w != wavefronts_per_group) continue;
+      double t = n2_estimate(n_bits, total, l, w);                // (no `resident` out-parameter: the plain launch)
+      // pieces of the wide two-wavefront form overlap better than one launch of their sum (4 x 5000 ciphertexts: 279 k/s
+      // against 257 k/s at 9 limbs per lane, where the estimates for one launch of 20 000 say 87 against 83 ms)
+      if (l == LIMBS_PER_LANE_WIDE && w == 2) t *= 0.93;
+      if (t > 0 && (best_t < 0 || t < best_t)) { best_t = t; *limbs_per_lane_out = l; *wavefronts_per_group_out = w; }
+    }
+  }
+  return best_t < 0 ? MX_ERR_SIZE : MX_OK;
+}
+
 extern "C" int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                                             int* resident_per_cu, int* units_per_group) {
   if (!resident_per_cu || !units_per_group || batch <= 0) return MX_ERR_ARG;

@@ -373,14 +373,18 @@ class Engine:
             simds = 4 * self.torch.cuda.get_device_properties(self.device).multi_processor_count
             if wv.value == 1 and l.value == 18 and total * k.value // 64 >= 15 * simds // 8:
                 return (18, 1)
-        _, l_, _, _, w_ = self.nsquare_launch_shape(n_bits, total)
+        # otherwise what one PLAIN launch of the total would run (a time-sliced form is a lone launch's: 4 x 2500 ciphertexts
+        # at key_length 2048 reach 214 k/s at 9 limbs per lane, 179 k/s in the shape of the time-sliced choice for 10 000)
+        lo, wo = ctypes.c_int(), ctypes.c_int()
+        _lib.check(self.lib.mx_nsquare_pieces_shape(n_bits, total, self._lpl_n2(), self._wpg, lo, wo), "mx_nsquare_pieces_shape")
+        l_, w_ = lo.value, wo.value
         if w_ == 1 and not self._wpg:
             # One launch of the total would run one wavefront per group (a few per cent ahead of two once it has a
             # wavefront for every SIMD), but the launches are `total` in PIECES: a piece with fewer wavefronts than SIMDs
             # is stacked on the CUs of its neighbours, and the two-wavefront form has twice the wavefronts to spread
             # (key_length 4096, 8 x 1024 in flight: 28.7 ms per step on two wavefronts per group, 42.2 on one)
-            if self.lib.mx_nsquare_launch_shape(n_bits, total, self._lpl_n2(), 2, k, l, w, b, wv) == 0:
-                return (self._lpl_n2() or l.value, 2)
+            if self.lib.mx_nsquare_pieces_shape(n_bits, total, self._lpl_n2(), 2, lo, wo) == 0:
+                return (self._lpl_n2() or lo.value, 2)
         return (self._lpl_n2() or l_, self._wpg or w_)
 
     def nsquare_launch_split(self, n_bits: int, batch: int) -> Optional[Tuple[int, Tuple[int, int], Tuple[int, int]]]:

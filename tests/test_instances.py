@@ -100,6 +100,29 @@ def test_time_sliced_launches_where_they_were_measured_to_pay():
     assert lib.mx_nsquare_launch_timesliced(2051, 0, 0, 0, ctypes.c_int(), ctypes.c_int()) == -1
 
 
+def test_shape_for_launches_that_share_the_machine_as_pieces():
+    """mx_nsquare_pieces_shape: the plain form for launches that are in flight together (Engine.saturating_shape below the
+    saturating sizes) — never the time-sliced choice of a lone launch; measured with four pieces in flight at key_length
+    2048: 4 x 1250 and 4 x 5000 best at 18 limbs on two wavefronts (152 k/s, 280 k/s), 4 x 2500 at 9 limbs (215 against 179)."""
+    import ctypes
+
+    from protocols.distributed_keygen_amd import _lib
+
+    lib = _lib.lib()
+
+    def pieces(bits, total, lpl=0, wpg=0):
+        l, w = ctypes.c_int(), ctypes.c_int()
+        assert lib.mx_nsquare_pieces_shape(bits, total, lpl, wpg, l, w) == 0
+        return l.value, w.value
+
+    assert pieces(2051, 5000) == (18, 2) and pieces(2051, 10000) == (9, 2) and pieces(2051, 12288) == (9, 2)
+    assert pieces(2051, 20000) == (18, 2) and pieces(2051, 30000) == (18, 1)
+    assert pieces(4099, 8192) == (18, 1) and pieces(4099, 8192, 0, 2) == (18, 2) and pieces(4099, 2048) == (9, 2)
+    assert pieces(2051, 10000, 18, 0)[0] == 18 and pieces(1027, 2048) == (3, 2)
+    assert lib.mx_nsquare_pieces_shape(2051, 0, 0, 0, ctypes.c_int(), ctypes.c_int()) == -1
+    assert lib.mx_nsquare_pieces_shape(2051, 100, 7, 0, ctypes.c_int(), ctypes.c_int()) == -1
+
+
 def test_no_kernel_has_a_private_segment():
     """Every shipped instance of the three modexp kernels runs without scratch memory: private_segment_fixed_size 0 and no
     spilled vector register in the kernel descriptors of the BUILT library (tools/scratch_report.py reads the code
