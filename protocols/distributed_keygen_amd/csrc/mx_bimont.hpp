@@ -319,7 +319,7 @@ struct BiHi {
 // puts the wavefronts of a second workgroup on SIMDs the first already uses: 500 pairs took 6.0 ms where 250 take 4.3).
 constexpr int BI_PAIRS = 2;
 
-#ifdef MX_BI_TRACE
+#ifdef MX_DEV_BI_TRACE
 __device__ u64 mx_bi_trace[16];
 #endif
 template <int K, int W>
@@ -381,7 +381,7 @@ __global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs 
   if (role == 1) H.gather(a, C);
 
   // one product: a <- a * B * theta (B = C: squaring), both wavefronts
-#ifdef MX_BI_TRACE          // developer builds (tools/bi_phase_probe.py): shader-clock cycles per phase of a product, pair 0 of workgroup 0
+#ifdef MX_DEV_BI_TRACE          // developer builds (tools/bi_phase_probe.py): shader-clock cycles per phase of a product, pair 0 of workgroup 0
   u64 trc[5] = {0, 0, 0, 0, 0};
 #define MX_BI_MARK(k) { const u64 now_ = __builtin_readcyclecounter(); trc[k] += now_ - mark_; mark_ = now_; }
 #else
@@ -391,7 +391,7 @@ __global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs 
     constexpr bool SQ = decltype(sq_tag)::value;
     u64 t[L];
     u32 dg0 = 0;
-#ifdef MX_BI_TRACE
+#ifdef MX_DEV_BI_TRACE
     u64 mark_ = __builtin_readcyclecounter();
 #endif
     if (role == 0) {
@@ -479,7 +479,7 @@ __global__ void __launch_bounds__(128 * BI_PAIRS) powmod_bi_kernel(PowmodBiArgs 
     M.cond_sub(res);
     M.store(A.out + elem * A.limbs, A.limbs, res, valid);
   }
-#ifdef MX_BI_TRACE
+#ifdef MX_DEV_BI_TRACE
   if (blockIdx.x == 0 && pair == 0 && lane == 0) {
     for (int k = 0; k < 5; ++k) mx_bi_trace[role * 8 + k] = trc[k];
   }

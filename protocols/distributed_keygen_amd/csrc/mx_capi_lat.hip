@@ -41,7 +41,7 @@ static int launch_bi(const mx::PowmodBiArgs& a, int64_t nblocks, hipStream_t s) 
   MxKernelTimer timer(s);
   hipLaunchKernelGGL((mx::powmod_bi_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(128 * mx::BI_PAIRS), lds, s, a);
   MX_HIP(hipGetLastError());
-#ifdef MX_BI_TRACE          // developer builds: cycles per phase of the products of pair 0 (tools/bi_phase_probe.py reads stderr)
+#ifdef MX_DEV_BI_TRACE          // developer builds: cycles per phase of the products of pair 0 (tools/bi_phase_probe.py reads stderr)
   {
     unsigned long long h[16] = {};
     MX_HIP(hipStreamSynchronize(s));

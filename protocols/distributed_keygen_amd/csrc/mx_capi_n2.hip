@@ -44,7 +44,7 @@ bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg
   p.table_bytes = align256((int64_t)p.nslots * 2 * p.geo.L * p.nlanes * 4);
   p.groups = (batch + 64 / p.geo.K - 1) / (64 / p.geo.K);
   p.sched_bytes = wpg == 2 ? align256((mx::N2_TS_HEADER + p.groups * (N2_TIMESLICE_MAX_SEGMENTS - 1)) * 4) : 0;
-#ifdef MX_TS_TRACE          // four words per unit behind the queues (mx_powmod_n2_split.hpp)
+#ifdef MX_DEV_TS_TRACE          // four words per unit behind the queues (mx_powmod_n2_split.hpp)
   if (wpg == 2) p.sched_bytes += align256(p.groups * N2_TIMESLICE_MAX_SEGMENTS * 16);
 #endif
   return true;

@@ -32,7 +32,7 @@ int launch_n2_wide(int K, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_
 }
 }  // namespace mxw
 
-#ifdef MX_PRIVATE_PAD_WORDS
+#ifdef MX_DEV_PRIVATE_PAD_WORDS
 // developer build: faults the pad check of powmod_n2_kernel counted since the last call (and the first 32 of them,
 // 7 words each: tag, workgroup, lane, index, expected, found, first*2+last); resets the counter
 extern "C" int mx_debug_pad_faults(uint32_t* log_words, int max_entries) {

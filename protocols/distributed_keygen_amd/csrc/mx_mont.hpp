@@ -25,6 +25,7 @@
 // verdict kernels.  It replaces the reference's calls into gmpy2/CPython big-int pow
 // (reference: distributed_keygen.py:1094,1097; paillier_shared_key.py:92,115-125).
 #pragma once
+#include "mx_dev.hpp"
 #include "mx_lanes.hpp"
 #include <utility>
 
@@ -46,14 +47,11 @@ struct Mont {
   static constexpr u32 MASK = (1u << W) - 1u;
   static constexpr int LIMBS = L;
   static constexpr int S = K * L;              // capacity in limbs
-  // per-group scratch (32-bit words): multiplier b, second multiplier d.  MX_LDS_PAD_WORDS (a build flag for A/B runs,
+  // per-group scratch (32-bit words): multiplier b, second multiplier d.  MX_DEV_LDS_PAD_WORDS (a build flag for A/B runs,
   // default 0) lengthens the stride between the groups of a wavefront: with 152 words (18-limb groups of 4 lanes) the 16
   // groups' broadcast reads of a multiplier limb fall on 4 of the 32 banks; an odd stride spreads them over 16
   // (profiles/r05_lds_stride_ab.txt: what that is worth)
-#ifndef MX_LDS_PAD_WORDS
-#define MX_LDS_PAD_WORDS 0
-#endif
-  static constexpr int LDS_WORDS = 2 * S + 8 + MX_LDS_PAD_WORDS;
+  static constexpr int LDS_WORDS = 2 * S + 8 + MX_DEV_LDS_PAD_WORDS;
   static constexpr int LDS_D = S + 4;          // offset of the second multiplier
 
   u32 n[L];      // modulus slice (exact W-bit limbs)

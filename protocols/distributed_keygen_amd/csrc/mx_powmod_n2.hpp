@@ -190,8 +190,8 @@ __device__ __forceinline__ u32 extract_field(const u32* words, int bitpos, int n
   return (u32)(v >> off) & (nbits >= 32 ? 0xFFFFFFFFu : ((1u << nbits) - 1u));
 }
 
-#ifdef MX_PRIVATE_PAD_WORDS
-// Developer build only (tools/build_variant.py -DMX_PRIVATE_PAD_WORDS=n, tools/concurrency_census.py): every lane of the
+#ifdef MX_DEV_PRIVATE_PAD_WORDS
+// Developer build only (tools/build_variant.py -DMX_DEV_PRIVATE_PAD_WORDS=n, tools/concurrency_census.py): every lane of the
 // one-wavefront pair kernel keeps a private array of n words in scratch memory, writes a pattern that names its
 // writer (launch tag, workgroup, lane, index) before the tape and checks it after the tape.  A word that changed while
 // the wavefront ran was overwritten by somebody else: the fault is counted and the first few are recorded, so that the
@@ -300,12 +300,12 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
     }
   }
 
-#ifdef MX_PRIVATE_PAD_WORDS
-  volatile u32 pad[MX_PRIVATE_PAD_WORDS];
+#ifdef MX_DEV_PRIVATE_PAD_WORDS
+  volatile u32 pad[MX_DEV_PRIVATE_PAD_WORDS];
   const u32 pad_tag = (u32)((unsigned long long)A.out >> 12) & 0xFFu;       // distinguishes the launches in flight
 #pragma unroll 1
-  for (int i = 0; i < MX_PRIVATE_PAD_WORDS; ++i)
-    pad[(i + lane) % MX_PRIVATE_PAD_WORDS] = pad_word(pad_tag, blockIdx.x, lane, (u32)((i + lane) % MX_PRIVATE_PAD_WORDS));
+  for (int i = 0; i < MX_DEV_PRIVATE_PAD_WORDS; ++i)
+    pad[(i + lane) % MX_DEV_PRIVATE_PAD_WORDS] = pad_word(pad_tag, blockIdx.x, lane, (u32)((i + lane) % MX_DEV_PRIVATE_PAD_WORDS));
 #endif
   // ---- the tape (this segment's part of it)
   u32 acc0[L], acc1[L];
@@ -350,10 +350,10 @@ __global__ void __launch_bounds__(64, (L > 9 ? 2 : 3)) powmod_n2_kernel(PowmodN2
       }
     }
   }
-#ifdef MX_PRIVATE_PAD_WORDS
+#ifdef MX_DEV_PRIVATE_PAD_WORDS
 #pragma unroll 1
-  for (int i = 0; i < MX_PRIVATE_PAD_WORDS; ++i) {
-    const u32 idx = (u32)((i + lane) % MX_PRIVATE_PAD_WORDS);
+  for (int i = 0; i < MX_DEV_PRIVATE_PAD_WORDS; ++i) {
+    const u32 idx = (u32)((i + lane) % MX_DEV_PRIVATE_PAD_WORDS);
     const u32 want = pad_word(pad_tag, blockIdx.x, lane, idx), got = pad[idx];
     if (got != want) {
       const u32 k = atomicAdd(&g_pad_faults, 1u);

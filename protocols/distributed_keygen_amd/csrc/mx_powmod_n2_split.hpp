@@ -84,11 +84,9 @@ __device__ __forceinline__ void ts_acquire_agent() {
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\tbuffer_inv sc1\n\ts_waitcnt vmcnt(0)" ::: "memory");
 }
 
-#ifndef MX_TS_MIN_WAVES          // developer builds: tools/build_variant.py <name> -DMX_TS_MIN_WAVES=2 / -DMX_TS_NO_A_FENCE
-#define MX_TS_MIN_WAVES 3
-#endif
+// (MX_DEV_TS_MIN_WAVES and the other MX_DEV_ switches below: developer builds, csrc/mx_dev.hpp)
 template <int K, int L, int W, bool PERSISTENT, bool FRIENDLY = (L == 3)>
-__global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTENT ? MX_TS_MIN_WAVES : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
+__global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTENT ? MX_DEV_TS_MIN_WAVES : 3)) powmod_n2_split_kernel(PowmodN2Args A) {
   using M_t = Mont<K, L, W, true, false>;          // wavefront-level ordering of the group scratch
   constexpr int S = M_t::S;
   constexpr int GROUP_WORDS = M_t::LDS_WORDS;
@@ -200,7 +198,7 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
     i64 slot, nlanes;
     int first, last, pos_begin, pos_end;
     u32 g = 0, sg = 0;
-#ifdef MX_TS_TRACE
+#ifdef MX_DEV_TS_TRACE
     u64 trace_t0 = 0;
 #endif
     if constexpr (!PERSISTENT) {
@@ -259,7 +257,7 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
       }
       if (u >= groups * nseg) break;
       g = u % groups; sg = u / groups;
-#ifdef MX_TS_TRACE          // developer builds (tools/ts_trace.py): when and where every unit ran, behind the queues
+#ifdef MX_DEV_TS_TRACE          // developer builds (tools/ts_trace.py): when and where every unit ran, behind the queues
       trace_t0 = __builtin_amdgcn_s_memrealtime();
 #endif
       // what the pair that pushed this unit stored (slots, accumulator) before its release of the entry
@@ -467,13 +465,13 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
       // workgroup-scope LDS release that neither waits for A's global stores (carry slot, table slots) nor writes
       // them back from this XCD's L2 — so A releases them at agent scope itself, before the token that lets B push.
       if (half == 0) {
-#ifndef MX_TS_NO_A_FENCE
+#ifndef MX_DEV_TS_NO_A_FENCE
         if (!last) ts_release_agent();
 #endif
         send_token();
       } else {
         receive_token();
-#ifdef MX_TS_TRACE
+#ifdef MX_DEV_TS_TRACE
         if (lane == 0) {
           u32* tr = q_ring + (size_t)groups * (N2_TS_LEVELS - 1) + ((size_t)sg * groups + g) * 4;
           const u64 t1 = __builtin_amdgcn_s_memrealtime();
@@ -484,12 +482,12 @@ __global__ void __launch_bounds__(64 * 2 * N2_SPLIT_PAIRS, (L > 9 ? 2 : PERSISTE
 #endif
         if (!last) {
           // (sg + 1 <= nseg - 1 < N2_TS_LEVELS)
-#ifndef MX_TS_COMPILER_RELEASE          // developer builds (tools/ts_handover_check.py): the sequence that lost groups
+#ifndef MX_DEV_TS_COMPILER_RELEASE          // developer builds (tools/ts_handover_check.py): the sequence that lost groups
           ts_release_agent();                                  // B's own stores; A released its own before the token
 #endif
           if (lane == 0) {
             const u32 t = __hip_atomic_fetch_add(q_tail + (sg + 1u), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifndef MX_TS_COMPILER_RELEASE
+#ifndef MX_DEV_TS_COMPILER_RELEASE
             __hip_atomic_store(q_ring + (size_t)sg * groups + t, g + 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #else
             __hip_atomic_store(q_ring + (size_t)sg * groups + t, g + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);

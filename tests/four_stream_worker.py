@@ -4,14 +4,18 @@ experimental kernel returned wrong rows while every single-stream test passed (D
 tests/test_gpu_stress.py (never imported by pytest): the number of HIP hardware queues can only be chosen before the
 runtime initialises, so this process calls configure_hw_queues(16) before anything touches the GPU.
 
-    four_stream_worker.py <what> <rows> <streams>
+    four_stream_worker.py <what>:<rows>[,<what>:<rows>...] <streams>
+
+(several legs in ONE child process: every leg used to be a process of its own, each paying the interpreter, the runtime
+and the page-in of torch again — VERDICT r05 "Next round" 1)
 
 what = "nsquare": powmod_nsquare at key_length 2048 with a full-length exponent in every launch shape (one- and
 two-wavefront groups, 3 / 9 / 18 limbs per lane, time-sliced), 4 x 10 000 rows = 4 x 625 wavefronts of the 18-limb shape
 on 1024 SIMDs; "biprime": biprime_v_t (Jacobi filter, selection, generic fixed-window modexps in every lane geometry incl. the
 bipartite latency form) at key_length 2048;
 "jacobi8192": the 257-word Jacobi instance; "k4096": the K = 16 friendly and time-sliced shapes at key_length 4096.
-Every row of every stream is compared with CPython pow() / the oracle computed on the host cores.  Prints "ok <what>"."""
+Every row of every stream is compared with pow() computed on the host cores (tests/hostpow.py: libgmp's mpz_powm, itself
+checked against CPython pow in every worker process) / the oracle.  Prints "ok <what> rows=<rows> ..." per leg."""
 import multiprocessing as mp
 import random
 import sys
@@ -33,9 +37,13 @@ def _jacobi(args):
 
 
 def main() -> None:
-    what, rows, nstreams = sys.argv[1], int(sys.argv[2]), int(sys.argv[3])
+    legs = [(w, int(r)) for w, r in (leg.split(":") for leg in sys.argv[1].split(","))]
+    nstreams = int(sys.argv[2])
+    import time
+
     import torch
 
+    import hostpow
     from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
     eng = Engine(0)
@@ -54,32 +62,34 @@ def main() -> None:
                 bad = (out != want_t).reshape(out.shape[0], -1).any(dim=1).nonzero().flatten().tolist()
                 assert not bad, (label, rep, k, len(bad), bad[:8])
 
-    if what in ("nsquare", "k4096"):
+    def leg_nsquare(what, rows):
         key_length = 2048 if what == "nsquare" else 4096
         key = synthetic.make_key(key_length, 3, 1)
         own = next(i for i in (1, 2, 3) if key.exponent(i) > 0)
         exp, n, n2 = key.exponent(own), key.n, key.n_square
         cts = synthetic.random_ciphertexts(key, rows, seed=23)
-        want = pool.starmap(pow, [(c, exp, n2) for c in cts], chunksize=8)
+        want = hostpow.powmod_many([(c, exp, n2) for c in cts], pool=pool)
         limbs2 = L.limbs_for(n2)
         c_t, want_t = eng.to_device(L.pack(cts, limbs2)), eng.to_device(L.pack(want, limbs2))
         shapes = (((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (18, 2, 2), (3, 2, 0)) if what == "nsquare" else
                   ((18, 1, 0), (9, 2, 0), (9, 2, 2), (18, 2, 0), (18, 2, 2)))
-        for lpl, wpg, sliced in shapes:
-            eng.set_limbs_per_lane(lpl)
-            eng.set_wavefronts_per_group(wpg)
-            eng.debug_knob("n2_timeslice", sliced)
-            in_flight(lambda: eng.powmod_nsquare_t(c_t, n, exp), want_t, (what, lpl, wpg, sliced))
-        eng.debug_knob("n2_timeslice", 0)
-    elif what in ("biprime", "jacobi8192"):
-        from oracle import oracle
+        try:
+            for lpl, wpg, sliced in shapes:
+                eng.set_limbs_per_lane(lpl)
+                eng.set_wavefronts_per_group(wpg)
+                eng.debug_knob("n2_timeslice", sliced)
+                in_flight(lambda: eng.powmod_nsquare_t(c_t, n, exp), want_t, (what, lpl, wpg, sliced))
+        finally:
+            eng.debug_knob("n2_timeslice", 0)
+            eng.set_limbs_per_lane(0)
+            eng.set_wavefronts_per_group(0)
 
+    def leg_biprime(what, rows):
         key_length = 2048 if what == "biprime" else 8192
         rng = random.Random(77)
         half = key_length // 2
-        cands = rows
         mods = []
-        while len(mods) < cands:
+        while len(mods) < rows:
             p, q = synthetic.candidate_shares(rng, 3, half)
             m = sum(p) * sum(q)
             if m % 2:
@@ -93,27 +103,38 @@ def main() -> None:
         if what == "jacobi8192":
             want_t = torch.tensor(sym, dtype=torch.int8, device=eng.device)
             in_flight(lambda: eng.jacobi_t(g_t, mods_op, gens), want_t, what)
-        else:
-            exps = [rng.getrandbits(m.bit_length() - 2) for m in mods]
-            exps_op = (eng.to_device(L.pack(exps, L.limbs_for_bits(max(e.bit_length() for e in exps)))), max(e.bit_length() for e in exps))
-            keep = 40
-            jobs, counts = [], []
-            for c, (row, m, e) in enumerate(zip(g, mods, exps)):
-                sel = [x for x, s in zip(row, sym[c * gens:(c + 1) * gens]) if s == 1][:keep]
-                counts.append(len(sel))
-                jobs.extend((x, e, m) for x in sel)
-                jobs.extend((0, e, m) for _ in range(keep - len(sel)))          # unselected rows: modexp of a zero row
-            want = pool.starmap(pow, jobs, chunksize=16)
-            want_t = eng.to_device(L.pack(want, limbs))
+            return
+        exps = [rng.getrandbits(m.bit_length() - 2) for m in mods]
+        exps_op = (eng.to_device(L.pack(exps, L.limbs_for_bits(max(e.bit_length() for e in exps)))), max(e.bit_length() for e in exps))
+        keep = 40
+        jobs, counts = [], []
+        for c, (row, m, e) in enumerate(zip(g, mods, exps)):
+            sel = [x for x, s in zip(row, sym[c * gens:(c + 1) * gens]) if s == 1][:keep]
+            counts.append(len(sel))
+            jobs.extend((x, e, m) for x in sel)
+            jobs.extend((0, e, m) for _ in range(keep - len(sel)))          # unselected rows: modexp of a zero row
+        want = hostpow.powmod_many(jobs, pool=pool, chunksize=16)
+        want_t = eng.to_device(L.pack(want, limbs))
+        try:
             for lpl in (9, 18, 3, 6):       # narrow, wide, and the latency instances on one and on two wavefronts (bipartite)
                 eng.set_limbs_per_lane(lpl)
                 in_flight(lambda: eng.biprime_v_t(g_t, mods_op, exps_op, gens, keep)[0], want_t, (what, lpl))
             cnt = eng.biprime_v_t(g_t, mods_op, exps_op, gens, keep)[1].cpu().tolist()
-            assert cnt == counts
-    else:
-        raise SystemExit(f"unknown test {what}")
+        finally:
+            eng.set_limbs_per_lane(0)
+        assert cnt == counts
+
+    for what, rows in legs:
+        t0 = time.time()
+        if what in ("nsquare", "k4096"):
+            leg_nsquare(what, rows)
+        elif what in ("biprime", "jacobi8192"):
+            leg_biprime(what, rows)
+        else:
+            raise SystemExit(f"unknown test {what}")
+        print(f"ok {what} rows={rows} streams={nstreams} queues_configured_in_time={IN_TIME} seconds={time.time() - t0:.1f} host_pow={hostpow.engine_name()}",
+              flush=True)
     pool.close()
-    print(f"ok {what} rows={rows} streams={nstreams} queues_configured_in_time={IN_TIME}")
 
 
 if __name__ == "__main__":

@@ -52,12 +52,11 @@ def test_c3_10k_ciphertexts_roundtrip_key2048(eng):
     partials, got, ok = _decrypt_all(eng, key, cts)
     assert all(ok) and got == msgs                                     # decrypt(encrypt(m)) == m, all 10 000
     # one party's partial decryptions, every 4th ciphertext, bit-exact vs pow() on all host cores
-    import multiprocessing as mp
+    import hostpow          # tests/hostpow.py: mpz_powm on the host cores, checked against CPython pow per process
 
     i_pos = next(i for i in (1, 2, 3) if key.exponent(i) >= 0)
     idx = list(range(0, batch, 4))
-    with mp.Pool() as pool:
-        want = pool.starmap(pow, [(cts[k], key.exponent(i_pos), n2) for k in idx], chunksize=8)
+    want = hostpow.powmod_many([(cts[k], key.exponent(i_pos), n2) for k in idx])
     assert [partials[i_pos - 1][k] for k in idx] == want
     # the N-adic pair kernel (mx_powmod_nsquare, what partial_decrypt_batch and bench.py launch), in
     # both lane geometries, on all 10 000: identical to the generic-modulus kernel checked above

@@ -121,45 +121,54 @@ def test_nsquare_randomized_differential_over_launch_shapes(eng):
         eng.set_wavefronts_per_group(0)
 
 
-def _worker(what: str, rows: int, streams: int = 4, timeout: int = 900) -> None:
-    """tests/four_stream_worker.py as a child process (it configures 16 HIP hardware queues before its first GPU call;
-    this pytest process runs with the runtime's default of 4)."""
+LEGS = {"nsquare": 10000, "k4096": 2500, "biprime": 600, "jacobi8192": 24}
+
+
+@pytest.fixture(scope="module")
+def four_stream_legs():
+    """tests/four_stream_worker.py as ONE child process for all four legs (it configures 16 HIP hardware queues before
+    its first GPU call; the number can only be chosen before the runtime initialises).  Returns its output; every test
+    below asserts its own leg's line, so a failing leg fails its own test (and those behind it)."""
     import subprocess
     import sys
     from pathlib import Path
 
     worker = Path(__file__).resolve().parent / "four_stream_worker.py"
-    r = subprocess.run([sys.executable, str(worker), what, str(rows), str(streams)], capture_output=True, text=True, timeout=timeout)
-    assert r.returncode == 0 and f"ok {what} rows={rows} streams={streams}" in r.stdout, f"rc={r.returncode}\n{r.stdout[-800:]}\n{r.stderr[-3000:]}"
-    assert "queues_configured_in_time=True" in r.stdout
+    spec = ",".join(f"{k}:{v}" for k, v in LEGS.items())
+    r = subprocess.run([sys.executable, str(worker), spec, "4"], capture_output=True, text=True, timeout=1500)
+    return r
 
 
-@pytest.mark.timeout(1200)
-def test_nsquare_four_streams_at_once_every_launch_shape():
+def _leg_ok(r, what: str) -> None:
+    line = next((l for l in r.stdout.splitlines() if l.startswith(f"ok {what} rows={LEGS[what]} streams=4")), None)
+    assert line is not None, f"rc={r.returncode}\n{r.stdout[-800:]}\n{r.stderr[-3000:]}"
+    assert "queues_configured_in_time=True" in line
+
+
+@pytest.mark.timeout(1800)
+def test_nsquare_four_streams_at_once_every_launch_shape(four_stream_legs):
     """Four launches of 10 000 rows in flight on four streams (4 x 625 wavefronts of the 18-limb shape: the machine is
     oversubscribed as in bench.py's steady state), every launch shape incl. the time-sliced form, 16 hardware queues:
-    every row of every stream bit for bit against CPython pow at key_length 2048 with a full-length exponent.
+    every row of every stream bit for bit against pow() on the host cores at key_length 2048 with a full-length exponent.
     Single-stream parity says nothing about what launches share while they overlap — an experimental kernel of round 3
     passed every single-stream test at full size and returned wrong rows here."""
-    _worker("nsquare", 10000)
+    _leg_ok(four_stream_legs, "nsquare")
 
 
-@pytest.mark.timeout(1200)
-def test_four_streams_at_once_key4096_shapes():
+def test_four_streams_at_once_key4096_shapes(four_stream_legs):
     """The same at key_length 4096 for the shapes whose instances differ from key_length 2048's: groups of 16 lanes on
     the friendly modulus, plain and time-sliced, and the wide kernels at K = 8."""
-    _worker("k4096", 2500)
+    _leg_ok(four_stream_legs, "k4096")
 
 
-@pytest.mark.timeout(1200)
-def test_four_streams_at_once_biprime_v():
+def test_four_streams_at_once_biprime_v(four_stream_legs):
     """biprime_v_t (Jacobi filter -> selection -> generic fixed-window modexps: narrow, wide, latency and bipartite-latency
     instances) from four streams at once: 4 x 600 candidates x 40 modexps at key_length 2048."""
-    _worker("biprime", 600)
+    _leg_ok(four_stream_legs, "biprime")
 
 
-@pytest.mark.timeout(1200)
-def test_four_streams_at_once_jacobi_257_words():
+def test_four_streams_at_once_jacobi_257_words(four_stream_legs):
     """The 257-word Jacobi instance (key_length 8192: the one kernel of the library whose operands do not fit the
     register file) from four streams at once."""
-    _worker("jacobi8192", 24)
+    _leg_ok(four_stream_legs, "jacobi8192")
+    assert four_stream_legs.returncode == 0, four_stream_legs.stderr[-3000:]

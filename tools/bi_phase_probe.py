@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Where the cycles of a product go in the bipartite form of the generic kernel: one launch of 10 candidates x 40 modexps
-per key length on a library built with -DMX_BI_TRACE (tools/build_variant.py bi_trace -DMX_BI_TRACE; MX_LIBRARY=...): the
+per key length on a library built with -DMX_DEV_BI_TRACE (tools/build_variant.py bi_trace -DMX_DEV_BI_TRACE; MX_LIBRARY=...): the
 launcher prints the shader-clock cycles pair 0 spent per phase, summed over all products of the exponentiation.
 usage: bi_phase_probe.py [key_length ...]"""
 import os

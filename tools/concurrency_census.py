@@ -4,7 +4,7 @@
 Round 3 had a build that was bit-exact on one stream and returned wrong rows with four launches in flight
 (DESIGN.md §9 1b).  This script reproduces the situation for any build of the library (MX_LIBRARY=<variant>.so,
 tools/build_variant.py) and says WHAT is wrong: how many rows per stream, whether whole wavefronts or single rows,
-which workgroups (XCD = workgroup index mod 8), and — for builds with -DMX_PRIVATE_PAD_WORDS=n — whether a wavefront's
+which workgroups (XCD = workgroup index mod 8), and — for builds with -DMX_DEV_PRIVATE_PAD_WORDS=n — whether a wavefront's
 private scratch was overwritten while it ran, and by whom (the pad pattern names its writer).
 
   python tools/concurrency_census.py [--rows 10000] [--streams 4] [--queues 16] [--segments 0] [--shape 18,1]

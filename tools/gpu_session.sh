@@ -3,7 +3,7 @@
 # Every step writes under gpurun_out/<tag>/ (merged back into the build container); the summaries that are cited are
 # copied to profiles/ by hand.  Steps (tools/README.md has the table):
 #   census        wrong-row census of overlapping launches for the shipped library and the pad variants
-#                 (build/variants/pad*.so, tools/build_variant.py padN -DMX_PRIVATE_PAD_WORDS=N), over hardware queues,
+#                 (build/variants/pad*.so, tools/build_variant.py padN -DMX_DEV_PRIVATE_PAD_WORDS=N), over hardware queues,
 #                 segments, one stream vs four, and the runtime's scratch knobs
 #   exec_half     tools/ubench/exec_half: issue cost of VALU instructions with half of EXEC disabled
 #   tests         pytest -m gpu (whole suite, log + durations)
@@ -145,7 +145,7 @@ for step in "$@"; do
     done
     ;;
   prio_ab)
-    # short kernels at raised wave priority (csrc/mx_prio.hpp) against a build without (build_variant.py noprio -DMX_AUX_WAVE_PRIO=0)
+    # short kernels at raised wave priority (csrc/mx_prio.hpp) against a build without (build_variant.py noprio -DMX_DEV_AUX_WAVE_PRIO=0)
     line() { python -c "import json,sys; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('$1', round(d['value']), d['unit'], round(d['ms_per_step'],3), 'ms/step frac', d['roofline'].get('frac'), 'kernel_ms', d['roofline'].get('kernel_ms'))"; }
     for rep in 1 2; do for lib in shipped $V/noprio.so; do
       [ $lib = shipped ] && unset MX_LIBRARY || export MX_LIBRARY=$R/$lib

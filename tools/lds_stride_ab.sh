@@ -1,8 +1,8 @@
 #!/bin/bash
 # A/B of the LDS stride between the groups of a wavefront (lever b): the shipped library (152 words
 # per 18-limb group of 4 lanes: the 16 groups' broadcast reads of a multiplier limb fall on 4 banks) against a build with
-# -DMX_LDS_PAD_WORDS=1 (153 words: 16 banks).  usage (GPU box): bash tools/lds_stride_ab.sh <outdir>
-# needs protocols/distributed_keygen_amd/build/variants/lds_pad1.so (tools/build_variant.py lds_pad1 -DMX_LDS_PAD_WORDS=1)
+# -DMX_DEV_LDS_PAD_WORDS=1 (153 words: 16 banks).  usage (GPU box): bash tools/lds_stride_ab.sh <outdir>
+# needs protocols/distributed_keygen_amd/build/variants/lds_pad1.so (tools/build_variant.py lds_pad1 -DMX_DEV_LDS_PAD_WORDS=1)
 export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 O=$R/${1:-gpurun_out/lds_ab}; mkdir -p $O

@@ -4,7 +4,8 @@
     lengths around the geometry steps), special and random moduli, per-group moduli of different — now and then VERY different — lengths, ragged groups,
     exponents 0 / 1 / all-ones / random, every pivot (developer knob) and more lanes per element than needed;
   * partial decryptions with the fixed-window tape in random launch shapes and segment counts.
-usage: soak_round5.py [seed] [seconds]"""
+usage: soak_round5.py [seed] [seconds]
+tests/test_gpu_soak_slices.py runs soak(engine, seed, rounds=...) for a few fixed seeds inside `pytest -m gpu`."""
 import multiprocessing as mp
 import os
 import random
@@ -12,24 +13,18 @@ import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from protocols.distributed_keygen_amd import configure_hw_queues
-
-configure_hw_queues(16)
 
 
-def main():
-    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
-    from protocols.distributed_keygen_amd import Engine
-
-    eng = Engine()
+def soak(eng, seed, seconds=None, rounds_limit=None, procs=16):
+    """Runs until `seconds` have passed or `rounds_limit` rounds are done (whichever is given); returns (rounds, counts).
+    Raises AssertionError on the first row that differs from CPython pow."""
     rng = random.Random(seed)
-    pool = mp.Pool(16)
+    pool = mp.Pool(procs)
     t0 = time.time()
     done = {"bipartite": 0, "fixed_window": 0}
     rounds = 0
     try:
-        while time.time() - t0 < budget:
+        while (seconds is None or time.time() - t0 < seconds) and (rounds_limit is None or rounds < rounds_limit):
             rounds += 1
             # ---- bipartite form
             bits = rng.choice([rng.randint(3, 140), rng.randint(140, 700), rng.choice([1026, 1027, 1028, 1029, 1183, 1184, 2050, 2051, 2052, 2053]),
@@ -82,10 +77,24 @@ def main():
             eng.set_wavefronts_per_group(0)
     finally:
         eng.set_fixed_window(False)
+        eng.set_segments(0)
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
         eng.debug_knob("bi_pivot", 0)
         eng.debug_knob("lat_lanes", 0)
+        pool.terminate()
+    return rounds, done
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
+    from protocols.distributed_keygen_amd import Engine, configure_hw_queues
+
+    configure_hw_queues(16)
+    t0 = time.time()
+    rounds, done = soak(Engine(), seed, seconds=budget)
     print(f"seed {seed}: {rounds} rounds in {time.time() - t0:.0f} s, all bit-exact: {done}")
-    pool.close()
 
 
 if __name__ == "__main__":

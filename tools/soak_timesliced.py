@@ -4,33 +4,32 @@ hand-over): random key lengths (every group width that has a time-sliced instanc
 and plain moduli), batches from a few groups to 1.6 x the resident pairs (ragged last groups), 1 .. 16 units per group,
 1 .. 3 workgroups per CU, exponents from a few bits to full length, one launch alone or two on two streams at once —
 every row compared with the plain one-wavefront launch of the same input, and a sample of rows with CPython pow.
-usage: soak_timesliced.py [seed] [seconds]"""
+usage: soak_timesliced.py [seed] [seconds]
+tests/test_gpu_soak_slices.py runs soak(engine, seed, launches_limit=...) for fixed seeds inside `pytest -m gpu`."""
 import os
 import random
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-from protocols.distributed_keygen_amd import configure_hw_queues
-
-configure_hw_queues(16)
 
 
-def main():
-    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 5
-    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
+def soak(eng, seed, seconds=None, launches_limit=None, max_rows=None):
+    """Runs until `seconds` have passed or `launches_limit` launches were compared; returns (launches, rows, by_shape).
+    max_rows bounds the size of one launch (the bounded slice inside the GPU suite).  AssertionError on the first
+    launch with a row that differs from the plain one-wavefront launch (itself sampled against CPython pow)."""
     import torch
 
-    from protocols.distributed_keygen_amd import Engine, limbs as L
+    from protocols.distributed_keygen_amd import limbs as L
 
-    eng = Engine()
+    budget = seconds
     rng = random.Random(seed)
     side = torch.cuda.Stream()
     t0 = time.time()
     launches = rows_checked = 0
     by_shape = {}
     try:
-        while time.time() - t0 < budget:
+        while (budget is None or time.time() - t0 < budget) and (launches_limit is None or launches < launches_limit):
             nb = rng.choice([131, 300, 515, 1027, 1030, 2051, 2053, 2075, 3075, 4099, 4160])
             lpl = rng.choice([9, 18])
             n = rng.getrandbits(nb) | (1 << (nb - 1)) | 1
@@ -45,6 +44,8 @@ def main():
             batch = max(1, int(pairs * gpw * scale) + rng.randint(-gpw, gpw))
             if nb >= 3075:
                 batch = min(batch, 3000)
+            if max_rows:
+                batch = min(batch, max_rows)
             ebits = rng.choice([40, 200, nb]) if batch * nb > 3_000_000 else rng.choice([17, 200, nb, 2 * nb + 90])
             e = rng.getrandbits(ebits) | (1 << (ebits - 1)) | 1
             bases = [0, 1, n, n2 - 1][:batch] + [rng.randrange(n2) for _ in range(max(0, batch - 4))]
@@ -75,6 +76,17 @@ def main():
             eng.debug_knob("n2_timeslice", 0)
     finally:
         eng.debug_knob("n2_timeslice", 0); eng.set_limbs_per_lane(0); eng.set_wavefronts_per_group(0)
+    return launches, rows_checked, by_shape
+
+
+def main():
+    seed = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+    budget = float(sys.argv[2]) if len(sys.argv) > 2 else 240.0
+    from protocols.distributed_keygen_amd import Engine, configure_hw_queues
+
+    configure_hw_queues(16)
+    t0 = time.time()
+    launches, rows_checked, by_shape = soak(Engine(), seed, seconds=budget)
     print(f"soak_timesliced seed {seed}: {launches} launches, {rows_checked} rows bit-identical to the plain launch in {time.time() - t0:.0f} s; "
           "launches per (limbs per lane, lanes per element, form): " + ", ".join(f"{k}: {v}" for k, v in sorted(by_shape.items())))
 

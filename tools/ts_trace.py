@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
-"""When and where every unit of a time-sliced launch ran (developer tool; needs a library built with -DMX_TS_TRACE:
-tools/build_variant.py trace -DMX_TS_TRACE, then MX_LIBRARY=.../variants/trace.so).
+"""When and where every unit of a time-sliced launch ran (developer tool; needs a library built with -DMX_DEV_TS_TRACE:
+tools/build_variant.py trace -DMX_DEV_TS_TRACE, then MX_LIBRARY=.../variants/trace.so).
 usage: ts_trace.py <batch> <limbs_per_lane 9|18> <resident per CU> <units per group> [key_length]"""
 import os
 import sys
