@@ -152,21 +152,72 @@ class Coalescer(_TickBatcher):
             self._run(combine, self._combine_groups, "combine_launches")
 
     @staticmethod
+    def _invert_own(key: Any, values: List[int]) -> Tuple[List[int], Dict[int, Exception]]:
+        """PSK:89-91 for one key's pending ciphertexts: (inverses of the invertible ones in order, {position: the
+        exception of a ciphertext that has no inverse modulo N^2}).  The reference fails exactly the decrypt() that
+        holds such a ciphertext; one device inversion of the whole batch fails as a whole (Engine.modinv_batch raises
+        for the batch), so on failure the offenders are found on the host (a gcd each, only on this path) and the rest
+        is inverted again without them."""
+        import math
+
+        try:
+            return key.engine.modinv_batch(values, key.n_square), {}
+        except ValueError as exc:
+            n2 = key.n_square
+            bad = {k: ValueError(*exc.args) for k, v in enumerate(values) if math.gcd(v % n2, n2) != 1}
+            if not bad:          # not an invertibility failure after all: it belongs to every ciphertext of this key
+                raise
+            rest = [v for k, v in enumerate(values) if k not in bad]
+            return (key.engine.modinv_batch(rest, n2) if rest else []), bad
+
+    @staticmethod
     def _partial_groups(groups) -> List[List[Any]]:
-        """One modexp batch per key; several keys side by side when the engine can (Engine.powmod_nsquare_groups)."""
-        jobs = []
-        for key, entries in groups:
+        """One modexp batch per key; several keys side by side when the engine can (Engine.powmod_nsquare_groups).
+        A failure stays with what caused it: a ciphertext without an inverse fails its own coroutine, a
+        key whose batch the engine refuses fails that key's coroutines — never the burst."""
+        results: List[Any] = [None] * len(groups)
+        jobs, owners, holes = [], [], []
+        for g, (key, entries) in enumerate(groups):
             values = [v for v, _ in entries]
-            exp = key.lagrange_exponent()
-            if exp < 0:       # PSK:89-91
-                values = key.engine.modinv_batch(values, key.n_square)
-                exp = -exp
+            try:
+                exp = key.lagrange_exponent()
+                bad: Dict[int, Exception] = {}
+                if exp < 0:       # PSK:89-91
+                    values, bad = Coalescer._invert_own(key, values)
+                    exp = -exp
+            except Exception as exc:
+                results[g] = [exc] * len(entries)
+                continue
             jobs.append((values, exp, key.n))
-        engine = groups[0][0].engine
-        side_by_side = getattr(engine, "powmod_nsquare_groups", None)
-        if side_by_side is not None and len(jobs) > 1 and all(key.engine is engine for key, _ in groups):
-            return side_by_side(jobs)
-        return [key.engine.powmod_nsquare_batch(v, e, n) for (key, _), (v, e, n) in zip(groups, jobs)]
+            owners.append(g)
+            holes.append(bad)
+
+        def scatter(g: int, outs: List[Any], bad: Dict[int, Exception]) -> List[Any]:
+            it = iter(outs)
+            return [bad[k] if k in bad else next(it) for k in range(len(groups[g][1]))]
+
+        live = [j for j, (values, _, _) in enumerate(jobs) if values]
+        for j in range(len(jobs)):
+            if j not in live:
+                results[owners[j]] = scatter(owners[j], [], holes[j])
+        if live:
+            engine = groups[owners[live[0]]][0].engine
+            side_by_side = getattr(engine, "powmod_nsquare_groups", None)
+            outs = None
+            if side_by_side is not None and len(live) > 1 and all(groups[owners[j]][0].engine is engine for j in live):
+                try:
+                    outs = side_by_side([jobs[j] for j in live])
+                except Exception:
+                    outs = None          # one key's batch was refused: run them one by one, the failure stays with its key
+            for pos, j in enumerate(live):
+                g = owners[j]
+                key = groups[g][0]
+                try:
+                    own = outs[pos] if outs is not None else key.engine.powmod_nsquare_batch(*jobs[j])
+                    results[g] = scatter(g, own, holes[j])
+                except Exception as exc:
+                    results[g] = [exc] * len(groups[g][1])
+        return results
 
     @staticmethod
     def _combine_groups(groups) -> List[List[Any]]:

@@ -175,6 +175,18 @@ class Engine:
             if plan.ready.query():
                 plan.ready = None
 
+    def _cache_plan(self, cache: "OrderedDict[Any, _Plan]", key: Any, plan: _Plan) -> _Plan:
+        """Keeps `plan`, dropping the least recently used ones beyond MAX_PLANS.  Dropping a plan only drops this
+        engine's reference to its device block; the memory goes back to torch's caching allocator, which hands a block
+        out again only behind the work of (a) the stream it was allocated on — the stream that prepared the plan — and
+        (b) every stream named to it with record_stream.  _use_plan names every OTHER stream before that stream's launch
+        reads the plan, so a launch still in flight on any stream when a 17th key evicts its plan keeps reading intact
+        memory (tests/test_host_logic.py: the eviction test on a stand-in allocator)."""
+        cache[key] = plan
+        while len(cache) > self.MAX_PLANS:
+            cache.popitem(last=False)
+        return plan
+
     def to_device(self, rows: np.ndarray):
         """uint32 rows -> int32 device tensor (bit pattern preserved)."""
         t = self.torch.from_numpy(np.ascontiguousarray(rows, dtype="<u4").view(np.int32))
@@ -511,10 +523,7 @@ class Engine:
             ready = self.torch.cuda.Event()
             ready.record(self.torch.cuda.current_stream(self.device))
         plan = _Plan(desc, block, self._stream_ptr(), ready)
-        self._n2_plans[key] = plan
-        while len(self._n2_plans) > self.MAX_PLANS:
-            self._n2_plans.popitem(last=False)
-        return plan
+        return self._cache_plan(self._n2_plans, key, plan)
 
     @_int_args
     def combine_plan(self, n: int, theta_inv: int, limbs2: int) -> _Plan:
@@ -543,10 +552,7 @@ class Engine:
             ready = self.torch.cuda.Event()
             ready.record(self.torch.cuda.current_stream(self.device))
         plan = _Plan(desc, block, self._stream_ptr(), ready)
-        self._combine_plans[key] = plan
-        while len(self._combine_plans) > self.MAX_PLANS:
-            self._combine_plans.popitem(last=False)
-        return plan
+        return self._cache_plan(self._combine_plans, key, plan)
 
     @_int_args
     def powmod_nsquare_t(self, bases_t, n: int, exp: int, out_t=None, segments: Optional[int] = None,
@@ -772,11 +778,21 @@ class Engine:
 
                 if not getattr(self, "_capped_warned", False):
                     self._capped_warned = True
+                    # what the PROBE measured, and only then a guess at why: with enough hardware queues configured the
+                    # shortfall is the runtime's own stream-to-queue mapping (streams of the process created earlier hold
+                    # queues too), not something the caller did
+                    import os
+
+                    queues = os.environ.get("GPU_MAX_HW_QUEUES")
+                    if queues is None or not queues.isdigit() or int(queues) < 8:
+                        why = (f"GPU_MAX_HW_QUEUES is {queues or 'unset (runtime default: 4)'}; call protocols.distributed_keygen_amd."
+                               "configure_hw_queues() before the first GPU call, or set GPU_MAX_HW_QUEUES=16")
+                    else:
+                        why = (f"GPU_MAX_HW_QUEUES={queues} was in effect, so this is the runtime's mapping of this process's streams "
+                               "onto its hardware queues, not a missing setting; the engine probes again later")
                     warnings.warn(
-                        f"protocols.distributed_keygen_amd: only {len(ok)} of {len(cands)} HIP streams run concurrently in this "
-                        "process (the HIP runtime was initialised with few hardware queues; call "
-                        "protocols.distributed_keygen_amd.configure_hw_queues() before the first GPU call, or set "
-                        f"GPU_MAX_HW_QUEUES=16): long batches are cut into {max(1, len(ok))} chunks instead of {wanted}",
+                        f"protocols.distributed_keygen_amd: the concurrency probe measured {len(ok)} of {len(cands)} side streams "
+                        f"running side by side ({why}): long batches are cut into {max(1, len(ok))} chunks instead of {wanted}",
                         RuntimeWarning, stacklevel=3)
                 self._side_streams_capped = True
             self._side_streams = ok

@@ -38,6 +38,7 @@ from .shared_key import GpuPaillierSharedKey
 DEFAULT_PACKAGE = "tno.mpc.protocols.distributed_keygen"
 _saved: Dict[Any, Dict[str, Any]] = {}
 _saved_names: Dict[Any, Dict[str, Any]] = {}      # module -> {name: original leaf function}
+_warned_late_queues = False                        # the "too late for hardware queues" warning is given once per process
 _coalescers: Dict[str, Coalescer] = {}            # package -> the micro-batcher of its installed patch
 _round_coalescers: Dict[str, RoundCoalescer] = {}  # package -> the batcher of the keygen rounds of co-located parties
 
@@ -97,11 +98,16 @@ def _gpu_key(key: Any, engine: Any) -> GpuPaillierSharedKey:
 
 
 def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = True, leaf: bool = False,
-            linger: float = 0.0, hw_queues: int = 16) -> None:
+            linger: float = 0.0, hw_queues: Optional[int] = None) -> None:
     """``hw_queues``: the engine keeps several launches in flight (chunks of long sequences, the batches of co-located
     parties), which needs more HIP hardware queues than the runtime's default of 4; they can only be chosen before
-    the process first touches the GPU, so install() asks for them here (``configure_hw_queues``; 0 = leave alone) and
-    warns when it is too late — the engine then measures what it has and uses fewer streams.
+    the process first touches the GPU.  Default (None): when install() is left to create the engine itself
+    (``engine=None`` — the engine is then made on first use, so the runtime is not up yet) it asks for 16 through
+    ``configure_hw_queues`` — which sets GPU_MAX_HW_QUEUES in os.environ unless the user set it, a process-wide setting
+    that child processes inherit; when the caller passes an engine, the runtime is initialised already and install()
+    leaves the environment alone (call ``configure_hw_queues()`` yourself before creating the engine — INTEGRATION.md
+    "call order").  An explicit number asks for that many and warns — once per process — when it is too late; 0 never
+    touches the environment.  Either way the engine measures what it has and uses no more streams than run side by side.
 
     ``linger``: seconds a burst of single ``decrypt()`` calls may wait for stragglers before its launch (0 = until
     the event loop has run every coroutine that was runnable, which is what ``asyncio.gather`` over an in-process
@@ -125,13 +131,18 @@ def install(engine: Any = None, package: str = DEFAULT_PACKAGE, scalars: bool = 
     PSK = psk_mod.PaillierSharedKey
     DP = dk_mod.DistributedPaillier
     check_limits(engine)
+    if hw_queues is None:
+        hw_queues = 16 if engine is None else 0
     if hw_queues:
         import os
 
         from . import configure_hw_queues
 
-        if not configure_hw_queues(hw_queues) and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < hw_queues:
+        global _warned_late_queues
+        if not configure_hw_queues(hw_queues) and int(os.environ.get("GPU_MAX_HW_QUEUES", "0") or 0) < hw_queues and not _warned_late_queues:
             import warnings
+
+            _warned_late_queues = True
 
             warnings.warn(
                 "protocols.distributed_keygen_amd.patch.install(): the HIP runtime of this process was initialised before "

@@ -664,3 +664,69 @@ def test_latency_geometry_is_passed_to_generic_launches_only_where_it_exists():
     for lpl in (0, 9, 18):
         e._lpl = lpl
         assert e._lpl_generic(8200) == lpl and e._lpl_generic(1029) == lpl
+
+
+def test_an_evicted_plan_stays_readable_for_launches_in_flight_on_every_stream():
+    """VERDICT r05 "weak" 10: Engine.MAX_PLANS keys are kept; the 17th evicts the least recently used plan, whose device
+    block goes back to torch's caching allocator.  The allocator reuses a block only behind (a) the stream it was
+    allocated on and (b) every stream named with record_stream — so the engine must have named every OTHER stream whose
+    launch reads the plan BEFORE that launch, whatever happens to the cache afterwards.  Engine plumbing on a stand-in for
+    torch's streams / allocator (no GPU): a plan prepared on stream A and used on B and C is evicted by 16 more keys
+    while B's and C's launches are "pending"; the block's wait-set must contain all three streams."""
+    from collections import OrderedDict
+
+    from protocols.distributed_keygen_amd.engine import Engine, _Plan
+
+    class Stream:
+        def __init__(self, ptr):
+            self.cuda_stream = ptr
+
+        def wait_event(self, ev):
+            ev.waited_by.append(self.cuda_stream)
+
+    class Event:
+        def __init__(self):
+            self.waited_by = []
+
+        def query(self):
+            return False          # the uploads are "still running"
+
+    class Block:
+        """What the caching allocator knows about a block: it may be reused behind these streams' work."""
+
+        def __init__(self, alloc_stream):
+            self.wait_set = {alloc_stream}
+
+        def record_stream(self, stream):
+            self.wait_set.add(stream.cuda_stream)
+
+    class Cuda:
+        current = Stream(0xA)
+
+        @staticmethod
+        def current_stream(device=None):
+            return Cuda.current
+
+    class Torch:
+        cuda = Cuda
+
+    eng = Engine.__new__(Engine)
+    eng.torch, eng.device = Torch, None
+    cache = OrderedDict()
+    first = _Plan(desc=object(), block=Block(0xA), stream_ptr=0xA, ready=Event())
+    eng._cache_plan(cache, "key0", first)
+    for ptr in (0xB, 0xC):                       # launches on two other streams read the plan ...
+        Cuda.current = Stream(ptr)
+        eng._use_plan(first)
+    assert first.ready.waited_by == [0xB, 0xC]   # ... behind its uploads
+    Cuda.current = Stream(0xA)
+    eng._use_plan(first)                         # the preparing stream itself needs neither
+    assert first.ready.waited_by == [0xB, 0xC]
+    for k in range(1, Engine.MAX_PLANS + 1):     # ... and stay "pending" while 16 more keys arrive
+        eng._cache_plan(cache, f"key{k}", _Plan(object(), Block(0xA), 0xA, None))
+    assert "key0" not in cache and len(cache) == Engine.MAX_PLANS
+    assert first.block.wait_set == {0xA, 0xB, 0xC}          # the allocator will not hand the block out before all three are done
+    # least RECENTLY USED goes first: a plan that was just looked up again survives the next key
+    cache.move_to_end("key1")                    # what nsquare_plan / combine_plan do on a hit
+    eng._cache_plan(cache, "key17", _Plan(object(), Block(0xA), 0xA, None))
+    assert "key1" in cache and "key2" not in cache

@@ -187,3 +187,21 @@ def test_golden_partial_decryptions_agree_with_gmpy2(golden_decrypt_synth, golde
     assert r.returncode == 0, r.stderr
     bad, total = map(int, r.stdout.split())
     assert bad == 0 and total == len(jobs) and total > 50
+
+
+def test_precomputed_field_primes_of_the_gpu_suite_are_prime():
+    """tests/test_gpu_ops.py takes its Shamir-field primes from a table (searching nextprime(2^4102) cost the GPU suite
+    81 s): the small ones are sympy's nextprime exactly, the long ones prime (all the field kernels need)."""
+    import importlib.util
+    from pathlib import Path
+
+    src = (Path(__file__).resolve().parent / "test_gpu_ops.py").read_text()
+    line = next(l for l in src.splitlines() if l.startswith("NEXT_PRIME_OFFSET"))
+    table = eval(line.split("=", 1)[1].split("#")[0])
+    assert set(table) == {61, 133, 1030, 2054, 4102}
+    for bits, off in table.items():
+        p = (1 << bits) + off
+        if bits <= 1030:
+            assert p == sympy.nextprime(1 << bits), bits
+        else:
+            assert sympy.isprime(p), bits

@@ -566,3 +566,73 @@ def test_coalescer_batches_only_what_is_pending_together():
         return await asyncio.gather(*[late(c, 0.002 * k) for k, c in enumerate(cts[:5])])
 
     assert asyncio.run(trickle()) == want[:5] and slow.stats["partial_launches"] == 1
+
+
+def test_coalesced_failures_stay_with_the_coroutine_or_key_that_caused_them():
+    """ADVICE r05 (medium).  PSK:89-91: under a negative Lagrange exponent the ciphertext is inverted modulo N^2 first, and
+    in the reference only the decrypt() that holds a ciphertext without an inverse fails.  One device inversion per batch
+    fails as a whole, so the coalescer must find the offender and give ValueError to ITS coroutine alone — not to the other
+    ciphertexts of that key, not to the other keys of the burst; and a key whose batch the engine refuses must not take
+    the co-located keys' batches with it."""
+    from fake_engine import FakeEngine
+    from protocols.distributed_keygen_amd import synthetic
+    from protocols.distributed_keygen_amd.coalesce import Coalescer
+    from protocols.distributed_keygen_amd.shared_key import GpuPaillierSharedKey, PlainCiphertext, ShareView
+
+    key = synthetic.make_key(64, 3, 1, kappa=20)
+    neg = next(i for i in (1, 2, 3) if key.exponent(i) < 0)
+    pos = next(i for i in (1, 2, 3) if key.exponent(i) > 0)
+    eng = FakeEngine()
+    mk = lambda i: GpuPaillierSharedKey(key.n, 1, i, ShareView({i: key.shares[i]}, key.degree, key.n_fac), key.theta, engine=eng)
+    k_neg, k_pos = mk(neg), mk(pos)
+    rng = random.Random(5)
+    good = [synthetic.encrypt(key, m, rng) for m in (7, 8, 9)]
+    ct = lambda v: PlainCiphertext(v, key.n)
+    co = Coalescer(eng)
+
+    async def burst():
+        return await asyncio.gather(co.partial_decrypt(k_neg, ct(good[0])), co.partial_decrypt(k_neg, ct(0)),
+                                    co.partial_decrypt(k_neg, ct(key.p * 5)), co.partial_decrypt(k_neg, ct(good[1])),
+                                    co.partial_decrypt(k_pos, ct(good[2])), co.partial_decrypt(k_pos, ct(0)), return_exceptions=True)
+
+    out = asyncio.run(burst())
+    n2 = key.n_square
+    assert out[0] == pow(pow(good[0], -1, n2), -key.exponent(neg), n2) == k_neg.partial_decrypt(ct(good[0]))
+    assert isinstance(out[1], ValueError) and isinstance(out[2], ValueError) and out[1] is not out[2]
+    assert out[3] == k_neg.partial_decrypt(ct(good[1]))
+    assert out[4] == k_pos.partial_decrypt(ct(good[2])) and out[5] == 0          # no inversion under a positive exponent: 0^e = 0
+    with pytest.raises(ValueError):
+        k_neg.partial_decrypt(ct(0))                                             # the un-coalesced call fails the same way
+    # every ciphertext of the key without an inverse: no modexp launch for that key, the other key unaffected
+    async def all_bad():
+        return await asyncio.gather(co.partial_decrypt(k_neg, ct(0)), co.partial_decrypt(k_pos, ct(good[0])), return_exceptions=True)
+
+    bad_out = asyncio.run(all_bad())
+    assert isinstance(bad_out[0], ValueError) and bad_out[1] == k_pos.partial_decrypt(ct(good[0]))
+
+    # an engine that runs keys side by side and refuses ONE key's batch: only that key's coroutines see the failure
+    class SideBySide(FakeEngine):
+        def powmod_nsquare_groups(self, jobs):
+            if any(n == other.n for _, _, n in jobs):
+                raise ValueError("rows narrower than N^2")
+            return [self.powmod_nsquare_batch(v, e, n) for v, e, n in jobs]
+
+        def powmod_nsquare_batch(self, bases, exp, n, keep_rows=False):
+            if n == other.n:
+                raise ValueError("rows narrower than N^2")
+            return super().powmod_nsquare_batch(bases, exp, n, keep_rows)
+
+    other = synthetic.make_key(64, 3, 1, kappa=20, seed=99)
+    eng2 = SideBySide()
+    a = GpuPaillierSharedKey(key.n, 1, pos, ShareView({pos: key.shares[pos]}, key.degree, key.n_fac), key.theta, engine=eng2)
+    opos = next(i for i in (1, 2, 3) if other.exponent(i) > 0)
+    b = GpuPaillierSharedKey(other.n, 1, opos, ShareView({opos: other.shares[opos]}, other.degree, other.n_fac), other.theta, engine=eng2)
+    co2 = Coalescer(eng2)
+
+    async def two_keys():
+        return await asyncio.gather(co2.partial_decrypt(a, ct(good[0])), co2.partial_decrypt(b, PlainCiphertext(12345, other.n)),
+                                    co2.partial_decrypt(a, ct(good[1])), return_exceptions=True)
+
+    r = asyncio.run(two_keys())
+    assert r[0] == pow(good[0], key.exponent(pos), n2) and r[2] == pow(good[1], key.exponent(pos), n2)
+    assert isinstance(r[1], ValueError) and "narrower" in str(r[1])
