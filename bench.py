@@ -64,7 +64,7 @@ SIMDS, NOMINAL_HZ = 1024, 2.4e9
 MAC_CYCLES, OTHER_CYCLES = 4.19, 2.28       # v_mad_u64_u32 (accumulator form) / plain VALU, >= 2 wavefronts per SIMD
 GUIDE_VECTOR_PEAK = SIMDS * NOMINAL_HZ / 2  # wave-instructions per second if every instruction issued in 2 cycles
 MAC_ISSUE_PEAK = SIMDS * NOMINAL_HZ / MAC_CYCLES
-INSTR_MODEL = ROOT / "profiles" / "r05_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits) + digest of the kernel sources
+INSTR_MODEL = ROOT / "profiles" / "r06_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits) + digest of the kernel sources
 HBM_MEASURED = ROOT / "profiles" / "r05_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
 
 
@@ -171,11 +171,18 @@ def instr_model():
         if model is None:
             reason = f"{INSTR_MODEL.name} not found"
         else:
-            from tools.calibrate_instr import kernel_sources_digest
+            from tools.calibrate_instr import kernel_code_digest, kernel_sources_digest
 
-            if model.get("kernel_sources_sha256") != kernel_sources_digest():
-                model, reason = None, (f"{INSTR_MODEL.name} was fitted to other kernel sources (digest mismatch): re-run "
-                                       "tools/calibrate_instr.py under rocprofv3 --pmc SQ_INSTS_VALU")
+            if model.get("kernel_code_sha256"):         # round 6: the machine code of the modelled kernels in the built library
+                try:
+                    same = model["kernel_code_sha256"] == kernel_code_digest()
+                except Exception as exc:
+                    same, reason = False, f"{INSTR_MODEL.name}: the library's kernel code could not be read ({exc})"
+            else:                                       # older models: the source headers
+                same = model.get("kernel_sources_sha256") == kernel_sources_digest()
+            if not same:
+                model, reason = None, reason or (f"{INSTR_MODEL.name} was fitted to other kernel code (digest mismatch): re-run "
+                                                 "tools/calibrate_instr.py under rocprofv3 --pmc SQ_INSTS_VALU")
         _MODEL_STATE["m"] = (model, reason)
     return _MODEL_STATE["m"]
 
@@ -192,47 +199,53 @@ def instr_per_wave(kind: str, L: int, nblk: int, n_sqr: int, n_mul: int):
 
 def valu_roofline(kernel: str, instr_per_launch, launches: int, elapsed: float, kernel_ms: float, concurrent: int,
                   mac_share=None, clock_mhz=None) -> dict:
-    """Roofline of an integer-VALU kernel: `achieved` = VALU wave-instructions of all timed launches / wall time;
-    `peak` = what THIS instruction mix could issue at the nominal clock (mac_share of it multiplies at 4.19
-    cycles, the rest plain VALU at 2.28: the measured costs); `frac` = achieved / peak.  Beside it: the same
-    fraction at the shader clock measured during the run, the multiply-accumulates alone against the multiply
-    issue rate, and everything against the guide's 2-cycle vector peak."""
+    """Roofline of an integer-VALU kernel as SURVEY.md §8(d) defines it: the binding roof is the integer multiply issue
+    rate, so `achieved` = multiply-accumulate wave-instructions of all timed launches / wall time, `peak` = the rate at
+    which the chip issues them (SIMDs x nominal clock / 4.19 cycles, measured), `frac` = achieved / peak.  The kernel's
+    other VALU instructions (carries, quotient digits, lane exchanges: mac_share < 1 of the mix) are NOT credited as
+    achieved work.  Beside it, under `issue_slots` / `frac_issue_slots`: all VALU wave-instructions
+    against what THIS instruction mix could issue (mac_share at 4.19 cycles, the rest at 2.28) — how full the VALU issue
+    slots are, which is what says whether scheduling or only fewer instructions can still help —, the same at the shader
+    clock measured during the run, and everything against the guide's 2-cycle vector peak."""
     out = {
-        "bound": "valu-multiply-issue", "kernel": kernel, "unit": "G VALU wave-instructions/s",
+        "bound": "valu-multiply-issue", "kernel": kernel, "unit": "G multiply-accumulate wave-instructions/s",
         "kernel_ms": kernel_ms, "concurrent_launches": concurrent,
         "instructions_per_launch": instr_per_launch,
         "instructions_basis": "n_waves x (n_sqr x I_sqr + n_mul x I_mul + F): squarings/multiplications from the "
-                              "exponent's tape, per-instance constants fitted to SQ_INSTS_VALU (profiles/r05_instr_model.json, "
-                              "refused when the digest of the kernel sources it records no longer matches)",
-        "peak_basis": (f"{SIMDS} SIMDs x {NOMINAL_HZ / 1e9} GHz / (mac_share x {MAC_CYCLES} + (1 - mac_share) x {OTHER_CYCLES}) cycles: issue costs measured "
-                       "on this chip with independent streams, wall clock and SQ_INSTS_VALU (profiles/r03_ubench_valu_peak.txt): integer "
-                       "multiplies issue at half the rate of plain VALU instructions, which issue at the 2 cycles of MI355X_MICROARCH.md "
-                       "(SIMD-32)"),
+                              "exponent's tape, per-instance constants fitted to SQ_INSTS_VALU (profiles/r06_instr_model.json, "
+                              "refused when the digest of the kernel sources it records no longer matches); x mac_share "
+                              "(v_mad_u64_u32 + v_mul_* share of the kernel's VALU instructions, tools/isa_mix.py) = multiply-accumulates",
+        "peak_basis": (f"{SIMDS} SIMDs x {NOMINAL_HZ / 1e9} GHz / {MAC_CYCLES} cycles per integer multiply(-accumulate) wave-instruction: the issue "
+                       "cost measured on this chip with independent streams, wall clock and SQ_INSTS_VALU (profiles/r03_ubench_valu_peak.txt; "
+                       f"plain VALU instructions: {OTHER_CYCLES} cycles)"),
         "shader_clock_mhz_measured": clock_mhz,
         "shader_clock_basis": "mx_clock_probe wavefronts running beside the timed steps (s_memtime / s_memrealtime x 100 MHz)",
     }
     if instr_per_launch is None:
-        out.update({"achieved": None, "peak": None, "frac": None})
+        out.update({"achieved": None, "peak": None, "frac": None, "frac_issue_slots": None})
         return out
-    achieved = instr_per_launch * launches / elapsed
+    all_valu = instr_per_launch * launches / elapsed
     share = 1.0 if mac_share is None else mac_share
     mix_cycles = share * MAC_CYCLES + (1 - share) * OTHER_CYCLES
-    peak = SIMDS * NOMINAL_HZ / mix_cycles
-    out["achieved"] = achieved / 1e9
-    out["peak"] = peak / 1e9
-    out["frac"] = achieved / peak
+    mix_peak = SIMDS * NOMINAL_HZ / mix_cycles
+    out["achieved"] = all_valu * share / 1e9
+    out["peak"] = MAC_ISSUE_PEAK / 1e9
+    out["frac"] = all_valu * share / MAC_ISSUE_PEAK
     out["mac_share"] = mac_share
-    out["frac_at_measured_clock"] = (achieved / (SIMDS * clock_mhz * 1e6 / mix_cycles)) if clock_mhz else None
+    out["issue_slots"] = {"achieved": all_valu / 1e9, "peak": mix_peak / 1e9, "unit": "G VALU wave-instructions/s", "frac": all_valu / mix_peak,
+                          "peak_basis": f"{SIMDS} SIMDs x {NOMINAL_HZ / 1e9} GHz / (mac_share x {MAC_CYCLES} + (1 - mac_share) x {OTHER_CYCLES}) cycles"}
+    out["frac_issue_slots"] = all_valu / mix_peak
+    out["frac_at_measured_clock"] = (all_valu / (SIMDS * clock_mhz * 1e6 / mix_cycles)) if clock_mhz else None
     # above 1 the instruction model, the issue costs or — for the short kernels of a biprime step, where a 0.3 ms probe can
     # catch a clock the governor has already lowered — the clock samples are off: the raw value stays, flagged
     out["clock_sample_inconsistent"] = bool(out["frac_at_measured_clock"] is not None and out["frac_at_measured_clock"] > 1.0)
-    out["frac_macs_vs_multiply_issue_peak"] = achieved * share / MAC_ISSUE_PEAK
-    out["frac_vs_guide_vector_peak"] = achieved / GUIDE_VECTOR_PEAK
+    out["frac_vs_guide_vector_peak"] = all_valu / GUIDE_VECTOR_PEAK
     out["guide_vector_peak"] = GUIDE_VECTOR_PEAK / 1e9
-    out["note"] = ("frac prices the kernel's own instruction mix at the measured issue costs and the NOMINAL clock; the chip "
-                   "sustains ~2.1-2.2 GHz under this load, so frac_at_measured_clock is the fraction of the issue slots the "
-                   "kernel fills.  frac_vs_guide_vector_peak is what a stream of 2-cycle instructions could reach — no "
-                   "32x32-bit multiply form issues at that rate (v_mul_lo_u32, v_mad_u64_u32, v_mad_u32_u24 all 4.1-4.3)")
+    out["note"] = ("frac = multiply-accumulates against the multiply issue rate at the NOMINAL clock (SURVEY 8d).  frac_issue_slots prices "
+                   "the kernel's whole instruction mix at the measured issue costs; the chip sustains ~2.1-2.3 GHz under this load, so "
+                   "frac_at_measured_clock is the fraction of the VALU issue slots the kernel fills.  frac_vs_guide_vector_peak is what a "
+                   "stream of 2-cycle instructions could reach — no 32x32-bit multiply form issues at that rate (v_mul_lo_u32, "
+                   "v_mad_u64_u32, v_mad_u32_u24 all 4.1-4.3)")
     return out
 
 
@@ -444,14 +457,37 @@ def time_steps(eng, torch, dist, step_fn, steps: int, warmup: int, nstreams: int
     # kernels of a biprime step a sample can catch a clock the governor has already lowered — valu_roofline flags a
     # frac_at_measured_clock above 1 as clock_sample_inconsistent)
     CLOCK["mhz"] = sum(clocks) / len(clocks) if clocks else None
+    RANK_TIMES["elapsed_s"] = [elapsed]
     if dist is not None:
+        # every rank's own clock around the same barrier-to-barrier region: the job's time is the slowest rank's, and the
+        # spread says whether a straggler (a slower GPU, a rank that shares its host cores) set it
+        world = dist.get_world_size()
         t = torch.tensor([elapsed], dtype=torch.float64, device=eng.device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        every = torch.zeros(world, dtype=torch.float64, device=eng.device)
+        dist.all_gather_into_tensor(every, t)
+        RANK_TIMES["elapsed_s"] = [float(x) for x in every.cpu().tolist()]
+        elapsed = max(RANK_TIMES["elapsed_s"])
     return elapsed, (kernel_total_ms / launches if launches else 0.0), launches
 
 
 CLOCK = {"mhz": None}       # shader clock measured during the last time_steps call
+QUIET = {"group": None}     # gloo process group of an N > 1 run (main): barriers that block in a socket instead of spinning
+
+
+def cpu_baseline_on_rank0(dist, rank: int, fn):
+    """The CPU baseline of an N > 1 run: rank 0 times it AFTER the timed region, on all usable host
+    cores, while the other ranks wait in a gloo barrier (no GPU work, no spinning host thread beside the timed processes)."""
+    res = fn() if rank == 0 else None
+    if dist is not None and QUIET["group"] is not None:
+        dist.barrier(group=QUIET["group"])
+    return res
+RANK_TIMES = {"elapsed_s": []}      # every rank's elapsed time of the last time_steps call (rank order)
+
+
+def per_rank_block(steps: int) -> dict:
+    """ms_per_step of every rank of the last timed region (the line's ms_per_step is the max)."""
+    ms = [e / steps * 1e3 for e in RANK_TIMES["elapsed_s"]]
+    return {"min": min(ms), "max": max(ms), "ranks": [float(f"{m:.5g}") for m in ms]} if ms else None
 
 
 def decrypt_roofline(eng, wl: DecryptWorkload, steps: int, elapsed: float, kernel_ms: float, nstreams: int, key_length: int) -> dict:
@@ -524,7 +560,7 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
         "unit": "modexps/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3,
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "distributed": dist_info(torch, dist, world),
+        "distributed": dist_info(torch, dist, world, args.steps),
         "config": {
             "workload": f"{label}: 3-party key_length={key_length} t=1, {batch} ciphertexts/GPU/step: "
                         "partial-decrypt c^exp mod N^2 + share-combine",
@@ -543,6 +579,25 @@ def run_decrypt_main(args, eng, torch, dist, rank: int, world: int, key_length: 
     return out
 
 
+def restores_launch_shape(fn):
+    """A leg that changes the engine's launch shape (limbs per lane, wavefronts per group) leaves it as it found it,
+    also when it raises: main()'s guarded() swallows a leg's exception, and every later leg would silently run with the
+    wrong shape and report numbers that no longer mean what their labels say."""
+    import functools
+
+    @functools.wraps(fn)
+    def wrapper(eng, *a, **k):
+        saved = (eng._lpl, eng._wpg)
+        try:
+            return fn(eng, *a, **k)
+        finally:
+            eng.set_limbs_per_lane(saved[0])
+            eng.set_wavefronts_per_group(saved[1])
+
+    return wrapper
+
+
+@restores_launch_shape
 def leg_single_batch(eng, torch, wl: DecryptWorkload, key_length: int) -> dict:
     """The same step with ONE launch in flight (what a caller without its own streams gets): the library picks the
     launch shape for a lone launch of this size."""
@@ -565,6 +620,7 @@ def leg_single_batch(eng, torch, wl: DecryptWorkload, key_length: int) -> dict:
                     + (f", time-sliced over {sliced[0]} resident workgroups per CU" if sliced[0] else "")}
 
 
+@restores_launch_shape
 def leg_latency(eng, torch, wl: DecryptWorkload, single_core_rate) -> dict:
     """The lone call the reference's API produces (DistributedPaillier.decrypt of ONE ciphertext,
     distributed_keygen.py:345-349 -> paillier_shared_key.py:92): Python int in, Python int out through
@@ -602,6 +658,7 @@ def leg_latency(eng, torch, wl: DecryptWorkload, single_core_rate) -> dict:
     return out
 
 
+@restores_launch_shape
 def leg_end_to_end(eng, torch, wl: DecryptWorkload, tensor_rate: float) -> dict:
     """Python ints in -> Python ints out through the drop-in classes: GpuPaillierSharedKey
     .partial_decrypt_batch (pack, H2D, modexp, D2H, unpack) and .decrypt_batch (the same around the
@@ -831,11 +888,14 @@ def priority_aux_for(nstreams: int) -> bool:
     return 1 < nstreams <= 4
 
 
-def dist_info(torch, dist, world: int):
-    """What the process group actually is: world size as the backend reports it and the RCCL version."""
+def dist_info(torch, dist, world: int, steps: int = 0):
+    """What the process group actually is: world size as the backend reports it, the RCCL version, and every rank's own
+    ms_per_step of the timed region just measured (straggler visibility)."""
     if dist is None:
         return None
     info = {"backend": dist.get_backend(), "world_size": dist.get_world_size(), "ranks_expected": world}
+    if steps:
+        info["ms_per_step_per_rank"] = per_rank_block(steps)
     try:
         info["rccl_version"] = ".".join(str(x) for x in torch.cuda.nccl.version())
     except Exception:  # pragma: no cover
@@ -888,7 +948,7 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
         "unit": "modexps/s", "n_gpus": world, "steps": steps, "warmup": warmup,
         "ms_per_step": elapsed / steps * 1e3,
         "higher_is_better": True, "scaling": "weak" if weak else "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-        "distributed": dist_info(torch, dist, world),
+        "distributed": dist_info(torch, dist, world, steps),
         "config": {
             "workload": f"C4: {n_parties}-party key_length={key_length} t=2, {total_cands} sieve-surviving candidate moduli "
                         f"sharded over {world} GPU(s) ({cands}/GPU/step): 160 Jacobi symbols + first-40 selection + 40 modexps "
@@ -912,6 +972,7 @@ def run_biprime(args, eng, torch, dist, rank: int, world: int, key_length: int, 
 # ---------------------------------------------------------------------------------------------------
 # one key-generation round, Python ints in -> verdicts out (distributed_keygen.py:1284-1360)
 # ---------------------------------------------------------------------------------------------------
+@restores_launch_shape
 def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 5, t: int = 2,
                      batch_sizes=(100, 1024, 16384, 65536)) -> dict:
     """What patch.compute_modulus does per round (biprime.BiprimeRound), timed from Python ints to Python verdicts for
@@ -1152,13 +1213,14 @@ def compact_roofline(roof):
     if not isinstance(roof, dict):
         return None
     r = _pick(roof, ("bound", "kernel", "achieved", "peak", "unit", "frac", "kernel_ms", "concurrent_launches", "mac_share",
-                     "frac_at_measured_clock", "clock_sample_inconsistent", "shader_clock_mhz_measured", "frac_macs_vs_multiply_issue_peak",
+                     "frac_issue_slots", "frac_at_measured_clock", "clock_sample_inconsistent", "shader_clock_mhz_measured",
                      "frac_vs_guide_vector_peak", "instructions_per_launch"))
     r["traffic"] = _num(roof.get("traffic"))
     if roof.get("frac") is None:
         r["frac"] = None
         r["why_null"] = str(roof.get("instructions_basis", ""))[:160]
-    r["peak_basis"] = f"{SIMDS} SIMDs x {NOMINAL_HZ / 1e9} GHz / (mac_share x {MAC_CYCLES} + (1 - mac_share) x {OTHER_CYCLES}) cycles, measured issue costs (DESIGN.md 6)"
+    r["peak_basis"] = (f"{SIMDS} SIMDs x {NOMINAL_HZ / 1e9} GHz / {MAC_CYCLES} cycles per integer multiply wave-instruction (measured; SURVEY 8d); "
+                       f"frac_issue_slots: whole mix at mac_share x {MAC_CYCLES} + (1 - mac_share) x {OTHER_CYCLES} cycles (DESIGN.md 6)")
     hbm = roof.get("hbm")
     if isinstance(hbm, dict):
         r["hbm"] = _pick(hbm, ("achieved", "peak", "unit", "frac", "algorithmic_bytes_per_launch", "traffic", "traffic_model",
@@ -1279,45 +1341,79 @@ def rank_command(argv, script=None) -> list:
     return [sys.executable, str(script or Path(__file__).resolve()), *argv]
 
 
-def spawn_ranks(argv, world: int, script=None, poll_s: float = 0.2) -> int:
+def profiler_preload(env=None) -> str:
+    """Name of the variable that says a GPU profiler is preloaded into this process (rocprofv3 exports these for its
+    target), or ''.  Such a process has initialised the GPU before Python started, and starting rank processes from it is
+    the exec-after-GPU-init this pool forbids."""
+    env = os.environ if env is None else env
+    if any(tok in env.get("LD_PRELOAD", "") for tok in ("rocprof", "rocprofiler", "roctracer", "rocsys")):
+        return "LD_PRELOAD"
+    return next((k for k in env if k.startswith(("ROCP_TOOL_LIB", "ROCPROFILER_", "ROCPROF_", "ROCTRACER_")) and env[k]), "")
+
+
+def spawn_ranks(argv, world: int, script=None, poll_s: float = 0.2, attempts: int = 3) -> int:
     """One FRESH child process per GPU (this parent has made no GPU call and makes none), rendezvous on 127.0.0.1.
     Rank 0's single stdout line is relayed as this process's single stdout line; the other ranks' stdout goes to
     stderr.  Returns 0, or the exit code of the first rank that failed — the remaining ranks (exactly the PIDs started
-    here) are then terminated instead of being left in a collective nobody will complete."""
+    here) are then terminated instead of being left in a collective nobody will complete.  The rendezvous port is
+    picked by binding port 0 and released before the ranks start; if another process takes it in between, rank 0 fails
+    with "address already in use" and the ranks are started again on another port (at most `attempts` times)."""
     import socket
     import threading
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
-    procs = []
-    for r in range(world):
-        procs.append(subprocess.Popen(rank_command(argv, script), env=rank_environment(r, world, port),
-                                      stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(), text=(r == 0)))
-    captured = []
-    reader = threading.Thread(target=lambda: captured.extend(procs[0].stdout), daemon=True)
-    reader.start()
-    failed = 0
-    try:
-        while any(p.poll() is None for p in procs):
-            bad = next((p for p in procs if p.poll() not in (None, 0)), None)
-            if bad is not None:
-                failed = bad.returncode
-                sys.stderr.write(f"bench.py: rank {procs.index(bad)} exited with {failed}; stopping the other ranks\n")
-                break
-            time.sleep(poll_s)
-    finally:
-        for p in procs:
-            if p.poll() is None:
-                p.terminate()
-        for p in procs:
-            try:
-                p.wait(timeout=20)
-            except subprocess.TimeoutExpired:
-                p.kill()
-                p.wait()
-    reader.join(timeout=5)
-    failed = failed or next((p.returncode for p in procs if p.returncode != 0), 0)
+    why = profiler_preload()
+    if why:
+        sys.stderr.write(f"bench.py --gpus {world}: a GPU profiler is preloaded into this process ({why}); it has initialised the GPU, and "
+                         "starting the rank processes from here is refused.  Profile ONE rank instead: rocprofv3 ... -- python3 bench.py --gpus 1 ..., "
+                         "or start the ranks with torch.distributed.run and put the profiler in front of a single rank's command.\n")
+        return 2
+    for attempt in range(attempts):
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = s.getsockname()[1]
+        procs = []
+        for r in range(world):
+            procs.append(subprocess.Popen(rank_command(argv, script), env=rank_environment(r, world, port),
+                                          stdout=subprocess.PIPE if r == 0 else sys.stderr.fileno(),
+                                          stderr=subprocess.PIPE if r == 0 else None, text=(r == 0)))
+        captured, port_taken = [], []
+
+        def relay_stderr():
+            for ln in procs[0].stderr:
+                if "address already in use" in ln.lower() or "EADDRINUSE" in ln:
+                    port_taken.append(ln)
+                sys.stderr.write(ln)
+
+        reader = threading.Thread(target=lambda: captured.extend(procs[0].stdout), daemon=True)
+        err_reader = threading.Thread(target=relay_stderr, daemon=True)
+        reader.start()
+        err_reader.start()
+        failed = 0
+        try:
+            while any(p.poll() is None for p in procs):
+                bad = next((p for p in procs if p.poll() not in (None, 0)), None)
+                if bad is not None:
+                    failed = bad.returncode
+                    sys.stderr.write(f"bench.py: rank {procs.index(bad)} exited with {failed}; stopping the other ranks\n")
+                    break
+                time.sleep(poll_s)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.terminate()
+            for p in procs:
+                try:
+                    p.wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    p.kill()
+                    p.wait()
+        reader.join(timeout=5)
+        err_reader.join(timeout=5)
+        failed = failed or next((p.returncode for p in procs if p.returncode != 0), 0)
+        if failed and port_taken and attempt + 1 < attempts:
+            sys.stderr.write(f"bench.py: port {port} was taken before the ranks met; starting them again on another port\n")
+            continue
+        break
     lines = [ln.strip() for ln in captured if ln.strip()]
     if failed == 0 and not lines:
         sys.stderr.write("bench.py: rank 0 printed no result line\n")
@@ -1378,6 +1474,10 @@ def main() -> None:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend)
+        # a second, socket-based group for waits that must not occupy host cores: while rank 0 times the CPU baseline
+        # on ALL usable cores, the other ranks block in a gloo barrier (an RCCL barrier is a device kernel plus a host
+        # thread that may spin on the stream)
+        QUIET["group"] = dist.new_group(backend="gloo") if world > 1 else None
 
     from protocols.distributed_keygen_amd import build as _build
 
@@ -1398,14 +1498,22 @@ def main() -> None:
         batch = args.batch or (10000 if args.workload == "c3" else 4096)
         label = "C3 (BASELINE.json configs[2])" if args.workload == "c3" else "C5 (BASELINE.json configs[4])"
         out = run_decrypt_main(args, eng, torch, dist, rank, world, key_length, batch, label)
+        cb = None
+        if not args.no_cpu_baseline:
+            def _cpu():
+                w_ = out["_wl"]
+                bases = [c if w_.exps[w_.own] >= 0 else pow(c, -1, w_.n2) for c in w_.cts[:64]]
+                # N > 1: a shorter sample — the other ranks wait for it, and the driver runs four such jobs back to back
+                secs = args.cpu_seconds if world == 1 else min(args.cpu_seconds, 5.0)
+                res = cpu_baseline(w_.n2, w_.own_exp, bases, secs, "same modulus/exponent, first 64 ciphertexts of the batch cycled")
+                if world > 1:
+                    res["sample"] = (res.get("sample", "") + f"; timed by rank 0 after the timed region while the other {world - 1} rank(s) wait in a gloo barrier")[:400]
+                return res
+
+            cb = cpu_baseline_on_rank0(dist, rank, _cpu)
         if rank == 0:
             wl = out.pop("_wl")
-            if world == 1 and not args.no_cpu_baseline:
-                bases = [c if wl.exps[wl.own] >= 0 else pow(c, -1, wl.n2) for c in wl.cts[:64]]
-                out["cpu_baseline"] = cpu_baseline(wl.n2, wl.own_exp, bases, args.cpu_seconds,
-                                                   "same modulus/exponent, first 64 ciphertexts of the batch cycled")
-            else:
-                out["cpu_baseline"] = None
+            out["cpu_baseline"] = cb
             if not extras:
                 del wl
             if extras:
@@ -1490,13 +1598,19 @@ def main() -> None:
         total = (args.batch or 4096) if weak else (args.batch * world if args.batch else 4096)
         nstreams = args.streams if args.streams > 0 else biprime_lanes(total if weak else -(-total // world), args.steps)
         out = run_biprime(args, eng, torch, dist, rank, world, key_length, total, args.steps, args.warmup, nstreams, weak=weak)
+        cb = None
+        if not args.no_cpu_baseline:
+            def _cpu_bp():
+                w_ = out["_wl"]
+                secs = args.cpu_seconds if world == 1 else min(args.cpu_seconds, 5.0)
+                return cpu_baseline(w_.mods[0], w_.exps[0], w_.g_sample[:40], secs,
+                                    "candidate 0's modulus and party-1 exponent, its first 40 generators cycled"
+                                    + ("" if world == 1 else f"; timed by rank 0 after the timed region while the other {world - 1} rank(s) wait in a gloo barrier"))
+
+            cb = cpu_baseline_on_rank0(dist, rank, _cpu_bp)
         if rank == 0:
             wl = out.pop("_wl")
-            if world == 1 and not args.no_cpu_baseline:
-                out["cpu_baseline"] = cpu_baseline(wl.mods[0], wl.exps[0], wl.g_sample[:40], args.cpu_seconds,
-                                                   "candidate 0's modulus and party-1 exponent, its first 40 generators cycled")
-            else:
-                out["cpu_baseline"] = None
+            out["cpu_baseline"] = cb
     if rank == 0:
         emit_result(out, result_fd)
     if dist is not None:

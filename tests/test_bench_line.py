@@ -165,3 +165,107 @@ def test_main_becomes_the_launcher_before_any_gpu_call(bench, monkeypatch):
     with pytest.raises(SystemExit) as exc:
         bench.main()
     assert exc.value.code == 0 and seen == {"argv": ["--gpus", "8", "--steps", "4", "--warmup", "1"], "world": 8}
+
+
+def test_spawn_ranks_retries_on_a_taken_port_and_refuses_under_a_profiler(bench, tmp_path, capfd, monkeypatch):
+    """the rendezvous port is released before the ranks bind it — a rank 0 that reports "address already in
+    use" gets the whole job started again on another port; and a parent with a GPU profiler preloaded must not start
+    rank processes at all (the profiler has initialised the GPU: an exec from there takes the machine down on this pool)."""
+    marker = tmp_path / "first_attempt_done"
+    script = tmp_path / "rank.py"
+    script.write_text(f"""
+import json, os, sys
+rank = int(os.environ["RANK"])
+marker = {str(marker)!r}
+if not os.path.exists(marker):
+    if rank == 0:
+        open(marker, "w").write(os.environ["MASTER_PORT"])
+        sys.stderr.write("RuntimeError: The server socket has failed to listen on any local network address. EADDRINUSE: address already in use\\n")
+        sys.exit(1)
+    import time; time.sleep(60)
+if rank == 0:
+    print(json.dumps({{"port": os.environ["MASTER_PORT"], "first": open(marker).read()}}))
+""")
+    rc = bench.spawn_ranks(["--gpus", "2"], 2, script=script)
+    cap = capfd.readouterr()
+    assert rc == 0, cap.err[-500:]
+    res = json.loads(cap.out.strip().splitlines()[-1])
+    assert res["port"] != res["first"] and "starting them again on another port" in cap.err
+    # a failure that is not about the port is not retried
+    marker.unlink()
+    script.write_text("import os, sys\nsys.exit(5 if os.environ['RANK'] == '0' else 0)\n")
+    assert bench.spawn_ranks(["--gpus", "2"], 2, script=script) == 5
+    # profiler preload: refused before anything is started
+    assert bench.profiler_preload({"LD_PRELOAD": "/opt/rocm/lib/librocprofiler-sdk-tool.so"}) == "LD_PRELOAD"
+    assert bench.profiler_preload({"ROCP_TOOL_LIBRARIES": "x.so"}) == "ROCP_TOOL_LIBRARIES"
+    assert bench.profiler_preload({"PATH": "/bin", "LD_PRELOAD": "libjemalloc.so"}) == ""
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    script.write_text("open(%r, 'w').write('started')\n" % str(tmp_path / "started"))
+    assert bench.spawn_ranks(["--gpus", "2"], 2, script=script) == 2
+    assert not (tmp_path / "started").exists() and "profiler is preloaded" in capfd.readouterr().err
+
+
+def test_roofline_frac_is_multiply_accumulates_against_the_multiply_issue_peak(bench):
+    """VERDICT r05 item 4 / SURVEY 8(d): roofline.frac = multiply-accumulate wave-instructions / time / multiply issue
+    peak; the kernel's bookkeeping instructions are not credited.  The mix-based figure stays as frac_issue_slots."""
+    roof = bench.valu_roofline("k", instr_per_launch=1.8e10, launches=20, elapsed=0.66, kernel_ms=30.0, concurrent=4, mac_share=0.805, clock_mhz=2300.0)
+    macs = 1.8e10 * 20 / 0.66 * 0.805
+    peak = bench.SIMDS * bench.NOMINAL_HZ / bench.MAC_CYCLES
+    assert roof["frac"] == pytest.approx(macs / peak) and roof["achieved"] == pytest.approx(macs / 1e9) and roof["peak"] == pytest.approx(peak / 1e9)
+    assert roof["achieved"] / roof["peak"] == pytest.approx(roof["frac"])
+    assert "multiply-accumulate" in roof["unit"]
+    mix = bench.SIMDS * bench.NOMINAL_HZ / (0.805 * bench.MAC_CYCLES + 0.195 * bench.OTHER_CYCLES)
+    assert roof["frac_issue_slots"] == pytest.approx(1.8e10 * 20 / 0.66 / mix) == pytest.approx(roof["issue_slots"]["frac"])
+    assert roof["frac"] < roof["frac_issue_slots"] < roof["frac_at_measured_clock"]
+    compact = bench.compact_roofline(roof)
+    assert compact["frac"] == pytest.approx(roof["frac"], rel=1e-4) and compact["frac_issue_slots"] == pytest.approx(roof["frac_issue_slots"], rel=1e-4)
+    assert "frac_macs_vs_multiply_issue_peak" not in compact
+    none = bench.valu_roofline("k", None, 20, 0.66, 30.0, 4)
+    assert none["frac"] is None and none["frac_issue_slots"] is None
+
+
+def test_multi_rank_line_carries_per_rank_times_and_the_cpu_baseline(bench):
+    """an N > 1 line has every rank's ms_per_step (min / max / list), the world size as the backend
+    reports it, and a cpu_baseline (rank 0 times it after the timed region)."""
+    bench.RANK_TIMES["elapsed_s"] = [0.60, 0.66, 0.63, 0.61]
+    blk = bench.per_rank_block(20)
+    assert blk["min"] == pytest.approx(30.0) and blk["max"] == pytest.approx(33.0) and len(blk["ranks"]) == 4
+    full = {"metric": "m", "value": 1.0, "unit": "u", "n_gpus": 4, "steps": 20, "warmup": 5, "ms_per_step": 33.0, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "u32", "data": "synthetic", "config": {"workload": "w"},
+            "roofline": {"bound": "b", "kernel": "k", "achieved": 1.0, "peak": 2.0, "unit": "x", "frac": 0.5, "traffic": None, "kernel_ms": 1.0},
+            "cpu_baseline": {"value": 1200.0, "unit": "modexps/s", "cores": 16, "kind": "reference", "sample": "s"},
+            "distributed": {"backend": "nccl", "world_size": 4, "ranks_expected": 4, "rccl_version": "2.22.3", "ms_per_step_per_rank": blk, "exchange": "x"}}
+    line = json.loads(bench.result_line(full))
+    assert line["distributed"]["world_size"] == 4 and line["distributed"]["ms_per_step_per_rank"]["max"] == pytest.approx(33.0)
+    assert line["cpu_baseline"]["value"] == 1200.0 and line["cpu_baseline"]["cores"] == 16
+    # the waiting ranks' barrier helper: rank 0 runs the function, the others do not
+    assert bench.cpu_baseline_on_rank0(None, 0, lambda: 7) == 7 and bench.cpu_baseline_on_rank0(None, 3, lambda: 7) is None
+
+
+def test_a_failing_leg_leaves_the_launch_shape_as_it_found_it(bench):
+    """leg_keygen_round / leg_end_to_end / leg_single_batch / leg_latency reset the engine to automatic
+    shapes; an exception inside must not leave that in place for the legs behind them."""
+    class Eng:
+        _lpl, _wpg = 18, 1
+
+        def set_limbs_per_lane(self, v):
+            self._lpl = v
+
+        def set_wavefronts_per_group(self, v):
+            self._wpg = v
+
+    @bench.restores_launch_shape
+    def leg(eng, fail):
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
+        if fail:
+            raise AssertionError("inside the leg")
+        return "ok"
+
+    e = Eng()
+    assert leg(e, False) == "ok" and (e._lpl, e._wpg) == (18, 1)
+    with pytest.raises(AssertionError):
+        leg(e, True)
+    assert (e._lpl, e._wpg) == (18, 1)
+    for name in ("leg_single_batch", "leg_latency", "leg_end_to_end", "leg_keygen_round"):
+        assert hasattr(getattr(bench, name), "__wrapped__"), name

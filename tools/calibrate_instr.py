@@ -18,9 +18,10 @@ for every (L, nblk):
         — matches the dispatches to the configs in launch order, solves the 3x3 system from the first
           three exponents and reports the residual of the held-out fourth (a check of the linear model)
 
-The model is committed as profiles/r04_instr_model.json together with a digest of the kernel sources it was
-fitted to; bench.py reads it and refuses it (roofline fraction null, with the reason) when the digest no longer
-matches the sources of the library it runs.  Kinds: "n2" (pair kernel, one wavefront per group), "n2split" (two
+The model is committed as profiles/r0N_instr_model.json together with a digest of the MACHINE CODE of the modelled
+kernels in the library it was fitted to (kernel_code_digest; models of rounds 2-5 recorded a digest of the source headers);
+bench.py reads it and refuses it (roofline fraction null, with the reason) when the digest no longer matches the library
+it runs.  Kinds: "n2" (pair kernel, one wavefront per group), "n2split" (two
 wavefronts per group: the constants are per PAIR of wavefronts), "generic" (fixed-window kernel).
 """
 
@@ -50,6 +51,58 @@ def kernel_sources_digest() -> str:
         h.update((ROOT / "protocols" / "distributed_keygen_amd" / "csrc" / name).read_bytes())
     return h.hexdigest()
 
+
+
+MODELLED_KERNELS = ("powmod_kernel", "powmod_n2_kernel", "powmod_n2_split_kernel")
+
+
+def kernel_code_digest(lib_path=None) -> str:
+    """sha256 over the MACHINE CODE of the modelled kernels in the built library (every instance of the three modexp kernel
+    templates: the bytes of its function symbol in the gfx950 code objects, by mangled name) — what the constants of
+    the model were actually fitted to.  A comment, a renamed macro or a new kernel elsewhere in the library leaves it
+    alone; any change of the instruction stream of a modelled kernel changes it.  (The digest over the source headers,
+    kernel_sources_digest, refused the model after every edit of those files, including the ones that generate the same
+    code.)"""
+    import hashlib
+    import struct
+
+    from tools import scratch_report
+
+    if lib_path is None:
+        from protocols.distributed_keygen_amd import _lib
+
+        lib_path = _lib.LIB_PATH
+    funcs = {}
+    for elf in scratch_report.code_objects_of_library(lib_path):
+        shoff, = struct.unpack_from("<Q", elf, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", elf, 0x3A)
+        secs = []
+        for i in range(shnum):
+            sh = shoff + i * shentsize
+            sh_type, = struct.unpack_from("<I", elf, sh + 4)
+            addr, off, size, link = struct.unpack_from("<QQQI", elf, sh + 0x10)
+            secs.append((sh_type, addr, off, size, link))
+        for sh_type, _addr, off, size, link in secs:
+            if sh_type != 2:                 # SHT_SYMTAB
+                continue
+            str_off = secs[link][2]
+            for p in range(off, off + size, 24):
+                st_name, st_info, _other, shndx, value, st_size = struct.unpack_from("<IBBHQQ", elf, p)
+                if st_info & 0xF != 2 or not st_size or shndx == 0 or shndx >= len(secs):      # STT_FUNC, defined
+                    continue
+                end = elf.index(b"\0", str_off + st_name)
+                name = elf[str_off + st_name:end].decode()
+                if not any(f"2mx{len(k)}{k}I" in name for k in MODELLED_KERNELS):
+                    continue
+                _t, s_addr, s_off, _s, _l = secs[shndx]
+                start = s_off + (value - s_addr)
+                funcs[name] = elf[start:start + st_size]
+    if len(funcs) < 60:
+        raise RuntimeError(f"only {len(funcs)} modexp kernel symbols found in {lib_path}")
+    h = hashlib.sha256()
+    for name in sorted(funcs):
+        h.update(name.encode() + b"\0" + struct.pack("<Q", len(funcs[name])) + funcs[name])
+    return h.hexdigest()
 
 
 def fixed_window(exp_bits: int) -> int:
@@ -164,6 +217,7 @@ def fit(cfg_path: str, pmc_dir: str, model_path: str) -> None:
             if kind:
                 disp[kind].append((int(r["Dispatch_Id"]), float(r["Counter_Value"]), name))
     model = {"n2": {"9": {}, "18": {}}, "n2split": {"3": {}, "9": {}, "18": {}}, "generic": {"3": {}, "9": {}, "18": {}}, "max_residual": 0.0,
+             "kernel_code_sha256": kernel_code_digest(), "kernel_code_of": list(MODELLED_KERNELS),
              "kernel_sources_sha256": kernel_sources_digest(), "kernel_sources": KERNEL_SOURCES,
              "source": "tools/calibrate_instr.py: SQ_INSTS_VALU of 4 exponents per (kernel, L, nblk); wave-instructions "
                        "per wavefront (n2split: per pair of wavefronts) = n_sqr*I_sqr + n_mul*I_mul + F"}
