@@ -166,7 +166,9 @@ def biprime_test_with_v_i_batch(
     if hasattr(eng, "biprime_verdict_columns"):
         # one flat column per party (candidate-major), packed with one codec call each; `own` = (party index, handle of
         # that party's values still on the device): taken from there instead of being packed again
-        columns = [own[1] if own is not None and own[0] == i else _party_column(v_by_party, i, nslots) for i in order]
+        nested = getattr(eng, "NestedColumn", None)      # one list per candidate, packed as it is (engine.NestedColumn)
+        columns = [own[1] if own is not None and own[0] == i else
+                   (nested([vc[i] for vc in v_by_party]) if nested is not None else _party_column(v_by_party, i, nslots)) for i in order]
         if _accepts(eng.biprime_verdict_columns, "as_array"):
             slot_pass = eng.biprime_verdict_columns(columns, list(moduli), nslots, mods_rows=mods_rows, as_array=True)
         else:

@@ -9,6 +9,14 @@
  *
  *   pack_into(values, limbs, buffer, row_offset) -> None   buffer: writable, C-contiguous, rows of 4*limbs bytes
  *   unpack(buffer, limbs) -> list[int]
+ *   pack_nested_into(lists, inner, limbs, buffer, row_offset) -> None    lists[g] contributes `inner` rows: its first
+ *                                                           min(len, inner) ints, then zero rows — the generator lists and
+ *                                                           v lists of a key-generation round (one list per candidate,
+ *                                                           DK:1313-1360) packed as the reference holds them, without a
+ *                                                           flattened copy of 230 000 references first
+ *   unpack_groups(buffer, limbs, counts, stride) -> list[list[int]]     group g = rows [g * stride, g * stride + counts[g]):
+ *                                                           the v lists of DK:1103-1108 built in one pass (no flat list
+ *                                                           that is sliced — and every int touched — a second time)
  *   rows_ge(rows, limbs, moduli_rows, group) -> list[int]  indices of rows that are >= their group's modulus
  *   set_threads(n) -> previous setting                     0 = automatic (usable cores, at most 16)
  *
@@ -76,6 +84,7 @@ static void* pack_worker(void* arg) {
   const Py_ssize_t room = 32 * j->limbs;
   for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
     PyObject* v = j->items[i];
+    if (!v) { memset(j->dst + i * j->limbs, 0, (size_t)j->limbs * 4); continue; }      /* padding row (pack_nested_into) */
     if (!PyLong_Check(v)) { j->bad = i; j->bad_kind = 1; return NULL; }
     const Py_ssize_t nd = Py_SIZE(v);
     const digit* d = ((PyLongObject*)v)->ob_digit;
@@ -88,6 +97,35 @@ static void* pack_worker(void* arg) {
     digits_to_words(d, nd, j->dst + i * j->limbs, j->limbs);
   }
   return NULL;
+}
+
+/* items[0..n) (NULL = a zero row) -> rows at dst, on several threads without the interpreter lock; the caller holds a
+ * reference to every item.  Returns 1, or 0 with a Python exception set. */
+static int run_pack(PyObject** items, Py_ssize_t n, uint32_t* dst, Py_ssize_t limbs) {
+  const int nt = usable_threads(n, 1024);
+  PackJob jobs[16];
+  pthread_t tid[16];
+  int started[16] = {0};
+  Py_BEGIN_ALLOW_THREADS
+  for (int t = 0; t < nt; ++t) {
+    jobs[t].items = items; jobs[t].dst = dst; jobs[t].limbs = limbs;
+    jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt; jobs[t].bad = -1; jobs[t].bad_kind = 0;
+    if (t > 0) started[t] = pthread_create(&tid[t], NULL, pack_worker, &jobs[t]) == 0;
+  }
+  pack_worker(&jobs[0]);
+  for (int t = 1; t < nt; ++t) {
+    if (started[t]) pthread_join(tid[t], NULL);
+    else pack_worker(&jobs[t]); /* thread creation failed: this thread does the slice */
+  }
+  Py_END_ALLOW_THREADS
+  for (int t = 0; t < nt; ++t) {
+    if (jobs[t].bad_kind == 1) { PyErr_SetString(PyExc_TypeError, "values must be ints"); return 0; }
+    if (jobs[t].bad_kind == 2) {
+      PyErr_Format(PyExc_ValueError, "value does not fit in %zd uint32 limbs (or is negative)", limbs);
+      return 0;
+    }
+  }
+  return 1;
 }
 
 static PyObject* pack_into(PyObject* self, PyObject* args) {
@@ -109,10 +147,6 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
   }
   {
     uint32_t* dst = (uint32_t*)((unsigned char*)out.buf + row_offset * nbytes);
-    const int nt = usable_threads(n, 1024);
-    PackJob jobs[16];
-    pthread_t tid[16];
-    int started[16] = {0};
     /* a private copy of the element pointers, each with a reference of its own: another thread may resize, clear or
      * overwrite the list while the lock is released, and the workers read the objects' headers and digits */
     PyObject** items = (PyObject**)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(PyObject*));
@@ -121,27 +155,10 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
       PyObject** src = PySequence_Fast_ITEMS(fast);
       for (Py_ssize_t i = 0; i < n; ++i) { items[i] = src[i]; Py_INCREF(items[i]); }
     }
-    Py_BEGIN_ALLOW_THREADS
-    for (int t = 0; t < nt; ++t) {
-      jobs[t].items = items; jobs[t].dst = dst; jobs[t].limbs = limbs;
-      jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt; jobs[t].bad = -1; jobs[t].bad_kind = 0;
-      if (t > 0) started[t] = pthread_create(&tid[t], NULL, pack_worker, &jobs[t]) == 0;
-    }
-    pack_worker(&jobs[0]);
-    for (int t = 1; t < nt; ++t) {
-      if (started[t]) pthread_join(tid[t], NULL);
-      else pack_worker(&jobs[t]); /* thread creation failed: this thread does the slice */
-    }
-    Py_END_ALLOW_THREADS
+    const int ok = run_pack(items, n, dst, limbs);
     for (Py_ssize_t i = 0; i < n; ++i) Py_DECREF(items[i]);
     PyMem_Free(items);
-    for (int t = 0; t < nt; ++t) {
-      if (jobs[t].bad_kind == 1) { PyErr_SetString(PyExc_TypeError, "values must be ints"); goto fail; }
-      if (jobs[t].bad_kind == 2) {
-        PyErr_Format(PyExc_ValueError, "value does not fit in %zd uint32 limbs (or is negative)", limbs);
-        goto fail;
-      }
-    }
+    if (!ok) goto fail;
   }
   Py_DECREF(fast);
   PyBuffer_Release(&out);
@@ -152,13 +169,59 @@ fail:
   return NULL;
 }
 
+/* pack_nested_into(lists, inner, limbs, buffer, row_offset): lists[g] -> rows [row_offset + g * inner, ... + inner) */
+static PyObject* pack_nested_into(PyObject* self, PyObject* args) {
+  PyObject* seq;
+  Py_ssize_t inner, limbs, row_offset;
+  Py_buffer out;
+  if (!PyArg_ParseTuple(args, "Onnw*n", &seq, &inner, &limbs, &out, &row_offset)) return NULL;
+  PyObject* fast = PySequence_Fast(seq, "lists must be a sequence of sequences of ints");
+  if (!fast) { PyBuffer_Release(&out); return NULL; }
+  const Py_ssize_t groups = PySequence_Fast_GET_SIZE(fast);
+  const Py_ssize_t nbytes = 4 * limbs;
+  PyObject** items = NULL;
+  Py_ssize_t n = 0, filled = 0;
+  int ok = 0;
+  if (limbs <= 0 || inner <= 0 || row_offset < 0 || groups > (PY_SSIZE_T_MAX / 8) / inner || (row_offset + groups * inner) * nbytes > out.len) {
+    PyErr_SetString(PyExc_ValueError, "buffer too small for the rows");
+    goto done;
+  }
+  if (((uintptr_t)out.buf & 3u) != 0) {
+    PyErr_SetString(PyExc_ValueError, "rows must be 4-byte aligned");
+    goto done;
+  }
+  n = groups * inner;
+  items = (PyObject**)PyMem_Calloc((size_t)(n ? n : 1), sizeof(PyObject*));
+  if (!items) { PyErr_NoMemory(); goto done; }
+  for (Py_ssize_t g = 0; g < groups; ++g) {
+    PyObject* in = PySequence_Fast(PySequence_Fast_GET_ITEM(fast, g), "lists must be a sequence of sequences of ints");
+    if (!in) goto done;
+    Py_ssize_t k = PySequence_Fast_GET_SIZE(in);
+    if (k > inner) k = inner;
+    PyObject** src = PySequence_Fast_ITEMS(in);
+    for (Py_ssize_t i = 0; i < k; ++i) { items[g * inner + i] = src[i]; Py_INCREF(src[i]); }
+    filled = (g + 1) * inner;
+    Py_DECREF(in);
+  }
+  ok = run_pack(items, n, (uint32_t*)((unsigned char*)out.buf + row_offset * nbytes), limbs);
+done:
+  if (items) {
+    for (Py_ssize_t i = 0; i < filled; ++i) Py_XDECREF(items[i]);
+    PyMem_Free(items);
+  }
+  Py_DECREF(fast);
+  PyBuffer_Release(&out);
+  if (!ok) return NULL;
+  Py_RETURN_NONE;
+}
+
 /* -------------------------------------------------------------------------------------------- unpack */
-typedef struct { const uint32_t* rows; Py_ssize_t limbs, lo, hi; Py_ssize_t* nd; PyObject** objs; int fill; } UnpackJob;
+typedef struct { const uint32_t* rows; Py_ssize_t limbs, lo, hi; Py_ssize_t* nd; PyObject** objs; int fill; const Py_ssize_t* src; } UnpackJob;
 
 static void* unpack_worker(void* arg) {
   UnpackJob* j = (UnpackJob*)arg;
   for (Py_ssize_t i = j->lo; i < j->hi; ++i) {
-    const uint32_t* w = j->rows + i * j->limbs;
+    const uint32_t* w = j->rows + (j->src ? j->src[i] : i) * j->limbs;      /* src: the row of output element i (unpack_groups) */
     if (!j->fill) { /* pass 1: digits needed */
       Py_ssize_t top = j->limbs;
       while (top > 0 && w[top - 1] == 0) --top;
@@ -225,7 +288,7 @@ static PyObject* unpack(PyObject* self, PyObject* args) {
     goto fail;
   }
   const int nt = usable_threads(n, 2048);
-  UnpackJob job = {(const uint32_t*)in.buf, limbs, 0, 0, nd, objs, 0};
+  UnpackJob job = {(const uint32_t*)in.buf, limbs, 0, 0, nd, objs, 0, NULL};
   Py_BEGIN_ALLOW_THREADS
   run_unpack(&job, n, nt);
   Py_END_ALLOW_THREADS
@@ -249,6 +312,84 @@ fail:
   Py_XDECREF(list);
   PyBuffer_Release(&in);
   return NULL;
+}
+
+/* unpack_groups(buffer, limbs, counts, stride) -> [[int, ...], ...]: group g = rows [g * stride, g * stride + counts[g]) */
+static PyObject* unpack_groups(PyObject* self, PyObject* args) {
+  Py_buffer in;
+  Py_ssize_t limbs, stride;
+  PyObject* counts_obj;
+  if (!PyArg_ParseTuple(args, "y*nOn", &in, &limbs, &counts_obj, &stride)) return NULL;
+  PyObject* counts = PySequence_Fast(counts_obj, "counts must be a sequence of ints");
+  if (!counts) { PyBuffer_Release(&in); return NULL; }
+  const Py_ssize_t nbytes = 4 * limbs;
+  const Py_ssize_t groups = PySequence_Fast_GET_SIZE(counts);
+  PyObject* outer = NULL;
+  Py_ssize_t* nd = NULL;
+  Py_ssize_t* src = NULL;
+  Py_ssize_t* cnt = NULL;
+  PyObject** objs = NULL;
+  Py_ssize_t n = 0;
+  int ok = 0;
+  if (limbs <= 0 || stride <= 0 || in.len % nbytes != 0 || ((uintptr_t)in.buf & 3)) {
+    PyErr_SetString(PyExc_ValueError, "buffer must be whole, 4-byte aligned rows");
+    goto done;
+  }
+  cnt = (Py_ssize_t*)PyMem_Malloc((size_t)(groups ? groups : 1) * sizeof(Py_ssize_t));
+  if (!cnt) { PyErr_NoMemory(); goto done; }
+  for (Py_ssize_t g = 0; g < groups; ++g) {
+    const Py_ssize_t c = PyNumber_AsSsize_t(PySequence_Fast_GET_ITEM(counts, g), PyExc_OverflowError);
+    if (c == -1 && PyErr_Occurred()) goto done;
+    if (c < 0 || c > stride) { PyErr_SetString(PyExc_ValueError, "a count must lie in 0 .. stride"); goto done; }
+    cnt[g] = c;
+    n += c;
+  }
+  if (groups * stride * nbytes > in.len) { PyErr_SetString(PyExc_ValueError, "buffer holds fewer than groups x stride rows"); goto done; }
+  nd = (Py_ssize_t*)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(Py_ssize_t));
+  src = (Py_ssize_t*)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(Py_ssize_t));
+  objs = (PyObject**)PyMem_Calloc((size_t)(n ? n : 1), sizeof(PyObject*));
+  outer = PyList_New(groups);
+  if (!nd || !src || !objs || !outer) { PyErr_NoMemory(); goto done; }
+  {
+    Py_ssize_t i = 0;
+    for (Py_ssize_t g = 0; g < groups; ++g)
+      for (Py_ssize_t k = 0; k < cnt[g]; ++k) src[i++] = g * stride + k;
+  }
+  {
+    const int nt = usable_threads(n, 2048);
+    UnpackJob job = {(const uint32_t*)in.buf, limbs, 0, 0, nd, objs, 0, src};
+    Py_BEGIN_ALLOW_THREADS
+    run_unpack(&job, n, nt);
+    Py_END_ALLOW_THREADS
+    for (Py_ssize_t i = 0; i < n; ++i) {
+      objs[i] = nd[i] == 0 ? PyLong_FromLong(0) : (PyObject*)_PyLong_New(nd[i]);
+      if (!objs[i]) goto done;
+    }
+    job.fill = 1;
+    Py_BEGIN_ALLOW_THREADS
+    run_unpack(&job, n, nt);
+    Py_END_ALLOW_THREADS
+  }
+  {
+    Py_ssize_t i = 0;
+    for (Py_ssize_t g = 0; g < groups; ++g) {
+      PyObject* inner = PyList_New(cnt[g]);
+      if (!inner) goto done;
+      for (Py_ssize_t k = 0; k < cnt[g]; ++k, ++i) { PyList_SET_ITEM(inner, k, objs[i]); objs[i] = NULL; }      /* the reference moves */
+      PyList_SET_ITEM(outer, g, inner);
+    }
+  }
+  ok = 1;
+done:
+  if (objs) for (Py_ssize_t i = 0; i < n; ++i) Py_XDECREF(objs[i]);
+  PyMem_Free(nd);
+  PyMem_Free(src);
+  PyMem_Free(cnt);
+  PyMem_Free(objs);
+  Py_DECREF(counts);
+  PyBuffer_Release(&in);
+  if (!ok) { Py_XDECREF(outer); return NULL; }
+  return outer;
 }
 
 #else /* ---- interpreters with another digit width or int layout: the per-element library routines */
@@ -375,6 +516,10 @@ static PyObject* set_threads(PyObject* self, PyObject* args) {
 static PyMethodDef methods[] = {
     {"pack_into", pack_into, METH_VARARGS, "pack_into(values, limbs, buffer, row_offset): ints -> uint32 rows"},
     {"unpack", unpack, METH_VARARGS, "unpack(buffer, limbs) -> list of ints"},
+#if MX_DIRECT_DIGITS
+    {"pack_nested_into", pack_nested_into, METH_VARARGS, "pack_nested_into(lists, inner, limbs, buffer, row_offset): inner rows per list, zero padded"},
+    {"unpack_groups", unpack_groups, METH_VARARGS, "unpack_groups(buffer, limbs, counts, stride) -> list of lists of ints"},
+#endif
     {"rows_ge", rows_ge, METH_VARARGS, "rows_ge(rows, limbs, moduli_rows, group) -> indices of rows >= their modulus"},
     {"set_threads", set_threads, METH_VARARGS, "set_threads(n) -> previous; 0 = automatic (usable cores, at most 16)"},
     {NULL, NULL, 0, NULL}};

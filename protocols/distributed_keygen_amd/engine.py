@@ -112,12 +112,24 @@ class _VRows:
         return _VRows(self.rows[k * groups * self.keep : (k + 1) * groups * self.keep], self.counts[k * groups : (k + 1) * groups], self.keep)
 
 
+class NestedColumn:
+    """A party's v values for ``Engine.biprime_verdict_columns`` as ONE LIST PER CANDIDATE (what the reference exchanges,
+    distributed_keygen.py:1331-1337) instead of one flat list: each candidate contributes its first n_slots values, zero
+    padded — packed by one codec call without a flattened copy."""
+
+    __slots__ = ("lists",)
+
+    def __init__(self, lists) -> None:
+        self.lists = lists if isinstance(lists, (list, tuple)) else list(lists)
+
+
 class Engine:
     """One engine per process/GPU.  Calls enqueue on ``torch.cuda.current_stream()``; every stream gets
     its own workspace, so one Engine may be driven from several streams (one launch in flight per
     stream).  Not thread-safe (matches the reference's single asyncio thread)."""
 
     MAX_PLANS = 16     # per-key plans kept (a party normally has one key)
+    NestedColumn = NestedColumn      # biprime.py asks the engine it was given for it (the CPU test double has none)
 
     def __init__(self, device: Optional[int] = None) -> None:
         import torch
@@ -805,25 +817,40 @@ class Engine:
             self._pin[which] = buf
         return buf[: rows * limbs].view(rows, limbs)
 
-    def _staged_rows(self, which: str, values: Sequence[int], limbs: int, moduli):
+    def _staged_rows(self, which: str, values, limbs: int, moduli, nested: int = 0):
         """ints -> device rows [len(values), limbs] of their residues (limbs.pack_reduced) through the page-locked buffer
         `which`: packed in place, one asynchronous copy.  The caller synchronises with the stream before it returns (every
-        int-level entry point fetches a result), so the buffer is free again by the time anybody packs into it."""
-        vals = values if isinstance(values, (list, tuple)) else list(values)
-        pin = self._pinned(which, len(vals), limbs)
+        int-level entry point fetches a result), so the buffer is free again by the time anybody packs into it.
+        `nested` = n: `values` is one list per group, every group `n` rows (its first n values, zero padded) —
+        limbs.pack_nested_into, no flattened copy."""
+        if nested:
+            lists = values if isinstance(values, (list, tuple)) else list(values)
+            count = len(lists) * nested
+        else:
+            vals = values if isinstance(values, (list, tuple)) else list(values)
+            count = len(vals)
+        pin = self._pinned(which, count, limbs)
         rows = pin.numpy().view(np.uint32)
         try:
-            _limbs.pack_into(vals, limbs, rows, 0)
+            if nested:
+                _limbs.pack_nested_into(lists, nested, limbs, rows, 0)
+            else:
+                _limbs.pack_into(vals, limbs, rows, 0)
             _limbs.reduce_rows(rows, moduli)
         except ValueError:                              # a value that does not fit the rows, or a negative one
+            if nested:
+                vals = [v for g in lists for v in (list(g)[:nested] + [0] * (nested - min(nested, len(g))))]
             rows[:] = _limbs.pack_reduced(vals, limbs, moduli)
         return pin.to(self.device, non_blocking=True)
 
-    def _fetched_ints(self, which: str, rows_t) -> List[int]:
-        """Device rows -> ints through the page-locked buffer `which` (waits for the current stream)."""
+    def _fetched_ints(self, which: str, rows_t, groups=None):
+        """Device rows -> ints through the page-locked buffer `which` (waits for the current stream).  `groups` =
+        (counts, stride): one list per group instead (limbs.unpack_groups)."""
         pin = self._pinned(which, rows_t.shape[0], rows_t.shape[1])
         pin.copy_(rows_t, non_blocking=True)
         self.torch.cuda.current_stream(self.device).synchronize()
+        if groups is not None:
+            return _limbs.unpack_groups(pin.numpy().view(np.uint32), groups[0], groups[1])
         return _limbs.unpack(pin.numpy().view(np.uint32))
 
     def _pipelined(self, vals: List[int], limbs_in: int, limbs_out: int, launch, modulus: int = 0) -> List[int]:
@@ -1272,21 +1299,12 @@ class Engine:
         if gsize == 0 or keep == 0:
             return ([[] for _ in mods], None) if keep_rows else [[] for _ in mods]
         limbs = _limbs.limbs_for_bits(_limbs.max_bits(mods))
-        if all(len(gs) == gsize for gs in g_values):
-            from itertools import chain
-
-            flat = list(chain.from_iterable(g_values))
-        else:
-            flat = []
-            for gs in g_values:
-                flat.extend(gs)
-                flat.extend([0] * (gsize - len(gs)))      # padding: symbol (0/N) = 0, never selected
-        g_t = self._staged_rows("generators", flat, limbs, mods)
+        # one list per candidate straight into the staging buffer (short lists zero padded: symbol (0/N) = 0, never selected)
+        g_t = self._staged_rows("generators", g_values, limbs, mods, nested=gsize)
         mods_op = mods_rows.operand(self, groups, limbs) if mods_rows is not None else mods
         v_t, cnt_t = self.biprime_v_t(g_t, mods_op, exps, gsize, keep)
-        vals = self._fetched_ints("v", v_t)
         counts = cnt_t.cpu().numpy()
-        lists = [vals[g * keep : g * keep + c] for g, c in enumerate(counts.tolist())]
+        lists = self._fetched_ints("v", v_t, groups=(counts.tolist(), keep))      # per candidate, built in one pass
         return (lists, _VRows(v_t, counts, keep)) if keep_rows else lists
 
     # ------------------------------------------------------------------ sieve
@@ -1444,6 +1462,10 @@ class Engine:
         for col in columns:
             if isinstance(col, _VRows):
                 parts.append(col.slots(self, groups, n_slots, limbs))
+            elif isinstance(col, NestedColumn):
+                if len(col.lists) != groups:
+                    raise ValueError("a party's column needs one list per candidate")
+                parts.append(self._staged_rows(f"column{len(parts)}", col.lists, limbs, mods, nested=n_slots).view(groups, n_slots, limbs))
             else:
                 if len(col) != groups * n_slots:
                     raise ValueError("a party's column needs groups * n_slots values")

@@ -73,6 +73,40 @@ def pack_into(values: Sequence[int], limbs: int, out: np.ndarray, row_offset: in
         raise ValueError(f"value does not fit in {limbs} uint32 limbs (or is negative)") from exc
 
 
+def pack_nested_into(lists: Sequence[Sequence[int]], inner: int, limbs: int, out: np.ndarray, row_offset: int = 0) -> None:
+    """lists[g] -> rows [row_offset + g * inner, row_offset + (g + 1) * inner) of `out`: the first min(len, inner) ints of
+    the list, then zero rows — one list per candidate as the reference holds them (the generator lists of
+    distributed_keygen.py:1313-1329, a party's v lists of :1339-1360), packed without flattening them into one list of
+    references first (230 000 of them in a 65 536-candidate round)."""
+    codec = _codec()
+    if codec is not None and hasattr(codec, "pack_nested_into") and isinstance(lists, (list, tuple)):
+        try:
+            codec.pack_nested_into(lists, inner, limbs, out, row_offset)
+            return
+        except TypeError:
+            pass                                    # int-like elements: the generic path converts them
+    flat: List[int] = []
+    for vals in lists:
+        vals = list(vals)[:inner]
+        flat.extend(vals)
+        flat.extend([0] * (inner - len(vals)))
+    pack_into(flat, limbs, out, row_offset)
+
+
+def unpack_groups(rows: np.ndarray, counts: Sequence[int], stride: int) -> List[List[int]]:
+    """uint32 array [groups * stride, limbs] -> per group the ints of its first counts[g] rows, as lists built in one
+    pass (the v lists of distributed_keygen.py:1103-1108; rows behind a group's count are never turned into ints)."""
+    rows = np.ascontiguousarray(rows, dtype="<u4")
+    counts = [int(c) for c in counts]
+    codec = _codec()
+    if codec is not None and hasattr(codec, "unpack_groups"):
+        return codec.unpack_groups(rows, rows.shape[1], counts, stride) if counts else []
+    vals = unpack(rows)
+    if any(c < 0 or c > stride for c in counts) or len(counts) * stride > len(vals):
+        raise ValueError("a count must lie in 0 .. stride and the rows must hold groups x stride")
+    return [vals[g * stride : g * stride + c] for g, c in enumerate(counts)]
+
+
 def pack(values: Sequence[int], limbs: int) -> np.ndarray:
     """ints (0 <= v < 2^(32*limbs)) -> uint32 array [len(values), limbs]."""
     if not isinstance(values, (list, tuple)):

@@ -730,3 +730,55 @@ def test_an_evicted_plan_stays_readable_for_launches_in_flight_on_every_stream()
     cache.move_to_end("key1")                    # what nsquare_plan / combine_plan do on a hit
     eng._cache_plan(cache, "key17", _Plan(object(), Block(0xA), 0xA, None))
     assert "key1" in cache and "key2" not in cache
+
+
+def test_nested_codec_calls_match_the_flat_ones():
+    """limbs.pack_nested_into / unpack_groups (csrc/mx_pycodec.c): one list per candidate in, one list per candidate out
+    — the same rows and ints as flattening / slicing by hand, for ragged lists, zero padding, empty groups, big and zero
+    values; errors as the flat calls raise them; the pure-Python fallbacks agree."""
+    from protocols.distributed_keygen_amd import limbs as L
+
+    rng = random.Random(606)
+    limbs = 9
+    lists = [[rng.getrandbits(rng.choice([1, 30, 31, 60, 200, 287])) for _ in range(rng.choice([0, 1, 3, 5, 7]))] for _ in range(2500)]
+    lists[3] = [0, (1 << 288) - 1, 1 << 287, 1]
+    inner = 5
+    want_flat = []
+    for vals in lists:
+        want_flat += vals[:inner] + [0] * (inner - min(inner, len(vals)))
+    out = np.full((len(lists) * inner + 2, limbs), 0xAAAAAAAA, dtype="<u4")
+    L.pack_nested_into(lists, inner, limbs, out, 1)
+    assert (out[1:-1] == L.pack(want_flat, limbs)).all() and (out[0] == 0xAAAAAAAA).all() and (out[-1] == 0xAAAAAAAA).all()
+    tuples = tuple(tuple(v) for v in lists[:50])
+    out2 = np.zeros((50 * inner, limbs), dtype="<u4")
+    L.pack_nested_into(tuples, inner, limbs, out2)
+    assert (out2 == out[1:1 + 50 * inner]).all()
+    with pytest.raises(ValueError):
+        L.pack_nested_into([[1 << 288]], 1, limbs, np.zeros((1, limbs), dtype="<u4"))
+    with pytest.raises(ValueError):
+        L.pack_nested_into([[-1]], 1, limbs, np.zeros((1, limbs), dtype="<u4"))
+    with pytest.raises(ValueError):
+        L.pack_nested_into([[1], [2]], 2, limbs, np.zeros((3, limbs), dtype="<u4"))          # buffer too small
+    # groups out
+    rows = L.pack(want_flat, limbs)
+    counts = [min(inner, len(v)) for v in lists]
+    got = L.unpack_groups(rows, counts, inner)
+    assert got == [v[:inner] for v in lists] and all(type(x) is int for g in got for x in g)
+    assert L.unpack_groups(rows[:0], [], inner) == []
+    with pytest.raises(ValueError):
+        L.unpack_groups(rows, [inner + 1] + counts[1:], inner)
+    with pytest.raises(ValueError):
+        L.unpack_groups(rows[: inner * 3], counts[:4], inner)
+    # the fallbacks (an interpreter without the C helper)
+    saved = L._mxcodec
+    try:
+        L._mxcodec = None
+        L._codec_tried = True if hasattr(L, "_codec_tried") else None
+        orig = L._codec
+        L._codec = lambda: None
+        out3 = np.zeros((len(lists) * inner, limbs), dtype="<u4")
+        L.pack_nested_into(lists, inner, limbs, out3)
+        assert (out3 == out[1:-1]).all() and L.unpack_groups(rows, counts, inner) == got
+    finally:
+        L._codec = orig
+        L._mxcodec = saved
