@@ -21,9 +21,10 @@
  *   set_threads(n) -> previous setting                     0 = automatic (usable cores, at most 16)
  *
  * Both directions read / write the digits of the int objects directly (CPython's 30-bit digits) and do the bit
- * shuffling on several threads WITHOUT the interpreter lock: a Python int is immutable and the list the caller passed
- * keeps every element alive for the duration of the call, so its digits can be read from any thread; new ints are
- * allocated under the lock (sizes computed first, in parallel) and filled in parallel before anybody else can see them.
+ * shuffling on several threads that never touch the Python API.  Packing keeps the interpreter lock in the calling
+ * thread (nobody can change the list or free an element meanwhile: no per-element reference counting, see run_pack);
+ * unpacking allocates the new ints under the lock (sizes computed first, in parallel, without it) and fills them in
+ * parallel without it, before anybody else can see them.
  */
 #define PY_SSIZE_T_CLEAN
 #include <Python.h>
@@ -99,14 +100,19 @@ static void* pack_worker(void* arg) {
   return NULL;
 }
 
-/* items[0..n) (NULL = a zero row) -> rows at dst, on several threads without the interpreter lock; the caller holds a
- * reference to every item.  Returns 1, or 0 with a Python exception set. */
+/* items[0..n) (NULL = a zero row) -> rows at dst, on several threads.  The CALLER KEEPS THE INTERPRETER LOCK for the whole
+ * call: the worker threads call nothing of the Python API — they read the size and the digits of immutable int objects —
+ * and while this thread holds the lock no other Python thread can run, so nobody can resize or overwrite the list the
+ * pointers came from or drop the last reference to an element.  (Rounds 4-5 released the lock and therefore took a
+ * reference to every element first and gave it back afterwards: two single-threaded passes that write to the header of
+ * every one of the 330 000 ints of a key-generation round — more than the conversion itself cost.)  Other Python threads
+ * are held up for the milliseconds the conversion takes, like behind any C call that does not release the lock.
+ * Returns 1, or 0 with a Python exception set. */
 static int run_pack(PyObject** items, Py_ssize_t n, uint32_t* dst, Py_ssize_t limbs) {
   const int nt = usable_threads(n, 1024);
   PackJob jobs[16];
   pthread_t tid[16];
   int started[16] = {0};
-  Py_BEGIN_ALLOW_THREADS
   for (int t = 0; t < nt; ++t) {
     jobs[t].items = items; jobs[t].dst = dst; jobs[t].limbs = limbs;
     jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt; jobs[t].bad = -1; jobs[t].bad_kind = 0;
@@ -117,7 +123,6 @@ static int run_pack(PyObject** items, Py_ssize_t n, uint32_t* dst, Py_ssize_t li
     if (started[t]) pthread_join(tid[t], NULL);
     else pack_worker(&jobs[t]); /* thread creation failed: this thread does the slice */
   }
-  Py_END_ALLOW_THREADS
   for (int t = 0; t < nt; ++t) {
     if (jobs[t].bad_kind == 1) { PyErr_SetString(PyExc_TypeError, "values must be ints"); return 0; }
     if (jobs[t].bad_kind == 2) {
@@ -147,17 +152,8 @@ static PyObject* pack_into(PyObject* self, PyObject* args) {
   }
   {
     uint32_t* dst = (uint32_t*)((unsigned char*)out.buf + row_offset * nbytes);
-    /* a private copy of the element pointers, each with a reference of its own: another thread may resize, clear or
-     * overwrite the list while the lock is released, and the workers read the objects' headers and digits */
-    PyObject** items = (PyObject**)PyMem_Malloc((size_t)(n ? n : 1) * sizeof(PyObject*));
-    if (!items) { PyErr_NoMemory(); goto fail; }
-    {
-      PyObject** src = PySequence_Fast_ITEMS(fast);
-      for (Py_ssize_t i = 0; i < n; ++i) { items[i] = src[i]; Py_INCREF(items[i]); }
-    }
-    const int ok = run_pack(items, n, dst, limbs);
-    for (Py_ssize_t i = 0; i < n; ++i) Py_DECREF(items[i]);
-    PyMem_Free(items);
+    /* the element pointers of the list itself: it cannot change while this thread holds the lock (run_pack) */
+    const int ok = run_pack(PySequence_Fast_ITEMS(fast), n, dst, limbs);
     if (!ok) goto fail;
   }
   Py_DECREF(fast);
@@ -180,7 +176,8 @@ static PyObject* pack_nested_into(PyObject* self, PyObject* args) {
   const Py_ssize_t groups = PySequence_Fast_GET_SIZE(fast);
   const Py_ssize_t nbytes = 4 * limbs;
   PyObject** items = NULL;
-  Py_ssize_t n = 0, filled = 0;
+  PyObject* keep = NULL;
+  Py_ssize_t n = 0;
   int ok = 0;
   if (limbs <= 0 || inner <= 0 || row_offset < 0 || groups > (PY_SSIZE_T_MAX / 8) / inner || (row_offset + groups * inner) * nbytes > out.len) {
     PyErr_SetString(PyExc_ValueError, "buffer too small for the rows");
@@ -199,16 +196,20 @@ static PyObject* pack_nested_into(PyObject* self, PyObject* args) {
     Py_ssize_t k = PySequence_Fast_GET_SIZE(in);
     if (k > inner) k = inner;
     PyObject** src = PySequence_Fast_ITEMS(in);
-    for (Py_ssize_t i = 0; i < k; ++i) { items[g * inner + i] = src[i]; Py_INCREF(src[i]); }
-    filled = (g + 1) * inner;
+    /* borrowed pointers: `in` is the inner list / tuple itself, which the outer sequence keeps alive while this thread
+     * holds the lock — or, for another kind of sequence (an iterator's values exist nowhere else), a NEW list, which is
+     * kept until the rows are written */
+    for (Py_ssize_t i = 0; i < k; ++i) items[g * inner + i] = src[i];
+    if (in != PySequence_Fast_GET_ITEM(fast, g)) {
+      if (!keep) keep = PyList_New(0);
+      if (!keep || PyList_Append(keep, in) < 0) { Py_DECREF(in); goto done; }
+    }
     Py_DECREF(in);
   }
   ok = run_pack(items, n, (uint32_t*)((unsigned char*)out.buf + row_offset * nbytes), limbs);
 done:
-  if (items) {
-    for (Py_ssize_t i = 0; i < filled; ++i) Py_XDECREF(items[i]);
-    PyMem_Free(items);
-  }
+  PyMem_Free(items);
+  Py_XDECREF(keep);
   Py_DECREF(fast);
   PyBuffer_Release(&out);
   if (!ok) return NULL;
@@ -458,6 +459,30 @@ static PyObject* unpack(PyObject* self, PyObject* args) {
 }
 #endif
 
+typedef struct { const uint32_t* rows; const uint32_t* mods; Py_ssize_t limbs, group, lo, hi; Py_ssize_t* found; Py_ssize_t nfound, cap; int oom; } GeJob;
+
+static void* ge_worker(void* arg) {
+  GeJob* j = (GeJob*)arg;
+  for (Py_ssize_t e = j->lo; e < j->hi; ++e) {
+    const uint32_t* a = j->rows + e * j->limbs;
+    const uint32_t* b = j->mods + (e / j->group) * j->limbs;
+    int ge = 1; /* equal counts as >= */
+    for (Py_ssize_t w = j->limbs - 1; w >= 0; --w) {
+      if (a[w] != b[w]) { ge = a[w] > b[w]; break; }
+    }
+    if (ge) {
+      if (j->nfound == j->cap) {
+        const Py_ssize_t cap = j->cap ? 2 * j->cap : 64;
+        Py_ssize_t* grown = (Py_ssize_t*)realloc(j->found, (size_t)cap * sizeof(Py_ssize_t));
+        if (!grown) { j->oom = 1; return NULL; }
+        j->found = grown; j->cap = cap;
+      }
+      j->found[j->nfound++] = e;
+    }
+  }
+  return NULL;
+}
+
 /* rows_ge(rows, limbs, moduli_rows, group) -> list of the indices e with rows[e] >= moduli_rows[e / group]
  * (both buffers little-endian uint32 rows of `limbs` words).  Received values are canonical residues already, so the
  * list is normally empty: this replaces a per-group Python / numpy pass over every row in front of each launch. */
@@ -479,21 +504,35 @@ static PyObject* rows_ge(PyObject* self, PyObject* args) {
     }
     out = PyList_New(0);
     if (!out) goto done;
-    const uint32_t* r = (const uint32_t*)rows.buf;
-    const uint32_t* m = (const uint32_t*)mods.buf;
-    for (Py_ssize_t e = 0; e < n; ++e) {
-      const uint32_t* a = r + e * limbs;
-      const uint32_t* b = m + (e / group) * limbs;
-      int ge = 1; /* equal counts as >= */
-      for (Py_ssize_t w = limbs - 1; w >= 0; --w) {
-        if (a[w] != b[w]) { ge = a[w] > b[w]; break; }
-      }
-      if (ge) {
-        PyObject* idx = PyLong_FromSsize_t(e);
-        if (!idx || PyList_Append(out, idx) < 0) { Py_XDECREF(idx); Py_CLEAR(out); goto done; }
-        Py_DECREF(idx);
-      }
+    /* the comparison on several threads (no Python API inside); a thread notes the rows it finds — normally none — in its
+     * own small array, and the list is built here, in ascending order */
+    GeJob jobs[16];
+    pthread_t tid[16];
+    int started[16] = {0};
+    const int nt = usable_threads(n, 8192);
+    Py_BEGIN_ALLOW_THREADS
+    for (int t = 0; t < nt; ++t) {
+      jobs[t].rows = (const uint32_t*)rows.buf; jobs[t].mods = (const uint32_t*)mods.buf; jobs[t].limbs = limbs; jobs[t].group = group;
+      jobs[t].lo = n * t / nt; jobs[t].hi = n * (t + 1) / nt; jobs[t].found = NULL; jobs[t].nfound = 0; jobs[t].cap = 0; jobs[t].oom = 0;
+      if (t > 0) started[t] = pthread_create(&tid[t], NULL, ge_worker, &jobs[t]) == 0;
     }
+    ge_worker(&jobs[0]);
+    for (int t = 1; t < nt; ++t) {
+      if (started[t]) pthread_join(tid[t], NULL);
+      else ge_worker(&jobs[t]);
+    }
+    Py_END_ALLOW_THREADS
+    int failed = 0;
+    for (int t = 0; t < nt; ++t) {
+      if (jobs[t].oom) failed = 1;
+      for (Py_ssize_t k = 0; k < jobs[t].nfound && !failed; ++k) {
+        PyObject* idx = PyLong_FromSsize_t(jobs[t].found[k]);
+        if (!idx || PyList_Append(out, idx) < 0) failed = 1;
+        Py_XDECREF(idx);
+      }
+      free(jobs[t].found);
+    }
+    if (failed) { if (!PyErr_Occurred()) PyErr_NoMemory(); Py_CLEAR(out); }
   }
 done:
   PyBuffer_Release(&rows);

@@ -782,3 +782,39 @@ def test_nested_codec_calls_match_the_flat_ones():
     finally:
         L._codec = orig
         L._mxcodec = saved
+
+
+def test_codec_threads_see_consistent_inputs_and_report_rows_in_order():
+    """csrc/mx_pycodec.c after round 6: packing keeps the interpreter lock and borrows the list's own element pointers (no
+    per-element reference counting) — the values of an ITERATOR, which exist nowhere but in the temporary list the codec
+    builds, must stay alive until the rows are written; rows_ge compares on several threads and still reports ascending
+    indices, however many there are."""
+    from protocols.distributed_keygen_amd import limbs as L
+
+    limbs = 5
+    rng = random.Random(77)
+    # inner sequences that are neither lists nor tuples: generators of FRESH ints (no other reference anywhere)
+    seeds = [rng.getrandbits(150) for _ in range(3000)]
+    gens = [map(lambda k, s=s: s + k, range(4)) for s in seeds]
+    out = np.zeros((3000 * 4, limbs), dtype="<u4")
+    L.pack_nested_into(gens, 4, limbs, out)
+    assert L.unpack(out) == [s + k for s in seeds for k in range(4)]
+    # reference counts of the elements are what they were (nothing leaked, nothing dropped)
+    import sys
+
+    vals = [rng.getrandbits(159) for _ in range(5000)]
+    before = [sys.getrefcount(v) for v in vals[:50]]
+    rows = L.pack(vals, limbs)
+    L.pack_nested_into([vals[:7], vals[7:9]], 7, limbs, np.zeros((14, limbs), dtype="<u4"))
+    assert [sys.getrefcount(v) for v in vals[:50]] == before
+    # rows_ge over 40 000 rows with every third row >= its group's modulus
+    mods = [(1 << 158) + 2 * k + 1 for k in range(400)]
+    group = 100
+    big = [(mods[k // group] + (k % 5)) if k % 3 == 0 else rng.randrange(mods[k // group]) for k in range(len(mods) * group)]
+    rows = L.pack(big, limbs)
+    codec = L._codec()
+    if codec is not None:
+        assert codec.rows_ge(rows, limbs, L.pack(mods, limbs), group) == [k for k in range(len(big)) if k % 3 == 0]
+        assert codec.rows_ge(rows[:0], limbs, L.pack(mods, limbs), group) == []
+    reduced = L.reduce_rows(rows.copy(), mods)
+    assert L.unpack(reduced) == [v % mods[k // group] for k, v in enumerate(big)]
