@@ -65,7 +65,14 @@ MAC_CYCLES, OTHER_CYCLES = 4.19, 2.28       # v_mad_u64_u32 (accumulator form) /
 GUIDE_VECTOR_PEAK = SIMDS * NOMINAL_HZ / 2  # wave-instructions per second if every instruction issued in 2 cycles
 MAC_ISSUE_PEAK = SIMDS * NOMINAL_HZ / MAC_CYCLES
 INSTR_MODEL = ROOT / "profiles" / "r06_instr_model.json"       # tools/calibrate_instr.py (SQ_INSTS_VALU fits) + digest of the kernel sources
-HBM_MEASURED = ROOT / "profiles" / "r05_hbm_traffic.json"      # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
+def _latest_profile(name: str) -> Path:
+    """profiles/r0N_<name> of the latest round that committed one (the per-round measurement files a later round did not
+    repeat stay valid as long as the kernels they describe are the same machine code — see INSTR_MODEL's digest)."""
+    found = sorted((ROOT / "profiles").glob(f"r[0-9][0-9]_{name}"))
+    return found[-1] if found else ROOT / "profiles" / f"r06_{name}"
+
+
+HBM_MEASURED = _latest_profile("hbm_traffic.json")             # tools/hbm_traffic.py (FETCH_SIZE / WRITE_SIZE passes)
 
 
 def parse() -> argparse.Namespace:
@@ -257,7 +264,7 @@ def hbm_block(alg_bytes: float, kernel_ms: float, traffic_model, traffic_key: st
         "algorithmic_bytes_per_launch": alg_bytes,
         "traffic": measured["bytes"] if measured else None,
         "traffic_source": (measured["source"] if measured else
-                           f"no rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass committed for '{traffic_key}' (profiles/r04_hbm_traffic.json)"),
+                           f"no rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE pass committed for '{traffic_key}' ({HBM_MEASURED.name})"),
         "traffic_model": traffic_model,
         "traffic_model_basis": "window-table accesses of the tape x 2 x limbs_per_lane words x lanes, plus the I/O rows "
                                "(an upper bound: L2 hits are not subtracted)",
@@ -1115,7 +1122,7 @@ def leg_keygen_round(eng, torch, args, key_length: int = 2048, n_parties: int = 
 # step.  Instruction counts per launch come from a counter pass of THIS function (tools/short_kernels.py:
 # rocprofv3 --pmc SQ_INSTS_VALU), committed as profiles/r05_short_kernels.json; the durations are measured live.
 # ---------------------------------------------------------------------------------------------------
-SHORT_KERNELS = ROOT / "profiles" / "r05_short_kernels.json"
+SHORT_KERNELS = _latest_profile("short_kernels.json")
 PLAIN_ISSUE_PEAK = SIMDS * NOMINAL_HZ / OTHER_CYCLES
 
 

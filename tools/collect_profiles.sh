@@ -1,7 +1,7 @@
 # usage (in the build container, after `gpurun -- bash tools/gpu_session.sh <tag> profile` merged gpurun_out/prof_<tag>):
 #   bash tools/collect_profiles.sh <tag>
 # Copies the outputs of tools/profile_round.sh into profiles/ under the names profiles/README.md lists.
-tag=${1:-r05}
+tag=${1:-r06}
 O=gpurun_out/prof_$tag; P=profiles
 [ -d $O ] || { echo "no $O"; exit 1; }
 for f in $O/bench_*.json; do cp $f $P/${tag}_$(basename $f); done

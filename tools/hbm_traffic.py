@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Measured HBM traffic per launch from two rocprofv3 --pmc passes (FETCH_SIZE and WRITE_SIZE cannot
-share a pass on gfx950), written to profiles/r05_hbm_traffic.json where bench.py picks it up by key.
+share a pass on gfx950), written to profiles/<PROFILE_TAG, default r06>_hbm_traffic.json where bench.py picks it up by key.
 
 usage: hbm_traffic.py <key> <kernel-name-substring> <fetch_pass_dir> <write_pass_dir> [<last N launches> [<dispatches per launch>]]
 
@@ -21,7 +21,9 @@ import json
 import sys
 from pathlib import Path
 
-OUT = Path(__file__).resolve().parent.parent / "profiles" / "r05_hbm_traffic.json"
+import os
+
+OUT = Path(__file__).resolve().parent.parent / "profiles" / (os.environ.get("PROFILE_TAG", "r06") + "_hbm_traffic.json")
 
 
 def mean_counter(d, kernel_sub, counter, last, per_launch=1):

@@ -2,7 +2,8 @@
 # Runs the bench lines and rocprofv3 passes whose summaries are copied into profiles/ (tools/prof_summary.py,
 # tools/hbm_traffic.py, tools/calibrate_instr.py, tools/sweep_shapes.py).  The library reads no environment; the
 # bench opts into 16 HIP hardware queues itself (protocols.distributed_keygen_amd.configure_hw_queues).
-tag=${1:-r05}
+tag=${1:-r06}
+export PROFILE_TAG=$tag
 export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 O=gpurun_out/prof_$tag; mkdir -p $O
