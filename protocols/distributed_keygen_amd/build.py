@@ -13,7 +13,7 @@ LIB = PKG / "libmxpaillier.so"
 CODEC_SRC = CSRC / "mx_pycodec.c"
 CODEC = PKG / "_mxcodec.so"          # CPython helper: bulk Python int <-> limb rows (host side, no arithmetic)
 SOURCES = [CSRC / "mx_capi.hip", CSRC / "mx_capi_n2.hip", CSRC / "mx_capi_n2w.hip", CSRC / "mx_capi_n2s.hip",
-           CSRC / "mx_capi_n2sw.hip", CSRC / "mx_capi_lat.hip"]
+           CSRC / "mx_capi_n2sw.hip", CSRC / "mx_capi_lat.hip", CSRC / "mx_capi_bip.hip"]
 HEADERS = sorted(CSRC.glob("*.hpp")) + [PKG.parent.parent / "include" / "mxpaillier.h"]
 BUILD_INPUTS = [Path(__file__).resolve(), PKG / "asm_align.py"]      # the build recipe itself
 

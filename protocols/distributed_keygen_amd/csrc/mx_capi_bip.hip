@@ -1,0 +1,24 @@
+// Four-wavefront latency form of the N^2 pair kernel (mx_bipair.hpp): one decrypt(), or a batch small enough to leave most
+// of the chip idle (paillier_shared_key.py:92 at distributed_keygen.py:345-349).  Translation unit of its own, built in
+// parallel with the others; the launcher is called from mx_capi_n2.hip.
+#include "mx_upload.hpp"
+#include "mx_bipair.hpp"
+
+namespace mxb {
+template <int K>
+static int launch(const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s) {
+  const size_t lds = mx::powmod_n2_bipair_lds_bytes<K, LIMB_BITS>();
+  hipLaunchKernelGGL((mx::powmod_n2_bipair_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(256), lds, s, a);
+  MX_HIP(hipGetLastError());
+  return MX_OK;
+}
+// groups of 16 / 32 lanes: moduli of ~800 .. 2700 bits (key_length 1024 and 2048)
+bool n2_bipair_instance(int K) { return K == 16 || K == 32; }
+int launch_n2_bipair(int K, const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s) {
+  switch (K) {
+    case 16: return launch<16>(a, nblocks, s);
+    case 32: return launch<32>(a, nblocks, s);
+  }
+  return MX_ERR_SIZE;
+}
+}  // namespace mxb

@@ -2,6 +2,7 @@
 // compiled in parallel with mx_capi.hip, the pair kernels are the most expensive to build).
 #include "mx_upload.hpp"
 #include "mx_powmod_n2_split.hpp"
+#include "mx_bipair.hpp"
 
 // ---- modexp modulo N^2 through pairs modulo N --------------------------------------------------
 namespace {
@@ -34,6 +35,10 @@ inline int max_lanes(int lpl, int wpg) {
 constexpr int N2_TIMESLICE_MAX_SEGMENTS = mx::N2_TS_LEVELS;      // units per group of a time-sliced launch, at most
 
 bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg, N2Shape& p) {
+  if (wpg == 4) {                                                // the four-wavefront latency form (mx_bipair.hpp) shares the
+    if (limbs_per_lane != LIMBS_PER_LANE_LAT) return false;      // slots of the two-wavefront 3-limb form
+    wpg = 2;
+  }
   if (geo_index(limbs_per_lane) < 0 || (wpg != 1 && wpg != 2)) return false;
   if (!choose_geometry(n_bits, p.geo, limbs_per_lane)) return false;
   if (p.geo.K > max_lanes(limbs_per_lane, wpg)) return false;   // instances that exist
@@ -66,6 +71,11 @@ namespace mxs {
 int launch_n2_split(int K, int L, bool timesliced, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
 int launch_n2_split_wide(int K, bool timesliced, const mx::PowmodN2Args& a, int64_t nblocks, hipStream_t s);
 }
+namespace mxb {
+bool n2_bipair_instance(int K);
+int launch_n2_bipair(int K, const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s);
+}
+namespace mxl { int launch_bisetup(int K, const mx::BiSetupArgs& a, hipStream_t s); }
 namespace {
 int launch_n2(const mx::PowmodN2Args& a, const N2Shape& p, int wpg, hipStream_t s, int64_t timesliced_blocks = 0) {
   const int K = p.geo.K, L = p.geo.L;
@@ -234,6 +244,23 @@ int n2_auto_segments(int n_sqr, int64_t nblocks) {
 inline int64_t n2_consts_words(int limbs_n) { return (int64_t)8 * limbs_n + 2 * (limbs_n + 1); }
 inline int64_t n2_consts_bytes(int limbs_n) { return align256(n2_consts_words(limbs_n) * 4); }
 
+// The four-wavefront latency form (mx_bipair.hpp): exists where the bipartite geometry of the modulus (mx_host.hpp: the
+// pivot, Pd data positions) and the pair kernel's 3-limb geometry agree on lanes and blocks, and the kernel is instantiated.
+bool bipair_geometry(int n_bits, Geometry& gb) {
+  Geometry g3;
+  if (!choose_geometry(n_bits, gb, LIMBS_PER_LANE_BI) || !choose_geometry(n_bits, g3, LIMBS_PER_LANE_LAT)) return false;
+  if (gb.K != g3.K || gb.nblk != g3.nblk || !mxb::n2_bipair_instance(gb.K)) return false;
+  const int pd = gb.L * gb.nblk;
+  return gb.h_lo < pd && LIMB_BITS * (pd - gb.h_lo) < n_bits - 1;      // E = 2^(W (Pd - hL)) is a digit below N
+}
+// its section of a plan's device block, behind the tape: constants for R' = 2^(W hL) | fold rows | quotient rows
+inline int64_t bipair_fold_bytes() { return align256((int64_t)mx::BI_ROWS * 3 * 64 * 4); }
+inline int64_t bipair_quot_bytes() { return align256((int64_t)mx::BP_QROWS * 3 * 64 * 4); }
+inline int64_t bipair_section_bytes(int limbs_n) { return n2_consts_bytes(limbs_n) + bipair_fold_bytes() + bipair_quot_bytes(); }
+inline int64_t bipair_section_offset(int limbs_n) { return N2_GEOS * n2_consts_bytes(limbs_n) + align256((int64_t)MAX_SLIDING_OPS * 4); }
+constexpr int N2_GEO_BIPAIR = 8;      // mx_nsquare_plan::geometries: the plan holds the constants of the four-wavefront form
+
+
 // The eight constant rows of one geometry (R = 2^m), each limbs_n words:
 //   N | ONE0 ONE1 | K1_0 K1_1 | K2_0 K2_1 | C'
 // followed by two rows of limbs_n + 1 words for the passes modulo the friendly multiple N~ = u N, u = -N^-1 mod 2^W
@@ -255,7 +282,7 @@ void n2_constants(u32* c, const u32* h_n, int limbs_n, int m, int k) {
   pair_of(2 * m, 3);          // represents R      (V = R^2)
   pair_of(2 * m + k, 5);      // represents 2^k R  (V = 2^k R^2)
   // C' = N*ceil(R/N) - R + 1 = N - (R mod N) + 1   (R mod N != 0 as N is odd > 1)
-  two_pow_mod(rr.data(), h_n, limbs_n, m);
+  pow2_mod(rr.data(), h_n, limbs_n, m);          // (R below N for the four-wavefront form: R = 2^(W hL))
   u64 borrow = 0, carry = 1;
   u32* cp = &c[(size_t)7 * limbs_n];
   for (int i = 0; i < limbs_n; ++i) {
@@ -292,6 +319,12 @@ extern "C" int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_
                                        int* l, int* w, int* blocks, int* wavefronts) {
   if (!k || !l || !w || !blocks || !wavefronts || batch <= 0) return MX_ERR_ARG;
   if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group == 4) {                         // the four-wavefront latency form: explicit only (mx_bipair.hpp)
+    Geometry gb;
+    if ((limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE_LAT) || !bipair_geometry(n_bits, gb)) return MX_ERR_SIZE;
+    *k = gb.K; *l = gb.L; *w = gb.W; *blocks = gb.nblk; *wavefronts = 4;
+    return MX_OK;
+  }
   if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
   const N2Choice ch = n2_auto_shape(n_bits, batch, limbs_per_lane, wavefronts_per_group);
   N2Shape p;
@@ -328,6 +361,7 @@ extern "C" int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs
                                             int* resident_per_cu, int* units_per_group) {
   if (!resident_per_cu || !units_per_group || batch <= 0) return MX_ERR_ARG;
   if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group == 4) { *resident_per_cu = 0; *units_per_group = 0; return MX_OK; }      // never time-sliced
   if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
   const N2Choice ch = n2_auto_shape(n_bits, batch, limbs_per_lane, wavefronts_per_group);
   N2Shape p;
@@ -341,6 +375,12 @@ extern "C" int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_p
                                           int* k, int* l, int* wavefronts, int* friendly, int* timesliced) {
   if (!k || !l || !wavefronts || !friendly || !timesliced || batch <= 0) return MX_ERR_ARG;
   if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
+  if (wavefronts_per_group == 4) {
+    Geometry gb;
+    if ((limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE_LAT) || !bipair_geometry(n_bits, gb)) return MX_ERR_SIZE;
+    *k = gb.K; *l = gb.L; *wavefronts = 4; *friendly = 1; *timesliced = 0;
+    return MX_OK;
+  }
   if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
   const N2Choice ch = n2_auto_shape(n_bits, batch, limbs_per_lane, wavefronts_per_group);
   N2Shape p;
@@ -393,7 +433,7 @@ extern "C" int mx_nsquare_geometry(int n_bits, int64_t batch, int* k, int* l, in
 
 extern "C" int64_t mx_nsquare_plan_bytes(int limbs_n, int exp_limbs) {
   if (limbs_n <= 0 || exp_limbs <= 0) return MX_ERR_ARG;
-  return N2_GEOS * n2_consts_bytes(limbs_n) + align256((int64_t)MAX_SLIDING_OPS * 4);
+  return bipair_section_offset(limbs_n) + bipair_section_bytes(limbs_n);
 }
 
 extern "C" int mx_powmod_nsquare_prepare(mx_nsquare_plan* plan, const uint32_t* h_n, const uint32_t* h_exp,
@@ -508,6 +548,39 @@ extern "C" int mx_powmod_nsquare_prepare_ex(mx_nsquare_plan* plan, const uint32_
     MX_TRY(upload_words(dp + g * cb, rows[g].data(), rows[g].size(), s));
   }
   MX_TRY(upload_words(dp + N2_GEOS * cb, tape.data(), tape.size(), s));
+  // ---- the four-wavefront latency form (mx_bipair.hpp): constants for R' = 2^(W hL), the fold rows (computed on the
+  // device from N by the bipartite form's setup kernel) and the quotients of the folds, floor(2^(W (Pd + k)) / N)
+  Geometry gb;
+  if (bipair_geometry(bits, gb)) {
+    char* bp = dp + bipair_section_offset(limbs_n);
+    std::vector<u32> rows((size_t)n2_consts_words(limbs_n));
+    n2_constants(rows.data(), h_n, limbs_n, gb.W * gb.h_lo, k);
+    MX_TRY(upload_words(bp, rows.data(), rows.size(), s));
+    const int pd = gb.L * gb.nblk, pw = gb.L * gb.K;
+    std::vector<u32> quot((size_t)mx::BP_QROWS * pw, 0u);
+    for (int r = 0; r < mx::BP_QROWS; ++r) {
+      const int m = gb.W * (pd + r);                            // 2^m / N
+      const int la = m / 32 + 1;
+      std::vector<u32> num(la, 0u), q(la, 0u), rem(limbs_n, 0u);
+      num[m / 32] = 1u << (m % 32);
+      divmod_words(q.data(), rem.data(), num.data(), la, h_n, limbs_n);
+      for (int i = 0; i < pw; ++i) {                            // W-bit limb i of the quotient
+        const int bit = gb.W * i, w0 = bit >> 5, off = bit & 31;
+        u64 v = w0 < la ? q[w0] : 0u;
+        if (w0 + 1 < la) v |= (u64)q[w0 + 1] << 32;
+        quot[(size_t)r * pw + i] = (u32)(v >> off) & ((1u << gb.W) - 1u);
+      }
+      if (bit_length(q.data(), la) > gb.W * pw) return MX_ERR_SIZE;
+    }
+    char* qp = bp + n2_consts_bytes(limbs_n) + bipair_fold_bytes();
+    MX_TRY(upload_words(qp, quot.data(), quot.size(), s));
+    mx::BiSetupArgs sa;
+    sa.mods = (const u32*)bp;                                   // row 0 of the constants: N
+    sa.consts = (u32*)(bp + n2_consts_bytes(limbs_n));
+    sa.groups = 1; sa.limbs = limbs_n; sa.nblk = gb.nblk; sa.pd = pd; sa.h_lo = gb.h_lo;
+    MX_TRY(mxl::launch_bisetup(gb.K, sa, s));
+    geometries |= N2_GEO_BIPAIR;
+  }
   plan->d_plan = d_plan;
   plan->plan_bytes = plan_bytes;
   plan->limbs_n = limbs_n;
@@ -540,10 +613,50 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   if (!plan || !plan->d_plan || !d_bases || !d_out || !d_ws) return MX_ERR_ARG;
   if (limbs2 <= 0 || batch <= 0 || plan->limbs_n <= 0 || plan->ntape <= 0) return MX_ERR_ARG;
   if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
-  if (wavefronts_per_group < 0 || wavefronts_per_group > 2) return MX_ERR_ARG;
+  if (wavefronts_per_group < 0 || (wavefronts_per_group > 2 && wavefronts_per_group != 4)) return MX_ERR_ARG;
   if (segments < 0 || segments > 64) return MX_ERR_ARG;
   const int bits = plan->n_bits;
   if (2 * bits - 1 > 32 * limbs2) return MX_ERR_ARG;          // rows too narrow for N^2
+  if (wavefronts_per_group == 4) {
+    // the four-wavefront latency form: its own kernel for everything in front of the last product, then the last product and
+    // the epilogue as a last segment of the two-wavefront 3-limb kernel, whose slots it shares
+    if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE_LAT) return MX_ERR_ARG;
+    Geometry gb;
+    if (!(plan->geometries & N2_GEO_BIPAIR) || !bipair_geometry(bits, gb)) return MX_ERR_SIZE;
+    N2Shape p;
+    if (!shape_n2(bits, plan->window, batch, LIMBS_PER_LANE_LAT, 2, p)) return MX_ERR_SIZE;
+    if (p.table_bytes > ws_bytes) return MX_ERR_WORKSPACE;
+    if (2 * p.geo.K * p.geo.L + 8 < limbs2 + 2) return MX_ERR_ARG;
+    const int64_t cb = n2_consts_bytes(plan->limbs_n);
+    const char* dp = (const char*)plan->d_plan;
+    const char* bp = dp + bipair_section_offset(plan->limbs_n);
+    hipStream_t s = (hipStream_t)stream;
+    const int pd = gb.L * gb.nblk;
+    mx::PowmodBiPairArgs b;
+    b.bases = d_bases;
+    b.consts = (const u32*)bp;
+    b.fold = (const u32*)(bp + cb);
+    b.quot = (const u32*)(bp + cb + bipair_fold_bytes());
+    b.tape = (const u32*)(dp + N2_GEOS * cb);
+    b.slots = (u32*)d_ws;
+    b.batch = batch; b.nlanes = p.nlanes;
+    b.limbsn = plan->limbs_n; b.limbs2 = limbs2; b.ntape = plan->ntape;
+    b.nblk = gb.nblk; b.pd = pd; b.h_lo = gb.h_lo; b.ksplit = bits - 1;
+    b.nc = 12;                                                 // c < 2^(6 W + 123): at most 11 limbs (the row is zero beyond them)
+    b.pos_end = 0x7FFFFFFF;
+    b.e_pos = pd - gb.h_lo;
+    MxKernelTimer timer(s);
+    MX_TRY(mxb::launch_n2_bipair(gb.K, b, p.nblocks * mx::N2_SPLIT_PAIRS, s));
+    mx::PowmodN2Args a;
+    a.bases = d_bases; a.out = d_out;
+    a.consts = (const u32*)(dp + geo_index(LIMBS_PER_LANE_LAT) * cb);
+    a.tape = b.tape; a.ntape = plan->ntape; a.slots = (u32*)d_ws;
+    a.batch = batch; a.limbsn = plan->limbs_n; a.limbs2 = limbs2; a.nblk = p.geo.nblk; a.ksplit = bits - 1;
+    a.friendly = 1;
+    a.sched = nullptr; a.sched_groups = a.sched_segments = a.sched_n_sqr = 0;
+    a.first = 0; a.last = 1; a.pos_begin = plan->n_sqr + 1; a.pos_end = 0x7FFFFFFF;
+    return launch_n2(a, p, 2, s);
+  }
   const N2Choice ch = n2_auto_shape(bits, batch, limbs_per_lane, wavefronts_per_group);
   N2Shape p;
   if (!shape_n2(bits, plan->window, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
