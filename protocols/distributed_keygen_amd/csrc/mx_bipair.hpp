@@ -52,7 +52,7 @@ struct PowmodBiPairArgs {
   i64 batch, nlanes;
   int limbsn, limbs2, ntape;
   int nblk, pd, h_lo, ksplit;
-  int nc;              // limbs of c
+  int nc;              // limbs of c (at most 11; informational)
   int pos_end;         // tape positions [0, pos_end) belong to this kernel (everything in front of N2_MULC)
   int e_pos;           // E = (2^(W e_pos), 0)
 };
@@ -103,11 +103,34 @@ struct BiHiPair : BiHi<K, W> {
     u32 al[L], rl[L], one = this->onev, one2 = this->onev;
 #pragma unroll
     for (int j = 0; j < L; ++j) { al[j] = ar[j]; rl[j] = this->rf[j]; }
-    for (int i = pd + 2; i >= h_lo; i -= 3) {
+    auto opaque = [&]() {
 #pragma unroll
       for (int j = 0; j < L; ++j) { asm volatile("" : "+v"(al[j])); asm volatile("" : "+v"(rl[j])); }
       asm volatile("" : "+v"(one));
       asm volatile("" : "+v"(one2));
+    };
+    int i = pd + 2;
+    // nine limb steps per trip, the next trip's multiplier limbs fetched behind this trip's work (as BiHi::half)
+    if (i - 8 >= h_lo) {
+      u32 nb[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) nb[k] = B[i - k];
+      for (; i - 8 >= h_lo; i -= 9) {
+        opaque();
+        u32 b[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) b[k] = nb[k];
+        const int nx = i - 17 >= h_lo ? i - 9 : i;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) nb[k] = B[nx - k];
+        u32* vs = V + (i - h_lo);
+        step_rec<SQ, 2>(t, al, rl, one, one2, b[0], vs);     step_rec<SQ, 1>(t, al, rl, one, one2, b[1], vs - 1); step_rec<SQ, 0>(t, al, rl, one, one2, b[2], vs - 2);
+        step_rec<SQ, 2>(t, al, rl, one, one2, b[3], vs - 3); step_rec<SQ, 1>(t, al, rl, one, one2, b[4], vs - 4); step_rec<SQ, 0>(t, al, rl, one, one2, b[5], vs - 5);
+        step_rec<SQ, 2>(t, al, rl, one, one2, b[6], vs - 6); step_rec<SQ, 1>(t, al, rl, one, one2, b[7], vs - 7); step_rec<SQ, 0>(t, al, rl, one, one2, b[8], vs - 8);
+      }
+    }
+    for (; i >= h_lo; i -= 3) {
+      opaque();
       const u32 b2 = B[i], b1 = B[i - 1], b0 = B[i - 2];
       u32* vs = V + (i - h_lo);
       step_rec<SQ, 2>(t, al, rl, one, one2, b2, vs);
@@ -167,11 +190,31 @@ struct BiHiPair : BiHi<K, W> {
     u32 al[L], cl[L], rl[L], one = this->onev, two = twow;
 #pragma unroll
     for (int j = 0; j < L; ++j) { al[j] = ar[j]; cl[j] = cr[j]; rl[j] = this->rf[j]; }
-    for (int i = pd + 2; i >= h_lo; i -= 3) {
+    auto opaque = [&]() {
 #pragma unroll
       for (int j = 0; j < L; ++j) { asm volatile("" : "+v"(al[j])); asm volatile("" : "+v"(rl[j])); if constexpr (TWO) asm volatile("" : "+v"(cl[j])); }
       asm volatile("" : "+v"(one));
       asm volatile("" : "+v"(two));
+    };
+    int i = pd + 2;
+    if (i - 8 >= h_lo) {
+      u32 nb[9], nd[9];
+#pragma unroll
+      for (int k = 0; k < 9; ++k) { nb[k] = B[i - k]; nd[k] = TWO ? D[i - k] : 0u; }
+      for (; i - 8 >= h_lo; i -= 9) {
+        opaque();
+        u32 b[9], d[9];
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { b[k] = nb[k]; d[k] = nd[k]; }
+        const int nx = i - 17 >= h_lo ? i - 9 : i;
+#pragma unroll
+        for (int k = 0; k < 9; ++k) { nb[k] = B[nx - k]; nd[k] = TWO ? D[nx - k] : 0u; }
+#pragma unroll
+        for (int k = 0; k < 9; ++k) step2<TWO, DBL>(t, al, cl, rl, one, two, b[k], d[k]);
+      }
+    }
+    for (; i >= h_lo; i -= 3) {
+      opaque();
       const u32 b2 = B[i], b1 = B[i - 1], b0 = B[i - 2];
       const u32 d2 = TWO ? D[i] : 0u, d1 = TWO ? D[i - 1] : 0u, d0 = TWO ? D[i - 2] : 0u;
       step2<TWO, DBL>(t, al, cl, rl, one, two, b2, d2);
@@ -182,6 +225,12 @@ struct BiHiPair : BiHi<K, W> {
 };
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------------
+#ifdef MX_DEV_BP_TRACE          // developer builds (tools/bp_phase_probe.py): shader-clock cycles per phase and role, workgroup 0
+__device__ u64 mx_bp_trace[16];
+#define MX_BP_MARK(k) { const u64 now_ = __builtin_readcyclecounter(); trc[k] += now_ - mark_; mark_ = now_; }
+#else
+#define MX_BP_MARK(k)
+#endif
 template <int K, int W>
 __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs A) {
   constexpr int L = 3, PW = L * K, GPW = 64 / K;
@@ -189,9 +238,14 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
   using H_t = BiHiPair<K, W>;
   constexpr int ROW = PW + 4;
   static_assert(ROW == M_t::LDS_D, "two rows side by side are the two multipliers of Mont::mulx<F_TWO>");
-  // per group of lanes: CA[2] CB F[2][2] TLA TLB QM[2] V DG QC ST_A ST_B
+  // per group of lanes: CA[2] CB F[2][2] TLA TLB QM[2] V[2] DG[2] QC[2] ST_A ST_B.  A V buffer is VROW words: the fold digits from
+  // word VOFF on, zeros in front of and behind them (wavefront AL reads V[pos - i] for every position of its lanes without
+  // a condition: a conditional read per limb of c was a wait per read, 2400 cycles per product)
+  constexpr int VROW = 2 * ROW, VOFF = 16;
   constexpr int O_CA = 0, O_CB = 2 * ROW, O_F = 3 * ROW, O_TLA = 7 * ROW, O_TLB = 8 * ROW, O_QM = 9 * ROW, O_V = 11 * ROW,
-                O_DG = 12 * ROW, O_QC = O_DG + 8, O_STA = O_QC + ROW, O_STB = O_STA + M_t::LDS_WORDS, GROUP_WORDS = O_STB + M_t::LDS_WORDS;
+                O_DG = O_V + 2 * VROW, O_QC = O_DG + 16, O_STA = O_QC + 2 * ROW, O_STB = O_STA + M_t::LDS_WORDS, GROUP_WORDS = O_STB + M_t::LDS_WORDS;
+  constexpr int NC = 11;         // limbs of c, at most: c <= 2^(W (Pd + 6) - bits + 1) < 2^(6 W + 123)
+  static_assert(VOFF >= NC + 2 && VOFF + 3 * K + 2 <= VROW, "every V[pos - i] lies inside the buffer");
   extern __shared__ u32 smem[];
   const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 AL, 1 AH, 2 BL, 3 BH
   const bool is_l = (role & 1) == 0;                                            // Mont-layout wavefronts
@@ -201,7 +255,7 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
   const int p = lane & (K - 1);
   u32* G = smem + gw * GROUP_WORDS;
   u32* CA = G + O_CA; u32* CB = G + O_CB; u32* F = G + O_F; u32* TLA = G + O_TLA; u32* TLB = G + O_TLB;
-  u32* QM = G + O_QM; u32* V = G + O_V; u32* DG = G + O_DG; u32* QC = G + O_QC;
+  u32* QM = G + O_QM; u32* V = G + O_V; u32* DG = G + O_DG; u32* QC = G + O_QC; u32* QC2 = QC + ROW;
   u32* ST = G + (role == 0 ? O_STA : O_STB);
 
   const i64 slot_id = (i64)blockIdx.x;
@@ -222,6 +276,8 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
   __syncthreads();
   u32 c2p[L];                    // BL: C2' (this lane's limbs)
   u32 cfr[6][L];                 // AL: the final folds' quotients (this lane's limbs)
+  u32 climb[11];                 // AL: the limbs of c (the same in every lane; fetched once — a scalar load per limb and product
+                                 // cost wavefront BL 2700 cycles per slot, profiles/r06_bp_phase_probe.txt)
   if (is_l) {
     M.load(M.n, A.consts, A.limbsn);
     M.setup_modulus();
@@ -233,6 +289,8 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
 #pragma unroll
       for (int j = 0; j < L; ++j) cfr[k][j] = A.quot[k * PW + p * L + j];
     }
+#pragma unroll
+    for (int i = 0; i < 11; ++i) climb[i] = A.quot[6 * PW + i];
   } else {
     H.gather(H.rf, A.fold + 6 * PW);
 #pragma unroll
@@ -275,12 +333,18 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
   // ---- one time slot: the A pair runs pass 1 of product `pa`, the B pair pass 2 of product `pb` (kind 0: none, 1: squaring,
   // 2: multiplication by the pair staged in F[f]); `nx` / `nxf`: a multiplication that follows `pa` directly — its table pair
   // is fetched during this slot and staged in F[nxf] before the slot's last barrier.
+#ifdef MX_DEV_BP_TRACE
+  u64 trc[4] = {0, 0, 0, 0};
+#endif
   int ca = 0;          // CA[ca]: the accumulator's first digit (the A pair's operand), CA[ca ^ 1] receives its product
   int qa = 0;          // QM[qa] receives the quotient digits of the A pair's product
   auto run_slot = [&](int pa, int fa, int pb, int fb, int ca_b, int qb, int nx_slot, int nxf) {
     u64 t[L];
     u32 dg0 = 0;
     u32 ynext[L];
+#ifdef MX_DEV_BP_TRACE
+    u64 mark_ = __builtin_readcyclecounter();
+#endif
     if (is_l && nx_slot >= 0) {
 #pragma unroll
       for (int j = 0; j < L; ++j) ynext[j] = slot_at(nx_slot, j);
@@ -302,11 +366,11 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
       u32 a[L];
       H.gather(a, CA + ca * ROW);
       if (pa == 1) {
-        H.template half_rec<true>(t, a, CA + ca * ROW, A.pd, A.h_lo, V);
+        H.template half_rec<true>(t, a, CA + ca * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
       } else {
-        H.template half_rec<false>(t, a, F + (fa * 2 + 1) * ROW, A.pd, A.h_lo, V);
+        H.template half_rec<false>(t, a, F + (fa * 2 + 1) * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
       }
-      dg0 = H.pre_rec(t, DG);
+      dg0 = H.pre_rec(t, DG + qa * 8);
     } else if (role == 2 && pb) {
       u32 x0[L], x1[L], r[L], qq[L];
 #pragma unroll
@@ -324,7 +388,7 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
         M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_INITQ | M_t::F_STAGED | M_t::F_FRIENDLY>(r, x0, x0, x1, x1, c2p, nullptr, nullptr, nblk_lo, qq);
       }
 #pragma unroll
-      for (int j = 0; j < L; ++j) TLB[p * L + j] = r[j] + QC[p * L + j];
+      for (int j = 0; j < L; ++j) TLB[p * L + j] = r[j] + QC[p * L + j] + QC2[p * L + j];
     } else if (role == 3 && pb) {
       u32 x0[L], x1[L];
       H.gather(x0, CA + ca_b * ROW);
@@ -336,7 +400,9 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
       }
       dg0 = H.pre_rec(t, nullptr);
     }
+    MX_BP_MARK(0)                                    // phase 1: this role's half (+ pre)
     __syncthreads();
+    MX_BP_MARK(1)                                    // waiting for the other halves
     // ---- phase 2
     if (role == 1 && pa) {
       u32 a[L];
@@ -344,46 +410,68 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
     } else if (role == 3 && pb) {
       u32 a[L];
       H.post(t, dg0, TLB, CB, a, A.pd);
-    } else if (role == 0 && pa) {
-      // Qc = c * Vq + sum dg_k cf_k for this lane's positions; dg_0 = wavefront H's own part + wavefront L's limb at Pd
+    } else if (is_l && pa) {
+      // Qc = c * Vq + sum dg_k cf_k of the A pair's product, for this lane's positions, while the H wavefronts finish their
+      // products (the L wavefronts would wait at the barrier otherwise) — split between the two of them so that neither part
+      // outlasts a post: AL the limbs c_0 .. c_(NCA-1) of c, BL the rest and the six final digits; each a batch of reads, its
+      // multiply-accumulates and one carry sweep into a row of its own (QC, QC2), which BL adds to its half of pass 2
+      constexpr int NCA = 7;
+      const u32* Vb = V + qa * VROW + VOFF + p * L;            // V[pos] of this lane's first position
       u64 qc[L];
-      u32 dgv[6];
+      if (role == 0) {
+        u32 vw[NCA + 2];                                       // V[base + 2 - k], k = 0 .. NCA + 1
 #pragma unroll
-      for (int k = 0; k < 6; ++k) dgv[k] = DG[k];
-      dgv[0] += TLA[A.pd];
-#pragma unroll
-      for (int j = 0; j < L; ++j) {
-        u64 s = 0;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-          u32 f = cfr[k][j];
-          asm volatile("" : "+v"(f));
-          s += (u64)f * dgv[k];
-        }
-        qc[j] = s;
-      }
-      const tape_ptr_t crow = (tape_ptr_t)(A.quot + 6 * PW);
-      const int base = p * L;
-      for (int i = 0; i < A.nc; ++i) {
-        const u32 ci = crow[i];
+        for (int k = 0; k < NCA + 2; ++k) vw[k] = Vb[2 - k];
 #pragma unroll
         for (int j = 0; j < L; ++j) {
-          const int idx = base + j - i;
-          const u32 vv = idx >= 0 ? V[idx] : 0u;
-          qc[j] += (u64)ci * vv;
+          u64 sum = 0;
+#pragma unroll
+          for (int i = 0; i < NCA; ++i) {
+            u32 ci = climb[i];
+            asm volatile("" : "+v"(ci));
+            sum += (u64)ci * vw[2 - j + i];                    // V[base + j - i]
+          }
+          qc[j] = sum;
+        }
+      } else {
+        u32 vw[NC - NCA + 2], dgv[6];                          // V[base + 2 - NCA - k]
+#pragma unroll
+        for (int k = 0; k < NC - NCA + 2; ++k) vw[k] = Vb[2 - NCA - k];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) dgv[k] = DG[qa * 8 + k];
+        dgv[0] += TLA[A.pd];                                   // dg_0: wavefront AH's own part + wavefront AL's limb at Pd
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          u64 sum = 0;
+#pragma unroll
+          for (int k = 0; k < 6; ++k) {
+            u32 f = cfr[k][j];
+            asm volatile("" : "+v"(f));
+            sum += (u64)f * dgv[k];
+          }
+#pragma unroll
+          for (int i = NCA; i < NC; ++i) {                     // (limbs of c beyond its length are zero)
+            u32 ci = climb[i];
+            asm volatile("" : "+v"(ci));
+            sum += (u64)ci * vw[2 - j + i - NCA];
+          }
+          qc[j] = sum;
         }
       }
       u32 r[L];
       M.normalize_weak(r, qc);
+      u32* dst = role == 0 ? QC : QC2;
 #pragma unroll
-      for (int j = 0; j < L; ++j) QC[p * L + j] = r[j];
+      for (int j = 0; j < L; ++j) dst[p * L + j] = r[j];
     }
     if (is_l && nx_slot >= 0) {
       // the table pair of the multiplication that follows: digit 0 -> F[nxf][1] (Y0), digit 1 -> F[nxf][0] (Y1)
 #pragma unroll
       for (int j = 0; j < L; ++j) F[(nxf * 2 + (dig == 0 ? 1 : 0)) * ROW + p * L + j] = ynext[j];
     }
+    MX_BP_MARK(2)                                    // phase 2: post (H wavefronts), staging (L wavefronts)
     __syncthreads();
+    MX_BP_MARK(3)                                    // second barrier
   };
 
   // ---- the tape: ONE call site of run_slot (the body holds four roles' code paths; inlined several times it would not fit
@@ -471,13 +559,18 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
 #pragma unroll
     for (int j = 0; j < L; ++j) slot_at(N2_SLOT_CARRY, j) = row[p * L + j];
   }
+#ifdef MX_DEV_BP_TRACE
+  if (blockIdx.x == 0 && lane == 0) {
+    for (int k = 0; k < 4; ++k) mx_bp_trace[role * 4 + k] = trc[k];
+  }
+#endif
 }
 
 template <int K, int W>
 constexpr size_t powmod_n2_bipair_lds_bytes() {
   using M_t = Mont<K, 3, W, true, false>;
   constexpr int ROW = 3 * K + 4;
-  return (size_t)(64 / K) * (12 * ROW + 8 + ROW + 2 * M_t::LDS_WORDS) * 4;
+  return (size_t)(64 / K) * (11 * ROW + 4 * ROW + 16 + 2 * ROW + 2 * M_t::LDS_WORDS) * 4;
 }
 
 }  // namespace mx

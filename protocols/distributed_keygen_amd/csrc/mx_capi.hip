@@ -21,6 +21,7 @@ Knob g_knob_n2_timeslice;
 Knob g_knob_n2_friendly_1w;
 Knob g_knob_generic_latency;
 Knob g_knob_n2_split;
+Knob g_knob_n2_bipair;
 Knob g_knob_jacobi_max_batches;
 Knob g_knob_bi_pivot;
 Knob g_knob_lat_lanes;
@@ -317,7 +318,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 402; }
+int mx_version(void) { return 403; }
 
 const char* mx_error_string(int code) {
   switch (code) {
@@ -342,6 +343,7 @@ int mx_debug_knob(int knob, int value) {
     case MX_KNOB_N2_FRIENDLY_1W: if (value > 1) return MX_ERR_ARG; g_knob_n2_friendly_1w = value; return MX_OK;
     case MX_KNOB_GENERIC_LATENCY: if (value > 2) return MX_ERR_ARG; g_knob_generic_latency = value; return MX_OK;
     case MX_KNOB_N2_SPLIT: if (value > 2) return MX_ERR_ARG; g_knob_n2_split = value; return MX_OK;
+    case MX_KNOB_N2_BIPAIR: if (value > 1) return MX_ERR_ARG; g_knob_n2_bipair = value; return MX_OK;
     case MX_KNOB_BI_PIVOT: if (value > 192) return MX_ERR_ARG; g_knob_bi_pivot = value; return MX_OK;
     case MX_KNOB_LAT_LANES: if (value > 64) return MX_ERR_ARG; g_knob_lat_lanes = value; return MX_OK;
   }

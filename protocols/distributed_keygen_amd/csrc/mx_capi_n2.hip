@@ -217,7 +217,9 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
   if (units) *units = best_units;
   return *resident ? best : plain;
 }
+bool bipair_geometry(int n_bits, Geometry& gb);
 N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
+  if (wpg == 4) return N2Choice{LIMBS_PER_LANE_LAT, 4, 0, 0};      // explicit: the four-wavefront latency form (mx_bipair.hpp)
   N2Choice best{LIMBS_PER_LANE, 1, 0, 0};
   double best_t = -1.0;
   for (int l : N2_LPLS) {
@@ -230,6 +232,14 @@ N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
     }
   }
   if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1, 0, 0};   // reported as MX_ERR_SIZE by the caller
+  // Launches that the two-wavefront latency form would run with at most ONE workgroup of the four-wavefront form per compute
+  // unit take that form where it exists (key_length 1024 / 2048): both passes of every product on two wavefronts each,
+  // 11.3 instead of 12.95 ms for 1 .. 512 ciphertexts at key_length 2048 (tools/bipair_check.py, profiles/r06_bipair_*);
+  // a second workgroup per unit costs more than it saves (1024: 15.0 against 13.4 ms).
+  if (wpg == 0 && best.lpl == LIMBS_PER_LANE_LAT && best.wpg == 2 && g_knob_n2_bipair != 1) {
+    Geometry gb;
+    if (bipair_geometry(n_bits, gb) && batch <= (int64_t)device_cus() * (64 / gb.K)) best.wpg = 4;
+  }
   return best;
 }
 
@@ -617,10 +627,12 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   if (segments < 0 || segments > 64) return MX_ERR_ARG;
   const int bits = plan->n_bits;
   if (2 * bits - 1 > 32 * limbs2) return MX_ERR_ARG;          // rows too narrow for N^2
-  if (wavefronts_per_group == 4) {
+  if (wavefronts_per_group == 4 && limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE_LAT) return MX_ERR_ARG;
+  N2Choice ch = n2_auto_shape(bits, batch, limbs_per_lane, wavefronts_per_group);
+  if (ch.wpg == 4 && wavefronts_per_group != 4 && !(plan->geometries & N2_GEO_BIPAIR)) ch.wpg = 2;      // a plan of an older layout
+  if (ch.wpg == 4) {
     // the four-wavefront latency form: its own kernel for everything in front of the last product, then the last product and
     // the epilogue as a last segment of the two-wavefront 3-limb kernel, whose slots it shares
-    if (limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE_LAT) return MX_ERR_ARG;
     Geometry gb;
     if (!(plan->geometries & N2_GEO_BIPAIR) || !bipair_geometry(bits, gb)) return MX_ERR_SIZE;
     N2Shape p;
@@ -642,7 +654,8 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
     b.batch = batch; b.nlanes = p.nlanes;
     b.limbsn = plan->limbs_n; b.limbs2 = limbs2; b.ntape = plan->ntape;
     b.nblk = gb.nblk; b.pd = pd; b.h_lo = gb.h_lo; b.ksplit = bits - 1;
-    b.nc = 12;                                                 // c < 2^(6 W + 123): at most 11 limbs (the row is zero beyond them)
+    b.nc = (gb.W * (pd + 6) - bits + 1) / gb.W + 1;           // c = floor(2^(W (Pd + 6)) / N) <= 2^(W (Pd + 6) - bits + 1)
+    if (b.nc > 11) return MX_ERR_SIZE;
     b.pos_end = 0x7FFFFFFF;
     b.e_pos = pd - gb.h_lo;
     MxKernelTimer timer(s);
@@ -657,7 +670,6 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
     a.first = 0; a.last = 1; a.pos_begin = plan->n_sqr + 1; a.pos_end = 0x7FFFFFFF;
     return launch_n2(a, p, 2, s);
   }
-  const N2Choice ch = n2_auto_shape(bits, batch, limbs_per_lane, wavefronts_per_group);
   N2Shape p;
   if (!shape_n2(bits, plan->window, batch, ch.lpl, ch.wpg, p)) return MX_ERR_SIZE;
   const int gi = geo_index(ch.lpl);

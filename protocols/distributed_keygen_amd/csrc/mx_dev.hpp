@@ -17,6 +17,8 @@
 //                                   pair and on which XCD it ran (four words behind the queues)
 //   MX_DEV_BI_TRACE                 shader-clock cycles per phase of the bipartite form's        tools/bi_phase_probe.py
 //                                   products, pair 0 of workgroup 0 (mx_bimont.hpp)
+//   MX_DEV_BP_TRACE                 shader-clock cycles per phase and role of the four-wavefront pair    tools/bp_phase_probe.py
+//                                   kernel, workgroup 0 (mx_bipair.hpp)
 //   MX_DEV_PRIVATE_PAD_WORDS=n      every lane of the one-wavefront pair kernel keeps n tagged   tools/concurrency_census.py
 //                                   words in a private segment and checks them at the end
 //   MX_DEV_LDS_PAD_WORDS=n          n more words between the LDS scratch of a wavefront's        tools/lds_stride_ab.sh
@@ -35,7 +37,7 @@
 #define MX_DEV_AUX_WAVE_PRIO 3
 #endif
 
-#if defined(MX_DEV_TS_COMPILER_RELEASE) || defined(MX_DEV_TS_NO_A_FENCE) || defined(MX_DEV_TS_TRACE) || defined(MX_DEV_BI_TRACE) || \
+#if defined(MX_DEV_TS_COMPILER_RELEASE) || defined(MX_DEV_TS_NO_A_FENCE) || defined(MX_DEV_TS_TRACE) || defined(MX_DEV_BI_TRACE) || defined(MX_DEV_BP_TRACE) || \
     defined(MX_DEV_PRIVATE_PAD_WORDS) || MX_DEV_TS_MIN_WAVES != 3 || MX_DEV_LDS_PAD_WORDS != 0 || MX_DEV_AUX_WAVE_PRIO != 3
 #define MX_DEV_BUILD 1          // a developer variant: never the library a release is built from
 #else

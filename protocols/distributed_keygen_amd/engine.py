@@ -316,7 +316,7 @@ class Engine:
     def debug_knob(self, knob: str, value: int) -> None:
         """Developer overrides of the library (include/mxpaillier.h: mx_debug_knob; process-wide, 0 restores
         the default): "n2_segments", "jacobi_max_batches", "n2_timeslice" (1 never, 2 always), "n2_friendly_1w" (1 never)."""
-        ids = {"n2_segments": 1, "jacobi_max_batches": 2, "n2_timeslice": 3, "n2_friendly_1w": 4, "generic_latency": 5, "n2_split": 6, "bi_pivot": 7, "lat_lanes": 8}
+        ids = {"n2_segments": 1, "jacobi_max_batches": 2, "n2_timeslice": 3, "n2_friendly_1w": 4, "generic_latency": 5, "n2_split": 6, "bi_pivot": 7, "lat_lanes": 8, "n2_bipair": 9}
         _lib.check(self.lib.mx_debug_knob(ids[knob], int(value)), "mx_debug_knob")
 
     def cu_slice_streams(self, n: int) -> List[Any]:

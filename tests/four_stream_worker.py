@@ -10,7 +10,7 @@ runtime initialises, so this process calls configure_hw_queues(16) before anythi
 and the page-in of torch again — VERDICT r05 "Next round" 1)
 
 what = "nsquare": powmod_nsquare at key_length 2048 with a full-length exponent in every launch shape (one- and
-two-wavefront groups, 3 / 9 / 18 limbs per lane, time-sliced), 4 x 10 000 rows = 4 x 625 wavefronts of the 18-limb shape
+two-wavefront groups, 3 / 9 / 18 limbs per lane, time-sliced, and the four-wavefront latency form), 4 x 10 000 rows = 4 x 625 wavefronts of the 18-limb shape
 on 1024 SIMDs; "biprime": biprime_v_t (Jacobi filter, selection, generic fixed-window modexps in every lane geometry incl. the
 bipartite latency form) at key_length 2048;
 "jacobi8192": the 257-word Jacobi instance; "k4096": the K = 16 friendly and time-sliced shapes at key_length 4096.
@@ -71,7 +71,7 @@ def main() -> None:
         want = hostpow.powmod_many([(c, exp, n2) for c in cts], pool=pool)
         limbs2 = L.limbs_for(n2)
         c_t, want_t = eng.to_device(L.pack(cts, limbs2)), eng.to_device(L.pack(want, limbs2))
-        shapes = (((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (18, 2, 2), (3, 2, 0)) if what == "nsquare" else
+        shapes = (((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (18, 2, 2), (3, 2, 0), (3, 4, 0)) if what == "nsquare" else
                   ((18, 1, 0), (9, 2, 0), (9, 2, 2), (18, 2, 0), (18, 2, 2)))
         try:
             for lpl, wpg, sliced in shapes:

@@ -11,7 +11,7 @@ Each case: (kind, modulus-root bits, limbs_per_lane argument, batch, exponent bi
 kind "n2": modulus is N^2 for an N of exactly that many bits; "shared" / "multi": modulus of that many bits.
 The pair kernel exists in two forms — ``powmod_n2_kernel`` (one wavefront per group of elements) and
 ``powmod_n2_split_kernel`` (two: mx_powmod_n2_split.hpp) — selected by the sixth field (1 | 2; 0 = the
-library's choice for this batch); both have friendly-modulus instances that the library takes when the modulus leaves
+library's choice for this batch; 4 = the four-wavefront latency form ``powmod_n2_bipair_kernel``, mx_bipair.hpp); both have friendly-modulus instances that the library takes when the modulus leaves
 the room (so the bit length of a case decides the instance), and the two-wavefront kernel has time-sliced instances
 (seventh field 2: forced through the developer knob, as the automatic choice only takes them for batches of several
 thousand).  An instance is the tuple ``mx_nsquare_launch_instance`` reports:
@@ -49,8 +49,11 @@ N2_CASES = [
     # ... and at L = 18, K = 4 and 8 (round 5: what a lone launch just above one workgroup per CU runs, e.g. 10 000 ciphertexts
     # at key_length 2048); batches that leave the last group ragged, more groups than one workgroup's two pairs
     ("n2", 2051, 18, 70, 200, 2, 2), ("n2", 2075, 18, 37, 200, 2, 2), ("n2", 4099, 18, 35, 96, 2, 2),
-    # the library's choice: a handful of elements -> the latency geometry on two wavefronts
-    ("n2", 2051, 0, 7, 64, 0),
+    # FOUR wavefronts per group (round 6, csrc/mx_bipair.hpp: both passes of every pair product bipartite), latency geometry,
+    # K = 16 and 32 (key_length 1024 / 2048); ragged last groups, a modulus that fills its geometry and one that does not
+    ("n2", 1027, 3, 9, 130, 4), ("n2", 1100, 3, 5, 300, 4), ("n2", 2051, 3, 5, 200, 4), ("n2", 1700, 3, 7, 64, 4), ("n2", 2600 - 65, 3, 3, 96, 4),
+    # the library's choice: a handful of elements -> the latency geometry on four wavefronts where that form exists, on two elsewhere
+    ("n2", 2051, 0, 7, 64, 0), ("n2", 4099, 0, 7, 64, 0),
 ]
 
 GENERIC_CASES = [

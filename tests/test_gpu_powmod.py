@@ -463,3 +463,71 @@ def test_bipartite_form_with_moduli_of_different_lengths_in_one_launch(eng):
     finally:
         eng.debug_knob("bi_pivot", 0)
         eng.set_limbs_per_lane(0)
+
+
+@pytest.mark.parametrize("n_bits", [1027, 1029, 2050, 2051, 2053, 1500, 900])
+def test_four_wavefront_latency_form_of_the_pair_kernel(eng, n_bits):
+    """csrc/mx_bipair.hpp (round 6): both passes of every pair product bipartite, four wavefronts per group of elements —
+    what a lone decrypt() and every launch of at most one workgroup per compute unit run at key_length 1024 / 2048.
+    Random and special moduli, bases that are 0 / 1 / multiples of N / N^2 - 1, exponents of 1 bit .. full length (incl. the
+    fixed-window tape), batches from 1 to more than one workgroup per CU: bit for bit CPython pow; the library's own choice
+    takes the form for small batches and the developer knob switches that off."""
+    rng = random.Random(n_bits * 7 + 1)
+    try:
+        for trial, n in enumerate([rng.getrandbits(n_bits) | (1 << (n_bits - 1)) | 1, (1 << n_bits) - 1, (1 << (n_bits - 1)) + 1]):
+            n2 = n * n
+            for ebits, batch in ((1, 3), (2, 1), (3, 5), (64, 2), (300, 70), (n_bits, 9), (2 * n_bits + 90, 4)):
+                e = rng.getrandbits(ebits) | (1 << (ebits - 1))
+                bases = ([0, 1, n, n2 - 1, n + 1, n * (n - 1)] + [rng.randrange(n2) for _ in range(batch)])[:max(batch, 1)]
+                want = [pow(b, e, n2) for b in bases]
+                eng.set_limbs_per_lane(3)
+                eng.set_wavefronts_per_group(4)
+                assert eng.nsquare_launch_shape(n_bits, len(bases))[4] == 4
+                assert eng.powmod_nsquare_batch(bases, e, n) == want, (trial, ebits, batch)
+                if trial == 0 and ebits in (64, n_bits):
+                    eng.set_fixed_window(True)                       # the fixed-window tape through the same kernel
+                    assert eng.powmod_nsquare_batch(bases, e, n) == want
+                    eng.set_fixed_window(False)
+                    eng.set_limbs_per_lane(0)
+                    eng.set_wavefronts_per_group(0)                  # the library's choice for a launch this small: this form
+                    assert eng.nsquare_launch_shape(n_bits, len(bases))[4] == 4
+                    assert eng.powmod_nsquare_batch(bases, e, n) == want
+                    eng.debug_knob("n2_bipair", 1)
+                    assert eng.nsquare_launch_shape(n_bits, len(bases))[4] == 2
+                    assert eng.powmod_nsquare_batch(bases, e, n) == want
+                    eng.debug_knob("n2_bipair", 0)
+        # more than one workgroup per compute unit (the form is then slower than two wavefronts, but must stay right)
+        n = rng.getrandbits(n_bits) | (1 << (n_bits - 1)) | 1
+        bases = [rng.randrange(n * n) for _ in range(1500)]
+        e = rng.getrandbits(40) | 1
+        eng.set_limbs_per_lane(3)
+        eng.set_wavefronts_per_group(4)
+        assert eng.powmod_nsquare_batch(bases, e, n) == [pow(b, e, n * n) for b in bases]
+    finally:
+        eng.set_fixed_window(False)
+        eng.debug_knob("n2_bipair", 0)
+        eng.set_limbs_per_lane(0)
+        eng.set_wavefronts_per_group(0)
+
+
+def test_four_wavefront_form_exists_only_where_its_kernel_does(eng):
+    """Groups of 16 and 32 lanes (moduli of ~700 .. 2700 bits); an explicit request elsewhere is refused, the library's own
+    choice falls back to two wavefronts."""
+    from protocols.distributed_keygen_amd._lib import MxError
+
+    rng = random.Random(3)
+    for n_bits in (300, 4099):
+        n = rng.getrandbits(n_bits) | (1 << (n_bits - 1)) | 1
+        bases = [rng.randrange(n * n) for _ in range(3)]
+        try:
+            eng.set_limbs_per_lane(3)
+            eng.set_wavefronts_per_group(4)
+            with pytest.raises(MxError):
+                eng.powmod_nsquare_batch(bases, 65537, n)
+            eng.set_limbs_per_lane(0)
+            eng.set_wavefronts_per_group(0)
+            assert eng.nsquare_launch_shape(n_bits, 3)[4] == 2
+            assert eng.powmod_nsquare_batch(bases, 65537, n) == [pow(b, 65537, n * n) for b in bases]
+        finally:
+            eng.set_limbs_per_lane(0)
+            eng.set_wavefronts_per_group(0)

@@ -34,7 +34,7 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     # mx_nsquare_launch_split, MX_KNOB_GENERIC_LATENCY / MX_KNOB_N2_SPLIT
     # 4.0: mx_set_limbs_per_lane removed (no process-wide launch-shape state), knobs atomic, mx_powmod_nsquare_prepare_ex
     # with MX_PLAN_FIXED_WINDOW
-    assert lib.mx_version() == 402
+    assert lib.mx_version() == 403
     assert lib.mx_error_string(-3).decode().startswith("modulus")
 
 

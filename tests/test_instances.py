@@ -33,6 +33,7 @@ def test_every_reachable_instance_has_a_parity_case():
         assert {k for _, k, l, w, fr, ts in n2 if l == 18 and w == wpg} == {1, 2, 4, 8, 16}
     assert {k for _, k, l, w, fr, ts in n2 if l == 3 and w == 2} == {1, 2, 4, 8, 16, 32, 64}
     assert not {k for _, k, l, w, fr, ts in n2 if l == 3 and w == 1}     # latency geometries are split only
+    assert {k for _, k, l, w, fr, ts in n2 if w == 4} == {16, 32} and all(l == 3 and fr and not ts for _, k, l, w, fr, ts in n2 if w == 4)   # four-wavefront form (round 6)
     # the friendly-modulus and the time-sliced instances are instances of their own (VERDICT r03 "weak" 1b)
     assert {(k, l, w) for _, k, l, w, fr, ts in n2 if fr and l != 3} == {(8, 9, 2), (16, 9, 2), (4, 18, 1), (8, 18, 1)}
     assert {(k, l, w, fr) for _, k, l, w, fr, ts in n2 if ts} >= {(8, 9, 2, 1), (8, 9, 2, 0), (16, 9, 2, 1)}
@@ -55,13 +56,13 @@ def test_auto_launch_shapes_match_the_measured_crossovers():
 
     lib = _lib.lib()
     shape = lambda bits, batch: ic.case_instance(lib, ("n2", bits, 0, batch, 0, 0))[:4]
-    for batch, want in ((1, (32, 3, 2)), (64, (32, 3, 2)), (1000, (32, 3, 2)), (2000, (32, 3, 2)), (3000, (8, 9, 2)), (4096, (8, 9, 2)),
+    for batch, want in ((1, (32, 3, 4)), (64, (32, 3, 4)), (512, (32, 3, 4)), (513, (32, 3, 2)), (1000, (32, 3, 2)), (2000, (32, 3, 2)), (3000, (8, 9, 2)), (4096, (8, 9, 2)),
                         (6144, (4, 18, 2)), (8192, (4, 18, 2)), (10000, (4, 18, 2)), (12288, (4, 18, 2)), (16384, (4, 18, 1)),
                         (20000, (4, 18, 2)), (24576, (4, 18, 2)), (30000, (4, 18, 1))):
         assert shape(2051, batch) == ("n2",) + want, batch
     for batch, want in ((1, (64, 3, 2)), (512, (64, 3, 2)), (1024, (64, 3, 2)), (2048, (16, 9, 2)), (4096, (8, 18, 2)), (16000, (8, 18, 1))):
         assert shape(4099, batch) == ("n2",) + want, batch
-    assert shape(1027, 256) == ("n2", 16, 3, 2) and shape(1027, 1000000)[3] == 1
+    assert shape(1027, 256) == ("n2", 16, 3, 4) and shape(1027, 1025) == ("n2", 16, 3, 2) and shape(1027, 1000000)[3] == 1
     # an explicit argument pins that half of the choice
     assert ic.case_instance(lib, ("n2", 2051, 18, 10, 0, 0)) == ("n2", 4, 18, 2, 0, 0)
     assert ic.case_instance(lib, ("n2", 2051, 0, 10, 0, 1)) == ("n2", 8, 9, 1, 0, 0)
