@@ -418,45 +418,56 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
       constexpr int NCA = 7;
       const u32* Vb = V + qa * VROW + VOFF + p * L;            // V[pos] of this lane's first position
       u64 qc[L];
+      // (loop-invariant 32-bit multiplicands: opaque IN PLACE once per product, or the compiler keeps their zero-extensions
+      // in register pairs; the reads are issued as one batch — a scheduling barrier keeps them in front of their uses, with
+      // the reads sunk to their uses every one of them was a wait of its own)
+#pragma unroll
+      for (int i = 0; i < NC; ++i) asm volatile("" : "+v"(climb[i]));
       if (role == 0) {
         u32 vw[NCA + 2];                                       // V[base + 2 - k], k = 0 .. NCA + 1
 #pragma unroll
         for (int k = 0; k < NCA + 2; ++k) vw[k] = Vb[2 - k];
+        __builtin_amdgcn_sched_barrier(0);
+        // (six independent chains — two per column, limb-major: a lone wavefront waits for every dependent multiply-accumulate)
+        u64 ev[L] = {0, 0, 0}, od[L] = {0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
-          u64 sum = 0;
+        for (int i = 0; i < NCA; ++i) {
 #pragma unroll
-          for (int i = 0; i < NCA; ++i) {
-            u32 ci = climb[i];
-            asm volatile("" : "+v"(ci));
-            sum += (u64)ci * vw[2 - j + i];                    // V[base + j - i]
+          for (int j = 0; j < L; ++j) {
+            if (i & 1) od[j] += (u64)climb[i] * vw[2 - j + i];                     // V[base + j - i]
+            else ev[j] += (u64)climb[i] * vw[2 - j + i];
           }
-          qc[j] = sum;
         }
+#pragma unroll
+        for (int j = 0; j < L; ++j) qc[j] = ev[j] + od[j];
       } else {
         u32 vw[NC - NCA + 2], dgv[6];                          // V[base + 2 - NCA - k]
 #pragma unroll
         for (int k = 0; k < NC - NCA + 2; ++k) vw[k] = Vb[2 - NCA - k];
 #pragma unroll
         for (int k = 0; k < 6; ++k) dgv[k] = DG[qa * 8 + k];
-        dgv[0] += TLA[A.pd];                                   // dg_0: wavefront AH's own part + wavefront AL's limb at Pd
+        const u32 tl_pd = TLA[A.pd];
+        __builtin_amdgcn_sched_barrier(0);
+        dgv[0] += tl_pd;                                       // dg_0: wavefront AH's own part + wavefront AL's limb at Pd
+        u64 ev[L] = {0, 0, 0}, od[L] = {0, 0, 0};
 #pragma unroll
-        for (int j = 0; j < L; ++j) {
-          u64 sum = 0;
+        for (int k = 0; k < 6; ++k) {
 #pragma unroll
-          for (int k = 0; k < 6; ++k) {
-            u32 f = cfr[k][j];
-            asm volatile("" : "+v"(f));
-            sum += (u64)f * dgv[k];
+          for (int j = 0; j < L; ++j) {
+            if (k & 1) od[j] += (u64)cfr[k][j] * dgv[k];
+            else ev[j] += (u64)cfr[k][j] * dgv[k];
           }
-#pragma unroll
-          for (int i = NCA; i < NC; ++i) {                     // (limbs of c beyond its length are zero)
-            u32 ci = climb[i];
-            asm volatile("" : "+v"(ci));
-            sum += (u64)ci * vw[2 - j + i - NCA];
-          }
-          qc[j] = sum;
         }
+#pragma unroll
+        for (int i = NCA; i < NC; ++i) {                                           // (limbs of c beyond its length are zero)
+#pragma unroll
+          for (int j = 0; j < L; ++j) {
+            if (i & 1) od[j] += (u64)climb[i] * vw[2 - j + i - NCA];
+            else ev[j] += (u64)climb[i] * vw[2 - j + i - NCA];
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < L; ++j) qc[j] = ev[j] + od[j];
       }
       u32 r[L];
       M.normalize_weak(r, qc);
