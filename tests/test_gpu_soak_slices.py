@@ -46,3 +46,14 @@ def test_timesliced_soak_slice(eng, seed, launches):
     done, rows, by_shape = soak_timesliced.soak(eng, seed, launches_limit=launches)
     assert done >= launches and rows > 0
     assert any(form == "sliced" for (_l, _k, form) in by_shape), by_shape
+
+
+@pytest.mark.parametrize("seed,rounds", [(3, 40), (29, 40)])
+def test_bipair_soak_slice(eng, seed, rounds):
+    """The four-wavefront latency form of the pair kernel (csrc/mx_bipair.hpp) over random modulus lengths of its whole range,
+    special moduli and bases, exponents of 1 bit .. full length, sliding and fixed-window tapes, batches of 1 .. 700, now and
+    then two launches at once: every result against CPython pow."""
+    import soak_bipair
+
+    done_rounds, modexps = soak_bipair.soak(eng, seed, rounds_limit=rounds)
+    assert done_rounds == rounds and modexps > 0
