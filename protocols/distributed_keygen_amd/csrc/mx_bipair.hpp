@@ -74,7 +74,9 @@ struct BiHiPair : BiHi<K, W> {
     asm volatile("" : "+v"(twow));
   }
 
-  // ---- pass 1: BiHi::half with the fold digit of every step written to V[i - h_lo] (all lanes of the group hold it)
+  // ---- pass 1: BiHi::half with the fold digit of every step written to V[i - h_lo] (all lanes of the group hold it; the
+  // compiler pairs the stores of neighbouring steps.  Recording costs wavefront AH 270 of its 4100 cycles per product;
+  // stores deferred to the end of a trip and made by one lane of the group came out 210 cycles slower)
   template <bool SQ, int I3>
   __device__ __forceinline__ void step_rec(u64 (&t)[L], const u32 (&ar)[L], const u32 (&rf)[L], u32 onev, u32 onew, u32 bi, u32* vslot) const {
     const u64 out = t[0];
@@ -109,12 +111,22 @@ struct BiHiPair : BiHi<K, W> {
       asm volatile("" : "+v"(one));
       asm volatile("" : "+v"(one2));
     };
-    int i = pd + 2;
+    // The chain opens at limb Pd: the multiplier limbs at Pd + 1 and Pd + 2 are zero in every row this kernel multiplies by
+    // (a product leaves at most 4 at Pd and nothing above it, constants and the halves of x end below Pd;
+    // tools/bipair_model.py asserts it), so the two steps BiHi::half spends on an empty accumulator are not run — 2 of
+    // 39 at key_length 2048 — and their fold digits stay the zeros the V buffers were cleared to.
+    int i = pd - 1;
     // nine limb steps per trip, the next trip's multiplier limbs fetched behind this trip's work (as BiHi::half)
-    if (i - 8 >= h_lo) {
-      u32 nb[9];
+    const bool trips = i - 8 >= h_lo;
+    u32 nb[9];
+    const u32 btop = B[pd];
+    if (trips) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) nb[k] = B[i - k];
+    }
+    opaque();
+    step_rec<SQ, 0>(t, al, rl, one, one2, btop, V + (pd - h_lo));
+    if (trips) {
       for (; i - 8 >= h_lo; i -= 9) {
         opaque();
         u32 b[9];
@@ -164,6 +176,30 @@ struct BiHiPair : BiHi<K, W> {
     return dg[0];
   }
 
+  // BiHi::post with a second row beside the L half's (pass 2: the quotient correction Qc, wavefront Q's row): both are read
+  // at the same words and under the same masks, the limb at Pd of their sum is the digit the last fold takes
+  __device__ __forceinline__ void post_sum(u64 (&t)[L], u32 dg0, const u32* TL, const u32* QR, u32* C, u32 (&ar)[L], int pd) const {
+    u32 tl[L], qr[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) { tl[j] = TL[this->addr[j]]; qr[j] = QR[this->addr[j]]; }
+    const u32 d = dg0 + TL[pd] + QR[pd];        // every lane reads the same words
+#pragma unroll
+    for (int j = 0; j < L; ++j) t[j] += (u64)((tl[j] + qr[j]) & this->data_ok[j]);
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      u32 f = this->fin[0][j];
+      asm volatile("" : "+v"(f));
+      t[j] += (u64)f * d;
+    }
+    u32 r[L];
+    this->template sweep<false>(r, t);
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      ar[j] = r[j] & this->pos_ok[j];
+      C[this->waddr[j]] = r[j];
+    }
+  }
+
   // ---- pass 2: one or two product rows, a column crosses to the lane above as 30 bits + a carry word of weight 2
   template <bool TWO, bool DBL>
   __device__ __forceinline__ void step2(u64 (&t)[L], const u32 (&ar)[L], const u32 (&cr)[L], const u32 (&rf)[L], u32 onev, u32 two, u32 bi, u32 di) const {
@@ -196,11 +232,17 @@ struct BiHiPair : BiHi<K, W> {
       asm volatile("" : "+v"(one));
       asm volatile("" : "+v"(two));
     };
-    int i = pd + 2;
-    if (i - 8 >= h_lo) {
-      u32 nb[9], nd[9];
+    int i = pd - 1;                 // (the chain opens at limb Pd, as in half_rec)
+    const bool trips = i - 8 >= h_lo;
+    u32 nb[9], nd[9];
+    const u32 btop = B[pd], dtop = TWO ? D[pd] : 0u;
+    if (trips) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) { nb[k] = B[i - k]; nd[k] = TWO ? D[i - k] : 0u; }
+    }
+    opaque();
+    step2<TWO, DBL>(t, al, cl, rl, one, two, btop, dtop);
+    if (trips) {
       for (; i - 8 >= h_lo; i -= 9) {
         opaque();
         u32 b[9], d[9];
@@ -226,13 +268,14 @@ struct BiHiPair : BiHi<K, W> {
 
 // ---- the kernel ------------------------------------------------------------------------------------------------------------------
 #ifdef MX_DEV_BP_TRACE          // developer builds (tools/bp_phase_probe.py): shader-clock cycles per phase and role, workgroup 0
-__device__ u64 mx_bp_trace[16];
+__device__ u64 mx_bp_trace[25];
 #define MX_BP_MARK(k) { const u64 now_ = __builtin_readcyclecounter(); trc[k] += now_ - mark_; mark_ = now_; }
 #else
 #define MX_BP_MARK(k)
 #endif
+constexpr int BP_THREADS = 320;   // five wavefronts: AL AH BL BH and Q (the quotient correction, one product behind the A pair)
 template <int K, int W>
-__global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs A) {
+__global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPairArgs A) {
   constexpr int L = 3, PW = L * K, GPW = 64 / K;
   using M_t = Mont<K, L, W, true, false>;
   using H_t = BiHiPair<K, W>;
@@ -247,15 +290,16 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
   constexpr int NC = 11;         // limbs of c, at most: c <= 2^(W (Pd + 6) - bits + 1) < 2^(6 W + 123)
   static_assert(VOFF >= NC + 2 && VOFF + 3 * K + 2 <= VROW, "every V[pos - i] lies inside the buffer");
   extern __shared__ u32 smem[];
-  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 AL, 1 AH, 2 BL, 3 BH
-  const bool is_l = (role & 1) == 0;                                            // Mont-layout wavefronts
+  const int role = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));     // 0 AL, 1 AH, 2 BL, 3 BH, 4 Q
+  const bool is_l = role == 0 || role == 2;                                     // Mont-layout wavefronts of the pairs
+  const bool is_q = role == 4;
   const bool is_a = role < 2;
   const int lane = threadIdx.x & 63;
   const int gw = lane / K;
   const int p = lane & (K - 1);
   u32* G = smem + gw * GROUP_WORDS;
   u32* CA = G + O_CA; u32* CB = G + O_CB; u32* F = G + O_F; u32* TLA = G + O_TLA; u32* TLB = G + O_TLB;
-  u32* QM = G + O_QM; u32* V = G + O_V; u32* DG = G + O_DG; u32* QC = G + O_QC; u32* QC2 = QC + ROW;
+  u32* QM = G + O_QM; u32* V = G + O_V; u32* DG = G + O_DG; u32* QC = G + O_QC;
   u32* ST = G + (role == 0 ? O_STA : O_STB);
 
   const i64 slot_id = (i64)blockIdx.x;
@@ -272,18 +316,13 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
   H.init(A.pd);
   H.init2();
   // zero every row once (positions beyond a number's top are read as zero limbs)
-  for (int k = threadIdx.x; k < GPW * GROUP_WORDS; k += 256) smem[k] = 0;
+  for (int k = threadIdx.x; k < GPW * GROUP_WORDS; k += BP_THREADS) smem[k] = 0;
   __syncthreads();
   u32 c2p[L];                    // BL: C2' (this lane's limbs)
-  u32 cfr[6][L];                 // AL: the final folds' quotients (this lane's limbs)
-  u32 climb[11];                 // AL: the limbs of c (the same in every lane; fetched once — a scalar load per limb and product
-                                 // cost wavefront BL 2700 cycles per slot, profiles/r06_bp_phase_probe.txt)
-  if (is_l) {
-    M.load(M.n, A.consts, A.limbsn);
-    M.setup_modulus();
-    M.load(M.nf, A.consts + 8 * A.limbsn, A.limbsn + 1);
-    M.setup_friendly();
-    M.load(c2p, A.consts + 8 * A.limbsn + (A.limbsn + 1), A.limbsn + 1);
+  u32 cfr[6][L];                 // Q: the final folds' quotients (this lane's limbs)
+  u32 climb[11];                 // Q: the limbs of c (the same in every lane; fetched once — a scalar load per limb and product
+                                 // cost 2700 cycles per slot, profiles/r06_bp_phase_probe.txt)
+  if (is_l || is_q) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
 #pragma unroll
@@ -291,6 +330,11 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
     }
 #pragma unroll
     for (int i = 0; i < 11; ++i) climb[i] = A.quot[6 * PW + i];
+    M.load(M.n, A.consts, A.limbsn);
+    M.setup_modulus();
+    M.load(M.nf, A.consts + 8 * A.limbsn, A.limbsn + 1);
+    M.setup_friendly();
+    M.load(c2p, A.consts + 8 * A.limbsn + (A.limbsn + 1), A.limbsn + 1);
   } else {
     H.gather(H.rf, A.fold + 6 * PW);
 #pragma unroll
@@ -335,6 +379,7 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
   // is fetched during this slot and staged in F[nxf] before the slot's last barrier.
 #ifdef MX_DEV_BP_TRACE
   u64 trc[4] = {0, 0, 0, 0};
+  const u64 trc_begin = __builtin_readcyclecounter();     // (behind the prologue)
 #endif
   int ca = 0;          // CA[ca]: the accumulator's first digit (the A pair's operand), CA[ca ^ 1] receives its product
   int qa = 0;          // QM[qa] receives the quotient digits of the A pair's product
@@ -350,7 +395,26 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
       for (int j = 0; j < L; ++j) ynext[j] = slot_at(nx_slot, j);
     }
     // ---- phase 1
-    if (role == 0 && pa) {
+    if (role == 1 && pa) {                   // (the H wavefronts first: theirs is the longest path of a slot)
+      u32 a[L];
+      H.gather(a, CA + ca * ROW);
+      if (pa == 1) {
+        H.template half_rec<true>(t, a, CA + ca * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
+      } else {
+        H.template half_rec<false>(t, a, F + (fa * 2 + 1) * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
+      }
+      dg0 = H.pre_rec(t, DG + qa * 8);
+    } else if (role == 3 && pb) {
+      u32 x0[L], x1[L];
+      H.gather(x0, CA + ca_b * ROW);
+      H.gather(x1, CB);
+      if (pb == 1) {
+        H.template half2<false, true>(t, x0, x0, CB, CB, A.pd, A.h_lo);          // 2 X0 X1: multiplier limb doubled
+      } else {
+        H.template half2<true, false>(t, x0, x1, F + fb * 2 * ROW, F + (fb * 2 + 1) * ROW, A.pd, A.h_lo);
+      }
+      dg0 = H.pre_rec(t, nullptr);
+    } else if (role == 0 && pa) {
       u32 a[L], r[L], q[L];
 #pragma unroll
       for (int j = 0; j < L; ++j) a[j] = CA[ca * ROW + p * L + j];
@@ -361,16 +425,11 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
         M.template mulx<M_t::F_FRIENDLY | M_t::F_STAGED | M_t::F_RECORD_Q>(r, a, a, a, a, a, q, nullptr, nblk_lo);
       }
 #pragma unroll
-      for (int j = 0; j < L; ++j) { TLA[p * L + j] = r[j]; QM[qa * ROW + p * L + j] = q[j]; }
-    } else if (role == 1 && pa) {
-      u32 a[L];
-      H.gather(a, CA + ca * ROW);
-      if (pa == 1) {
-        H.template half_rec<true>(t, a, CA + ca * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
-      } else {
-        H.template half_rec<false>(t, a, F + (fa * 2 + 1) * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
+      for (int j = 0; j < L; ++j) {
+        TLA[p * L + j] = r[j];
+        QM[qa * ROW + p * L + j] = q[j];
+        if (p * L + j == A.pd) DG[qa * 8 + 6] = r[j];          // (TLA is this wavefront's again before Q reads it)
       }
-      dg0 = H.pre_rec(t, DG + qa * 8);
     } else if (role == 2 && pb) {
       u32 x0[L], x1[L], r[L], qq[L];
 #pragma unroll
@@ -388,17 +447,50 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
         M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_INITQ | M_t::F_STAGED | M_t::F_FRIENDLY>(r, x0, x0, x1, x1, c2p, nullptr, nullptr, nblk_lo, qq);
       }
 #pragma unroll
-      for (int j = 0; j < L; ++j) TLB[p * L + j] = r[j] + QC[p * L + j] + QC2[p * L + j];
-    } else if (role == 3 && pb) {
-      u32 x0[L], x1[L];
-      H.gather(x0, CA + ca_b * ROW);
-      H.gather(x1, CB);
-      if (pb == 1) {
-        H.template half2<false, true>(t, x0, x0, CB, CB, A.pd, A.h_lo);          // 2 X0 X1: multiplier limb doubled
-      } else {
-        H.template half2<true, false>(t, x0, x1, F + fb * 2 * ROW, F + (fb * 2 + 1) * ROW, A.pd, A.h_lo);
+      for (int j = 0; j < L; ++j) TLB[p * L + j] = r[j];
+    } else if (is_q && pb) {
+      // Qc = c * Vq + sum dg_k cf_k of the product whose pass 2 the B pair runs in this slot, for this lane's positions: from
+      // the digits its pass 1 recorded one slot ago (V, DG: double buffers) into the row QC that wavefront BH adds in its post.
+      // (Rounds of this work by the L wavefronts between the barriers cost 840 cycles of every slot, a lone wavefront issuing
+      // an instruction every five cycles; a wavefront of its own has a whole phase for them.)
+      const u32* Vb = V + qb * VROW + VOFF + p * L;            // V[pos] of this lane's first position
+      // (loop-invariant 32-bit multiplicands: opaque IN PLACE once per product, or the compiler keeps their zero-extensions
+      // in register pairs; the reads are issued as one batch — a scheduling barrier keeps them in front of their uses)
+#pragma unroll
+      for (int i = 0; i < NC; ++i) asm volatile("" : "+v"(climb[i]));
+      u32 vw[NC + 2], dgv[6];                                  // V[base + 2 - k], k = 0 .. NC + 1
+#pragma unroll
+      for (int k = 0; k < NC + 2; ++k) vw[k] = Vb[2 - k];
+#pragma unroll
+      for (int k = 0; k < 6; ++k) dgv[k] = DG[qb * 8 + k];
+      const u32 tl_pd = DG[qb * 8 + 6];
+      __builtin_amdgcn_sched_barrier(0);
+      dgv[0] += tl_pd;                                         // dg_0: wavefront AH's own part + wavefront AL's limb at Pd
+      // (six independent chains — two per column: a lone wavefront waits for every dependent multiply-accumulate)
+      u64 ev[L] = {0, 0, 0}, od[L] = {0, 0, 0};
+#pragma unroll
+      for (int k = 0; k < 6; ++k) {
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          if (k & 1) od[j] += (u64)cfr[k][j] * dgv[k];
+          else ev[j] += (u64)cfr[k][j] * dgv[k];
+        }
       }
-      dg0 = H.pre_rec(t, nullptr);
+#pragma unroll
+      for (int i = 0; i < NC; ++i) {                                               // (limbs of c beyond its length are zero)
+#pragma unroll
+        for (int j = 0; j < L; ++j) {
+          if (i & 1) od[j] += (u64)climb[i] * vw[2 - j + i];                       // V[base + j - i]
+          else ev[j] += (u64)climb[i] * vw[2 - j + i];
+        }
+      }
+      u64 qc[L];
+#pragma unroll
+      for (int j = 0; j < L; ++j) qc[j] = ev[j] + od[j];
+      u32 r[L];
+      M.normalize_weak(r, qc);
+#pragma unroll
+      for (int j = 0; j < L; ++j) QC[p * L + j] = r[j];
     }
     MX_BP_MARK(0)                                    // phase 1: this role's half (+ pre)
     __syncthreads();
@@ -409,71 +501,7 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
       H.post(t, dg0, TLA, CA + (ca ^ 1) * ROW, a, A.pd);
     } else if (role == 3 && pb) {
       u32 a[L];
-      H.post(t, dg0, TLB, CB, a, A.pd);
-    } else if (is_l && pa) {
-      // Qc = c * Vq + sum dg_k cf_k of the A pair's product, for this lane's positions, while the H wavefronts finish their
-      // products (the L wavefronts would wait at the barrier otherwise) — split between the two of them so that neither part
-      // outlasts a post: AL the limbs c_0 .. c_(NCA-1) of c, BL the rest and the six final digits; each a batch of reads, its
-      // multiply-accumulates and one carry sweep into a row of its own (QC, QC2), which BL adds to its half of pass 2
-      constexpr int NCA = 7;
-      const u32* Vb = V + qa * VROW + VOFF + p * L;            // V[pos] of this lane's first position
-      u64 qc[L];
-      // (loop-invariant 32-bit multiplicands: opaque IN PLACE once per product, or the compiler keeps their zero-extensions
-      // in register pairs; the reads are issued as one batch — a scheduling barrier keeps them in front of their uses, with
-      // the reads sunk to their uses every one of them was a wait of its own)
-#pragma unroll
-      for (int i = 0; i < NC; ++i) asm volatile("" : "+v"(climb[i]));
-      if (role == 0) {
-        u32 vw[NCA + 2];                                       // V[base + 2 - k], k = 0 .. NCA + 1
-#pragma unroll
-        for (int k = 0; k < NCA + 2; ++k) vw[k] = Vb[2 - k];
-        __builtin_amdgcn_sched_barrier(0);
-        // (six independent chains — two per column, limb-major: a lone wavefront waits for every dependent multiply-accumulate)
-        u64 ev[L] = {0, 0, 0}, od[L] = {0, 0, 0};
-#pragma unroll
-        for (int i = 0; i < NCA; ++i) {
-#pragma unroll
-          for (int j = 0; j < L; ++j) {
-            if (i & 1) od[j] += (u64)climb[i] * vw[2 - j + i];                     // V[base + j - i]
-            else ev[j] += (u64)climb[i] * vw[2 - j + i];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < L; ++j) qc[j] = ev[j] + od[j];
-      } else {
-        u32 vw[NC - NCA + 2], dgv[6];                          // V[base + 2 - NCA - k]
-#pragma unroll
-        for (int k = 0; k < NC - NCA + 2; ++k) vw[k] = Vb[2 - NCA - k];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) dgv[k] = DG[qa * 8 + k];
-        const u32 tl_pd = TLA[A.pd];
-        __builtin_amdgcn_sched_barrier(0);
-        dgv[0] += tl_pd;                                       // dg_0: wavefront AH's own part + wavefront AL's limb at Pd
-        u64 ev[L] = {0, 0, 0}, od[L] = {0, 0, 0};
-#pragma unroll
-        for (int k = 0; k < 6; ++k) {
-#pragma unroll
-          for (int j = 0; j < L; ++j) {
-            if (k & 1) od[j] += (u64)cfr[k][j] * dgv[k];
-            else ev[j] += (u64)cfr[k][j] * dgv[k];
-          }
-        }
-#pragma unroll
-        for (int i = NCA; i < NC; ++i) {                                           // (limbs of c beyond its length are zero)
-#pragma unroll
-          for (int j = 0; j < L; ++j) {
-            if (i & 1) od[j] += (u64)climb[i] * vw[2 - j + i - NCA];
-            else ev[j] += (u64)climb[i] * vw[2 - j + i - NCA];
-          }
-        }
-#pragma unroll
-        for (int j = 0; j < L; ++j) qc[j] = ev[j] + od[j];
-      }
-      u32 r[L];
-      M.normalize_weak(r, qc);
-      u32* dst = role == 0 ? QC : QC2;
-#pragma unroll
-      for (int j = 0; j < L; ++j) dst[p * L + j] = r[j];
+      H.post_sum(t, dg0, TLB, QC, CB, a, A.pd);
     }
     if (is_l && nx_slot >= 0) {
       // the table pair of the multiplication that follows: digit 0 -> F[nxf][1] (Y0), digit 1 -> F[nxf][0] (Y1)
@@ -573,6 +601,7 @@ __global__ void __launch_bounds__(256) powmod_n2_bipair_kernel(PowmodBiPairArgs 
 #ifdef MX_DEV_BP_TRACE
   if (blockIdx.x == 0 && lane == 0) {
     for (int k = 0; k < 4; ++k) mx_bp_trace[role * 4 + k] = trc[k];
+    mx_bp_trace[20 + role] = __builtin_readcyclecounter() - trc_begin;
   }
 #endif
 }

@@ -8,16 +8,16 @@ namespace mxb {
 template <int K>
 static int launch(const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s) {
   const size_t lds = mx::powmod_n2_bipair_lds_bytes<K, LIMB_BITS>();
-  hipLaunchKernelGGL((mx::powmod_n2_bipair_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((mx::powmod_n2_bipair_kernel<K, LIMB_BITS>), dim3((unsigned)nblocks), dim3(mx::BP_THREADS), lds, s, a);
   MX_HIP(hipGetLastError());
 #ifdef MX_DEV_BP_TRACE          // developer builds: cycles per phase and role of workgroup 0 (tools/bp_phase_probe.py reads stderr)
   {
-    unsigned long long h[16] = {};
+    unsigned long long h[25] = {};
     MX_HIP(hipStreamSynchronize(s));
     MX_HIP(hipMemcpyFromSymbol(h, HIP_SYMBOL(mx::mx_bp_trace), sizeof(h)));
-    const char* names[4] = {"AL", "AH", "BL", "BH"};
-    for (int r = 0; r < 4; ++r)
-      fprintf(stderr, "bp_trace K=%d %s: phase1 %llu wait1 %llu phase2 %llu wait2 %llu\n", K, names[r], h[r * 4], h[r * 4 + 1], h[r * 4 + 2], h[r * 4 + 3]);
+    const char* names[5] = {"AL", "AH", "BL", "BH", "Q"};
+    for (int r = 0; r < 5; ++r)
+      fprintf(stderr, "bp_trace K=%d %s: phase1 %llu wait1 %llu phase2 %llu wait2 %llu tape loop %llu\n", K, names[r], h[r * 4], h[r * 4 + 1], h[r * 4 + 2], h[r * 4 + 3], h[20 + r]);
   }
 #endif
   return MX_OK;

@@ -118,7 +118,12 @@ def half_hi_and_sum(geo, cst, rows, t_lo, record=None, double_result=False, spli
     t = [[0] * L for _ in range(K)]
     vmax = cymax = 0
     vs = {}
-    for i in range(Pd + L - 1, geo.h_lo - 1, -1):
+    # (the limbs at Pd + 1 and Pd + 2 of every multiplier row are zero — a product leaves at most 4 at Pd and nothing above,
+    # asserted below; constants and the halves of x end below Pd — so the two steps that would open the chain on an empty
+    # accumulator are not run: their fold digits stay the zeros the V buffer was cleared to)
+    for _, B, _, _ in rows:
+        assert all(x == 0 for x in B[Pd + 1:]), "a multiplier limb above Pd"
+    for i in range(Pd, geo.h_lo - 1, -1):
         out = [t[p][0] for p in range(K)]
         v = out[0]
         assert v < (1 << split_bits) + 64, ("fold digit", v.bit_length(), v - (1 << split_bits))
