@@ -286,7 +286,8 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   // a condition: a conditional read per limb of c was a wait per read, 2400 cycles per product)
   constexpr int VROW = 2 * ROW, VOFF = 16;
   constexpr int O_CA = 0, O_CB = 2 * ROW, O_F = 3 * ROW, O_TLA = 7 * ROW, O_TLB = 8 * ROW, O_QM = 9 * ROW, O_V = 11 * ROW,
-                O_DG = O_V + 2 * VROW, O_QC = O_DG + 16, O_STA = O_QC + 2 * ROW, O_STB = O_STA + M_t::LDS_WORDS, GROUP_WORDS = O_STB + M_t::LDS_WORDS;
+                O_DG = O_V + 2 * VROW, O_QC = O_DG + 16, O_STA = O_QC + 2 * ROW, O_STB = O_STA + M_t::LDS_WORDS, O_STQ = O_STB + M_t::LDS_WORDS,
+                GROUP_WORDS = O_STQ + M_t::LDS_WORDS;
   constexpr int NC = 11;         // limbs of c, at most: c <= 2^(W (Pd + 6) - bits + 1) < 2^(6 W + 123)
   static_assert(VOFF >= NC + 2 && VOFF + 3 * K + 2 <= VROW, "every V[pos - i] lies inside the buffer");
   extern __shared__ u32 smem[];
@@ -300,7 +301,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   u32* G = smem + gw * GROUP_WORDS;
   u32* CA = G + O_CA; u32* CB = G + O_CB; u32* F = G + O_F; u32* TLA = G + O_TLA; u32* TLB = G + O_TLB;
   u32* QM = G + O_QM; u32* V = G + O_V; u32* DG = G + O_DG; u32* QC = G + O_QC;
-  u32* ST = G + (role == 0 ? O_STA : O_STB);
+  u32* ST = G + (role == 0 ? O_STA : (role == 4 ? O_STQ : O_STB));     // (Mont::load stages through it: one per Mont wavefront)
 
   const i64 slot_id = (i64)blockIdx.x;
   const i64 elem_raw = slot_id * GPW + gw;
@@ -322,6 +323,9 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   u32 cfr[6][L];                 // Q: the final folds' quotients (this lane's limbs)
   u32 climb[11];                 // Q: the limbs of c (the same in every lane; fetched once — a scalar load per limb and product
                                  // cost 2700 cycles per slot, profiles/r06_bp_phase_probe.txt)
+  // (The L wavefronts AND Q load all of these, each staging through an LDS area of its own: with the modulus left undefined in
+  // Q the compiler treated the L wavefronts' limbs of N~ as 64-bit values — a third more multiply-adds in every block of
+  // their products, 3700 -> 5070 cycles per product — and with constants in its place the slots came out 5 % slower.)
   if (is_l || is_q) {
 #pragma unroll
     for (int k = 0; k < 6; ++k) {
@@ -610,7 +614,7 @@ template <int K, int W>
 constexpr size_t powmod_n2_bipair_lds_bytes() {
   using M_t = Mont<K, 3, W, true, false>;
   constexpr int ROW = 3 * K + 4;
-  return (size_t)(64 / K) * (11 * ROW + 4 * ROW + 16 + 2 * ROW + 2 * M_t::LDS_WORDS) * 4;
+  return (size_t)(64 / K) * (11 * ROW + 4 * ROW + 16 + 2 * ROW + 3 * M_t::LDS_WORDS) * 4;
 }
 
 }  // namespace mx
