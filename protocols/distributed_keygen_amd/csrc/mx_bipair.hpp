@@ -524,6 +524,15 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   int fcur = 0;                                           // F buffer of the next multiplication
   int staged = -1;                                        // table slot already staged in F[fcur] by a look-ahead
   int k = 0, pos = 0;
+  // the tape word at k and the one behind it, fetched when k moved last — a slot or more before they are looked at (a scalar
+  // load at the point of use was 200 cycles in which none of the five wavefronts had anything to issue, 1200 times per launch)
+  constexpr u32 TAPE_END = N2_MULC << 28;
+  u32 w0 = A.ntape > 0 ? tape[0] : TAPE_END, w1 = A.ntape > 1 ? tape[1] : TAPE_END;
+  auto next_word = [&]() {
+    ++k;
+    w0 = w1;
+    w1 = k + 1 < A.ntape ? tape[k + 1] : TAPE_END;
+  };
   int rem = 0, run_nx = -1;                               // squarings left in the current run; the multiplication behind it
   bool done = false;
   while (!done) {
@@ -536,7 +545,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
       u32 op = N2_MULC;
       int arg = 0;
       if (k < A.ntape && pos < A.pos_end) {
-        const u32 word = tape[k];
+        const u32 word = w0;
         op = word >> 28;
         arg = (int)(word & 0x0FFFFFFFu);
       }
@@ -548,11 +557,10 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
         rem = hi - pos;
         run_nx = -1;
         if (pos + arg <= A.pos_end && k + 1 < A.ntape) {
-          const u32 w2 = tape[k + 1];
-          if ((w2 >> 28) == N2_MUL) run_nx = (int)(w2 & 0x0FFFFFFFu);
+          if ((w1 >> 28) == N2_MUL) run_nx = (int)(w1 & 0x0FFFFFFFu);
         }
         pos += arg;
-        ++k;
+        next_word();
         continue;
       } else if (op == N2_MUL) {
         if (staged != arg) {
@@ -567,7 +575,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
         kind = 2;
         f = fcur;
         fcur ^= 1;
-        ++k;
+        next_word();
       } else if (pend) {
         // LOAD / STORE / ADD act on the complete pair: the outstanding pass 2 first (kind 0), the operation next time round
       } else {
@@ -589,7 +597,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
           }
         }
         __syncthreads();
-        ++k;
+        next_word();
         continue;
       }
     }

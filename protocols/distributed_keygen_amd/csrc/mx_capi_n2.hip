@@ -667,7 +667,10 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
     a.batch = batch; a.limbsn = plan->limbs_n; a.limbs2 = limbs2; a.nblk = p.geo.nblk; a.ksplit = bits - 1;
     a.friendly = 1;
     a.sched = nullptr; a.sched_groups = a.sched_segments = a.sched_n_sqr = 0;
-    a.first = 0; a.last = 1; a.pos_begin = plan->n_sqr + 1; a.pos_end = 0x7FFFFFFF;
+    // (the last product is the last word of the tape: the segment is handed that word alone, at position 1 — walking the
+    // whole tape to it, a dependent scalar load per word, was 100 of this launch's 136 us)
+    a.tape = b.tape + (plan->ntape - 1); a.ntape = 1;
+    a.first = 0; a.last = 1; a.pos_begin = 1; a.pos_end = 0x7FFFFFFF;
     return launch_n2(a, p, 2, s);
   }
   N2Shape p;
@@ -723,7 +726,8 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   }
   if (fr_tape) {
     a.first = 0; a.last = 1; a.friendly = 0;
-    a.pos_begin = plan->n_sqr + 1; a.pos_end = 0x7FFFFFFF;
+    a.tape += plan->ntape - 1; a.ntape = 1;          // (the last word of the tape alone, as in the latency form above)
+    a.pos_begin = 1; a.pos_end = 0x7FFFFFFF;
     MX_TRY(launch_n2(a, p, ch.wpg, s));
   }
   return MX_OK;
