@@ -117,9 +117,9 @@ int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* 
  * N-adic digits never reads the second digits) — 0.54-0.58 of the time per operation with twice the wavefronts,
  * for launches that leave SIMDs idle: a single ciphertext (PSK:92 called from DK:345-349), a keygen-sized batch,
  * one 10 000-ciphertext sequence; 4 (ABI 4.3; limbs_per_lane 3 or 0; moduli whose groups have 16 or 32 lanes: key_length
- * 1024 and 2048) = BOTH passes bipartite on two wavefronts each, four wavefronts per group of elements — the shortest
- * dependent chain there is, for launches of at most one workgroup per compute unit (a lone decrypt: 11.3 instead of
- * 12.95 ms at key_length 2048); 0 = the library's choice (which takes 4 for such launches).  With both at 0 the library estimates the duration
+ * 1024 and 2048) = BOTH passes bipartite on two wavefronts each — four wavefronts per group of elements and a fifth that
+ * forms the quotient correction one product behind —, the shortest dependent chain there is, for launches of at most one
+ * workgroup per compute unit (a lone decrypt: 10.6 instead of 12.95 ms at key_length 2048); 0 = the library's choice (which takes 4 for such launches).  With both at 0 the library estimates the duration
  * of ONE launch of this batch on an idle GPU for every shape and takes the shortest; callers that keep several
  * launches in flight fill the machine between them and should pass 18 / 1.  mx_nsquare_launch_shape reports the
  * choice.  Same result bit for bit in every shape.
@@ -313,7 +313,7 @@ int mx_selftest_lanes(void* stream);
 #define MX_KNOB_GENERIC_LATENCY 5
 #define MX_KNOB_N2_SPLIT 6
 #define MX_KNOB_LAT_LANES 8         /* 3-limb latency forms of the generic kernel: at least this many lanes per element (0 = the smallest group that holds the number) */
-#define MX_KNOB_N2_BIPAIR 9         /* 1 = mx_powmod_nsquare_run never chooses the four-wavefront latency form by itself (A/B runs) */
+#define MX_KNOB_N2_BIPAIR 9         /* 1 = mx_powmod_nsquare_run never chooses the five-wavefront latency form by itself (A/B runs) */
 #define MX_KNOB_BI_PIVOT 7          /* bipartite form of the generic kernel: multiplier limbs on the Montgomery wavefront (0 = the library's pivot) */
 int mx_debug_knob(int knob, int value);
 /* Enqueues a kernel of ONE wavefront that idles for `microseconds` (0..1 000 000) on `stream` and touches no

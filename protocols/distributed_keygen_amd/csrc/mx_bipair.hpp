@@ -1,4 +1,5 @@
-// Four-wavefront latency form of the N^2 pair kernel:  out[e] = bases[e]^exp mod N^2  with BOTH passes of every pair product
+// Five-wavefront latency form of the N^2 pair kernel (wavefronts_per_group 4: four wavefronts carry the two passes, a fifth the
+// quotient correction):  out[e] = bases[e]^exp mod N^2  with BOTH passes of every pair product
 // split over two wavefronts each (tools/bipair_model.py is the column-exact model of the arithmetic in this file;
 // tests/test_bipair_model.py runs it against big-integer arithmetic with every width asserted).
 //
@@ -20,15 +21,17 @@
 //        BL   TL2 = (X0 Y1lo + X1 Y0lo + [C2' + u (2^(W hL) - 1 - Qm)] + q' N~) / 2^(W hL)  +  Qc
 //        BH   tH2 =  X0 Y1hi + X1 Y0hi   folded;   Z1 = TL2 + tH2
 //
-// Qc (8-10 limbs of c times the 36 fold digits + six small terms) is formed by AL while AH finishes pass 1 — AL would wait
-// at the barrier otherwise — and reaches BL as almost-normalised limbs.  BH's columns take twelve 2^58 terms in their three
+// Qc (6-11 limbs of c times the ~36 fold digits + six small terms) is formed by a fifth wavefront, Q, one product behind the A
+// pair — from the digits AH recorded in double-buffered LDS rows, while AH is already on the next product — and reaches BH's
+// post as a row of almost-normalised limbs.  (Formed by the L wavefronts between the barriers, where they have nothing else to
+// do, it was 840 cycles of every slot: a wavefront alone on its SIMD issues one instruction per five cycles, and the H
+// wavefronts' posts take 450.)  BH's columns take twelve 2^58 terms in their three
 // steps in a lane (two product rows, or one row with a doubled multiplier limb, plus the fold) instead of AH's six: a column
 // that moves to the lane above therefore crosses as its low 30 bits and a carry word with weight 2 (29 bits and weight 1 in
 // pass 1), which keeps that word below 2^32 (the model asserts both).
 //
-// A workgroup is the four wavefronts of ONE group set (64 / K elements), one per SIMD of a compute unit.  The B pair works
-// one product BEHIND the A pair (pass 2 of product s needs Qm, Qc and X0 of pass 1 of s), so in a run of products all four
-// wavefronts are busy in every time slot; two workgroup barriers per slot (between the halves and the end of a product, as in
+// A workgroup is the five wavefronts of ONE group set (64 / K elements).  The B pair works one product BEHIND the A pair
+// (pass 2 of product s needs Qm, Qc and X0 of pass 1 of s), so in a run of products all of them are busy in every time slot; two workgroup barriers per slot (between the halves and the end of a product, as in
 // mx_bimont.hpp).  Operations of the tape that are not products (LOAD / STORE / ADD: conversion and table build) drain that
 // pipeline first.  The kernel runs the tape up to, not including, its last product (N2_MULC) and leaves the accumulator in
 // the carry slot; the last product and the epilogue — plain passes that bring both digits below 2 N — run as a last segment

@@ -1,4 +1,4 @@
-// Four-wavefront latency form of the N^2 pair kernel (mx_bipair.hpp): one decrypt(), or a batch small enough to leave most
+// Five-wavefront latency form of the N^2 pair kernel (mx_bipair.hpp): one decrypt(), or a batch small enough to leave most
 // of the chip idle (paillier_shared_key.py:92 at distributed_keygen.py:345-349).  Translation unit of its own, built in
 // parallel with the others; the launcher is called from mx_capi_n2.hip.
 #include "mx_upload.hpp"

@@ -35,7 +35,7 @@ inline int max_lanes(int lpl, int wpg) {
 constexpr int N2_TIMESLICE_MAX_SEGMENTS = mx::N2_TS_LEVELS;      // units per group of a time-sliced launch, at most
 
 bool shape_n2(int n_bits, int window, int64_t batch, int limbs_per_lane, int wpg, N2Shape& p) {
-  if (wpg == 4) {                                                // the four-wavefront latency form (mx_bipair.hpp) shares the
+  if (wpg == 4) {                                                // the five-wavefront latency form (mx_bipair.hpp) shares the
     if (limbs_per_lane != LIMBS_PER_LANE_LAT) return false;      // slots of the two-wavefront 3-limb form
     wpg = 2;
   }
@@ -219,7 +219,7 @@ double n2_estimate(int n_bits, int64_t batch, int lpl, int wpg, int* resident = 
 }
 bool bipair_geometry(int n_bits, Geometry& gb);
 N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
-  if (wpg == 4) return N2Choice{LIMBS_PER_LANE_LAT, 4, 0, 0};      // explicit: the four-wavefront latency form (mx_bipair.hpp)
+  if (wpg == 4) return N2Choice{LIMBS_PER_LANE_LAT, 4, 0, 0};      // explicit: the five-wavefront latency form (mx_bipair.hpp)
   N2Choice best{LIMBS_PER_LANE, 1, 0, 0};
   double best_t = -1.0;
   for (int l : N2_LPLS) {
@@ -232,7 +232,7 @@ N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
     }
   }
   if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1, 0, 0};   // reported as MX_ERR_SIZE by the caller
-  // Launches that the two-wavefront latency form would run with at most ONE workgroup of the four-wavefront form per compute
+  // Launches that the two-wavefront latency form would run with at most ONE workgroup of the five-wavefront form per compute
   // unit take that form where it exists (key_length 1024 / 2048): both passes of every product on two wavefronts each,
   // 11.3 instead of 12.95 ms for 1 .. 512 ciphertexts at key_length 2048 (tools/bipair_check.py, profiles/r06_bipair_*);
   // a second workgroup per unit costs more than it saves (1024: 15.0 against 13.4 ms).
@@ -254,7 +254,7 @@ int n2_auto_segments(int n_sqr, int64_t nblocks) {
 inline int64_t n2_consts_words(int limbs_n) { return (int64_t)8 * limbs_n + 2 * (limbs_n + 1); }
 inline int64_t n2_consts_bytes(int limbs_n) { return align256(n2_consts_words(limbs_n) * 4); }
 
-// The four-wavefront latency form (mx_bipair.hpp): exists where the bipartite geometry of the modulus (mx_host.hpp: the
+// The five-wavefront latency form (mx_bipair.hpp): exists where the bipartite geometry of the modulus (mx_host.hpp: the
 // pivot, Pd data positions) and the pair kernel's 3-limb geometry agree on lanes and blocks, and the kernel is instantiated.
 bool bipair_geometry(int n_bits, Geometry& gb) {
   Geometry g3;
@@ -268,7 +268,7 @@ inline int64_t bipair_fold_bytes() { return align256((int64_t)mx::BI_ROWS * 3 * 
 inline int64_t bipair_quot_bytes() { return align256((int64_t)mx::BP_QROWS * 3 * 64 * 4); }
 inline int64_t bipair_section_bytes(int limbs_n) { return n2_consts_bytes(limbs_n) + bipair_fold_bytes() + bipair_quot_bytes(); }
 inline int64_t bipair_section_offset(int limbs_n) { return N2_GEOS * n2_consts_bytes(limbs_n) + align256((int64_t)MAX_SLIDING_OPS * 4); }
-constexpr int N2_GEO_BIPAIR = 8;      // mx_nsquare_plan::geometries: the plan holds the constants of the four-wavefront form
+constexpr int N2_GEO_BIPAIR = 8;      // mx_nsquare_plan::geometries: the plan holds the constants of the five-wavefront form
 
 
 // The eight constant rows of one geometry (R = 2^m), each limbs_n words:
@@ -292,7 +292,7 @@ void n2_constants(u32* c, const u32* h_n, int limbs_n, int m, int k) {
   pair_of(2 * m, 3);          // represents R      (V = R^2)
   pair_of(2 * m + k, 5);      // represents 2^k R  (V = 2^k R^2)
   // C' = N*ceil(R/N) - R + 1 = N - (R mod N) + 1   (R mod N != 0 as N is odd > 1)
-  pow2_mod(rr.data(), h_n, limbs_n, m);          // (R below N for the four-wavefront form: R = 2^(W hL))
+  pow2_mod(rr.data(), h_n, limbs_n, m);          // (R below N for the five-wavefront form: R = 2^(W hL))
   u64 borrow = 0, carry = 1;
   u32* cp = &c[(size_t)7 * limbs_n];
   for (int i = 0; i < limbs_n; ++i) {
@@ -329,7 +329,7 @@ extern "C" int mx_nsquare_launch_shape(int n_bits, int64_t batch, int limbs_per_
                                        int* l, int* w, int* blocks, int* wavefronts) {
   if (!k || !l || !w || !blocks || !wavefronts || batch <= 0) return MX_ERR_ARG;
   if (limbs_per_lane != 0 && geo_index(limbs_per_lane) < 0) return MX_ERR_ARG;
-  if (wavefronts_per_group == 4) {                         // the four-wavefront latency form: explicit only (mx_bipair.hpp)
+  if (wavefronts_per_group == 4) {                         // the five-wavefront latency form: explicit only (mx_bipair.hpp)
     Geometry gb;
     if ((limbs_per_lane != 0 && limbs_per_lane != LIMBS_PER_LANE_LAT) || !bipair_geometry(n_bits, gb)) return MX_ERR_SIZE;
     *k = gb.K; *l = gb.L; *w = gb.W; *blocks = gb.nblk; *wavefronts = 4;
@@ -558,7 +558,7 @@ extern "C" int mx_powmod_nsquare_prepare_ex(mx_nsquare_plan* plan, const uint32_
     MX_TRY(upload_words(dp + g * cb, rows[g].data(), rows[g].size(), s));
   }
   MX_TRY(upload_words(dp + N2_GEOS * cb, tape.data(), tape.size(), s));
-  // ---- the four-wavefront latency form (mx_bipair.hpp): constants for R' = 2^(W hL), the fold rows (computed on the
+  // ---- the five-wavefront latency form (mx_bipair.hpp): constants for R' = 2^(W hL), the fold rows (computed on the
   // device from N by the bipartite form's setup kernel) and the quotients of the folds, floor(2^(W (Pd + k)) / N)
   Geometry gb;
   if (bipair_geometry(bits, gb)) {
@@ -631,7 +631,7 @@ extern "C" int mx_powmod_nsquare_run(const mx_nsquare_plan* plan, const uint32_t
   N2Choice ch = n2_auto_shape(bits, batch, limbs_per_lane, wavefronts_per_group);
   if (ch.wpg == 4 && wavefronts_per_group != 4 && !(plan->geometries & N2_GEO_BIPAIR)) ch.wpg = 2;      // a plan of an older layout
   if (ch.wpg == 4) {
-    // the four-wavefront latency form: its own kernel for everything in front of the last product, then the last product and
+    // the five-wavefront latency form: its own kernel for everything in front of the last product, then the last product and
     // the epilogue as a last segment of the two-wavefront 3-limb kernel, whose slots it shares
     Geometry gb;
     if (!(plan->geometries & N2_GEO_BIPAIR) || !bipair_geometry(bits, gb)) return MX_ERR_SIZE;

@@ -17,7 +17,7 @@
 //                                   pair and on which XCD it ran (four words behind the queues)
 //   MX_DEV_BI_TRACE                 shader-clock cycles per phase of the bipartite form's        tools/bi_phase_probe.py
 //                                   products, pair 0 of workgroup 0 (mx_bimont.hpp)
-//   MX_DEV_BP_TRACE                 shader-clock cycles per phase and role of the four-wavefront pair    tools/bp_phase_probe.py
+//   MX_DEV_BP_TRACE                 shader-clock cycles per phase and role of the five-wavefront pair    tools/bp_phase_probe.py
 //                                   kernel, workgroup 0 (mx_bipair.hpp)
 //   MX_DEV_PRIVATE_PAD_WORDS=n      every lane of the one-wavefront pair kernel keeps n tagged   tools/concurrency_census.py
 //                                   words in a private segment and checks them at the end

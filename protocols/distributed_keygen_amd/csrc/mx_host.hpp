@@ -39,7 +39,7 @@ extern Knob g_knob_n2_split;           // MX_KNOB_N2_SPLIT: 0 = mx_nsquare_launc
 extern Knob g_knob_generic_latency;    // MX_KNOB_GENERIC_LATENCY: 0 = the automatic choice may take the 3-limb instances of the generic kernel, 1 = never
 extern Knob g_knob_jacobi_max_batches; // MX_KNOB_JACOBI_MAX_BATCHES: 0 = the kernel's own bound, v = at most v - 1 batches
 extern Knob g_knob_lat_lanes;          // MX_KNOB_LAT_LANES: 0 = the smallest group that holds the number, v = at least v lanes per element for the 3-limb latency forms of the generic kernel
-extern Knob g_knob_n2_bipair;          // MX_KNOB_N2_BIPAIR: 0 = small launches of the pair kernel take the four-wavefront latency form where it exists, 1 = never
+extern Knob g_knob_n2_bipair;          // MX_KNOB_N2_BIPAIR: 0 = small launches of the pair kernel take the five-wavefront latency form where it exists, 1 = never
 extern Knob g_knob_bi_pivot;           // MX_KNOB_BI_PIVOT: 0 = the library's pivot of the bipartite form, v = v multiplier limbs on wavefront L (rounded down to a multiple of 3)
 
 struct Geometry {

@@ -223,7 +223,7 @@ class Engine:
 
     def set_wavefronts_per_group(self, wavefronts: int) -> None:
         """N^2 pair kernel (powmod_nsquare_t): 1 = one wavefront runs both Montgomery passes of a pair product,
-        2 = two wavefronts, one pass each (for launches that leave SIMDs idle), 4 = the four-wavefront latency form
+        2 = two wavefronts, one pass each (for launches that leave SIMDs idle), 4 = the five-wavefront latency form
         (both passes bipartite, csrc/mx_bipair.hpp: 3 limbs per lane only, moduli whose groups have 16 or 32 lanes),
         0 = the library's choice (include/mxpaillier.h: mx_powmod_nsquare_run)."""
         if wavefronts not in (0, 1, 2, 4):

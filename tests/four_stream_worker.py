@@ -10,7 +10,7 @@ runtime initialises, so this process calls configure_hw_queues(16) before anythi
 and the page-in of torch again — VERDICT r05 "Next round" 1)
 
 what = "nsquare": powmod_nsquare at key_length 2048 with a full-length exponent in every launch shape (one- and
-two-wavefront groups, 3 / 9 / 18 limbs per lane, time-sliced, and the four-wavefront latency form), 4 x 10 000 rows = 4 x 625 wavefronts of the 18-limb shape
+two-wavefront groups, 3 / 9 / 18 limbs per lane, time-sliced, and the five-wavefront latency form), 4 x 10 000 rows = 4 x 625 wavefronts of the 18-limb shape
 on 1024 SIMDs; "biprime": biprime_v_t (Jacobi filter, selection, generic fixed-window modexps in every lane geometry incl. the
 bipartite latency form) at key_length 2048;
 "jacobi8192": the 257-word Jacobi instance; "k4096": the K = 16 friendly and time-sliced shapes at key_length 4096.

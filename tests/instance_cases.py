@@ -11,7 +11,7 @@ Each case: (kind, modulus-root bits, limbs_per_lane argument, batch, exponent bi
 kind "n2": modulus is N^2 for an N of exactly that many bits; "shared" / "multi": modulus of that many bits.
 The pair kernel exists in two forms — ``powmod_n2_kernel`` (one wavefront per group of elements) and
 ``powmod_n2_split_kernel`` (two: mx_powmod_n2_split.hpp) — selected by the sixth field (1 | 2; 0 = the
-library's choice for this batch; 4 = the four-wavefront latency form ``powmod_n2_bipair_kernel``, mx_bipair.hpp); both have friendly-modulus instances that the library takes when the modulus leaves
+library's choice for this batch; 4 = the five-wavefront latency form ``powmod_n2_bipair_kernel``, mx_bipair.hpp); both have friendly-modulus instances that the library takes when the modulus leaves
 the room (so the bit length of a case decides the instance), and the two-wavefront kernel has time-sliced instances
 (seventh field 2: forced through the developer knob, as the automatic choice only takes them for batches of several
 thousand).  An instance is the tuple ``mx_nsquare_launch_instance`` reports:

@@ -1,5 +1,5 @@
 """CPU: the column-exact model of the BIPARTITE PAIR product (tools/bipair_model.py — the arithmetic of csrc/mx_bipair.hpp,
-the four-wavefront latency form of the N^2 pair kernel) against big-integer arithmetic modulo N^2.  The model asserts every
+the five-wavefront latency form of the N^2 pair kernel) against big-integer arithmetic modulo N^2.  The model asserts every
 width the kernel relies on while it runs: 64-bit lazy columns in all four wavefronts, the 32-bit words that cross lanes
 (29-bit limb + carry word in pass 1, 30-bit limb + carry word of weight 2 in pass 2), the fold digits, the quotient
 columns c * Vq + sum dg_k cf_k; tools/bipair_debug.py compares the kernel's slots with this model limb for limb on the GPU."""

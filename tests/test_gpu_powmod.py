@@ -467,7 +467,7 @@ def test_bipartite_form_with_moduli_of_different_lengths_in_one_launch(eng):
 
 @pytest.mark.parametrize("n_bits", [1027, 1029, 2050, 2051, 2053, 1500, 900])
 def test_four_wavefront_latency_form_of_the_pair_kernel(eng, n_bits):
-    """csrc/mx_bipair.hpp (round 6): both passes of every pair product bipartite, four wavefronts per group of elements —
+    """csrc/mx_bipair.hpp (round 6): both passes of every pair product bipartite, four wavefronts per group of elements and a fifth for the quotient correction —
     what a lone decrypt() and every launch of at most one workgroup per compute unit run at key_length 1024 / 2048.
     Random and special moduli, bases that are 0 / 1 / multiples of N / N^2 - 1, exponents of 1 bit .. full length (incl. the
     fixed-window tape), batches from 1 to more than one workgroup per CU: bit for bit CPython pow; the library's own choice

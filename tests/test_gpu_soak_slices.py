@@ -50,7 +50,7 @@ def test_timesliced_soak_slice(eng, seed, launches):
 
 @pytest.mark.parametrize("seed,rounds", [(3, 40), (29, 40)])
 def test_bipair_soak_slice(eng, seed, rounds):
-    """The four-wavefront latency form of the pair kernel (csrc/mx_bipair.hpp) over random modulus lengths of its whole range,
+    """The five-wavefront latency form of the pair kernel (csrc/mx_bipair.hpp) over random modulus lengths of its whole range,
     special moduli and bases, exponents of 1 bit .. full length, sliding and fixed-window tapes, batches of 1 .. 700, now and
     then two launches at once: every result against CPython pow."""
     import soak_bipair

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""The four-wavefront latency form of the pair kernel (csrc/mx_bipair.hpp) against CPython pow: random and special moduli
+"""The five-wavefront latency form of the pair kernel (csrc/mx_bipair.hpp) against CPython pow: random and special moduli
 of key_length 1024 / 2048 size, exponents from a few bits to full length, batches of 1 .. 600, and its time for ONE
 ciphertext beside the two-wavefront form's.   usage: bipair_check.py [seed]"""
 import os
@@ -57,5 +57,5 @@ for batch in (1, 64, 256, 512, 1024):
         torch.cuda.synchronize()
         res[wpg] = ((time.perf_counter() - t0) / 5 * 1e3, out.clone())
     same = bool((res[2][1] == res[4][1]).all())
-    print(f"batch {batch}: two wavefronts {res[2][0]:.2f} ms, four wavefronts {res[4][0]:.2f} ms, identical {same}")
+    print(f"batch {batch}: two wavefronts {res[2][0]:.2f} ms, five-wavefront form {res[4][0]:.2f} ms, identical {same}")
 sys.exit(1 if bad else 0)

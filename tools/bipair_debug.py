@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Stage-by-stage check of the four-wavefront pair kernel against tools/bipair_model.py: runs x^e for a tiny exponent, reads the
+"""Stage-by-stage check of the five-wavefront pair kernel against tools/bipair_model.py: runs x^e for a tiny exponent, reads the
 pair slots the kernel left in the workspace and compares them, limb for limb and as values, with the model's.
 usage: bipair_debug.py [bits] [e]"""
 import os

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Column-exact model of a BIPARTITE PAIR product — the arithmetic a four-wavefront latency form of the N^2 pair kernel
+"""Column-exact model of a BIPARTITE PAIR product — the arithmetic a five-wavefront latency form of the N^2 pair kernel
 would run (developer tool, not a kernel's model yet).
 
 The pair kernel (csrc/mx_powmod_n2.hpp) holds x mod N^2 as digits (X0, X1) with x = rho (X0 + X1 N) and multiplies with two

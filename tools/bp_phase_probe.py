@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """One decrypt() at key_length 2048 on a library built with -DMX_DEV_BP_TRACE (tools/build_variant.py bp_trace -DMX_DEV_BP_TRACE;
-MX_LIBRARY=...): the launcher prints the shader-clock cycles every role of the four-wavefront pair kernel spent per phase
+MX_LIBRARY=...): the launcher prints the shader-clock cycles every role of the five-wavefront pair kernel spent per phase
 (stderr), this tool the number of slots to divide by and the call's time."""
 import os
 import sys

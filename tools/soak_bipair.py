@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Randomised differential soak of the four-wavefront latency form of the pair kernel (csrc/mx_bipair.hpp) against CPython pow on
+"""Randomised differential soak of the five-wavefront latency form of the pair kernel (csrc/mx_bipair.hpp) against CPython pow on
 the host cores: modulus lengths over the whole range the form takes (groups of 16 and 32 lanes, lengths around the geometry
 steps), random and special moduli, bases 0 / 1 / multiples of N / N^2 - 1 / random, exponents from one bit to full length with
 sliding and fixed-window tapes, batches from 1 to several workgroups per compute unit, now and then two launches at once on two streams.
