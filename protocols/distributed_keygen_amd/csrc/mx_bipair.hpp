@@ -390,6 +390,110 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
 #endif
   int ca = 0;          // CA[ca]: the accumulator's first digit (the A pair's operand), CA[ca ^ 1] receives its product
   int qa = 0;          // QM[qa] receives the quotient digits of the A pair's product
+  // ---- what each role does in a time slot (phase 1: its half of a product; phase 2, H wavefronts: the post).  `ca`, `qa` as
+  // above; ca_b, qb: the same two of the product the B pair works on (one slot older).
+  auto ah_half = [&](int pa, int fa, u64 (&t)[L]) -> u32 {
+    u32 a[L];
+    H.gather(a, CA + ca * ROW);
+    if (pa == 1) {
+      H.template half_rec<true>(t, a, CA + ca * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
+    } else {
+      H.template half_rec<false>(t, a, F + (fa * 2 + 1) * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
+    }
+    return H.pre_rec(t, DG + qa * 8);
+  };
+  auto bh_half = [&](int pb, int fb, int ca_b, u64 (&t)[L]) -> u32 {
+    u32 x0[L], x1[L];
+    H.gather(x0, CA + ca_b * ROW);
+    H.gather(x1, CB);
+    if (pb == 1) {
+      H.template half2<false, true>(t, x0, x0, CB, CB, A.pd, A.h_lo);          // 2 X0 X1: multiplier limb doubled
+    } else {
+      H.template half2<true, false>(t, x0, x1, F + fb * 2 * ROW, F + (fb * 2 + 1) * ROW, A.pd, A.h_lo);
+    }
+    return H.pre_rec(t, nullptr);
+  };
+  auto al_half = [&](int pa, int fa) {
+    u32 a[L], r[L], q[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) a[j] = CA[ca * ROW + p * L + j];
+    M.lds = pa == 1 ? CA + ca * ROW : F + (fa * 2 + 1) * ROW;                // squaring: X0 itself; multiplication: Y0
+    if (pa == 1) {
+      M.template mulx<M_t::F_FRIENDLY | M_t::F_STAGED | M_t::F_RECORD_Q | M_t::F_SQUARE>(r, a, a, a, a, a, q, nullptr, nblk_lo);
+    } else {
+      M.template mulx<M_t::F_FRIENDLY | M_t::F_STAGED | M_t::F_RECORD_Q>(r, a, a, a, a, a, q, nullptr, nblk_lo);
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      TLA[p * L + j] = r[j];
+      QM[qa * ROW + p * L + j] = q[j];
+      if (p * L + j == A.pd) DG[qa * 8 + 6] = r[j];          // (TLA is this wavefront's again before Q reads it)
+    }
+  };
+  auto bl_half = [&](int pb, int fb, int ca_b, int qb) {
+    u32 x0[L], x1[L], r[L], qq[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) {
+      x0[j] = CA[ca_b * ROW + p * L + j];
+      x1[j] = CB[p * L + j];
+      const u32 qd = QM[qb * ROW + p * L + j];
+      qq[j] = (p < nblk_lo) ? (M_t::MASK - qd) : 0u;                          // u (2^(W hL) - 1 - Qm), limb-wise
+    }
+    if (pb == 1) {
+      M.lds = ST;
+      M.template mulx<M_t::F_INIT | M_t::F_INITQ | M_t::F_BDOUBLE | M_t::F_FRIENDLY>(r, x0, x1, x0, x1, c2p, nullptr, nullptr, nblk_lo, qq);
+    } else {
+      M.lds = F + fb * 2 * ROW;                                               // b = Y1 (with X0), d = Y0 (with X1)
+      M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_INITQ | M_t::F_STAGED | M_t::F_FRIENDLY>(r, x0, x0, x1, x1, c2p, nullptr, nullptr, nblk_lo, qq);
+    }
+#pragma unroll
+    for (int j = 0; j < L; ++j) TLB[p * L + j] = r[j];
+  };
+  auto q_row = [&](int qb) {
+    // Qc = c * Vq + sum dg_k cf_k of the product whose pass 2 the B pair runs in this slot, for this lane's positions: from
+    // the digits its pass 1 recorded one slot ago (V, DG: double buffers) into the row QC that wavefront BH adds in its post.
+    // (Rounds of this work by the L wavefronts between the barriers cost 840 cycles of every slot, a lone wavefront issuing
+    // an instruction every five cycles; a wavefront of its own has a whole phase for them.)
+    const u32* Vb = V + qb * VROW + VOFF + p * L;            // V[pos] of this lane's first position
+    // (loop-invariant 32-bit multiplicands: opaque IN PLACE once per product, or the compiler keeps their zero-extensions
+    // in register pairs; the reads are issued as one batch — a scheduling barrier keeps them in front of their uses)
+#pragma unroll
+    for (int i = 0; i < NC; ++i) asm volatile("" : "+v"(climb[i]));
+    u32 vw[NC + 2], dgv[6];                                  // V[base + 2 - k], k = 0 .. NC + 1
+#pragma unroll
+    for (int k = 0; k < NC + 2; ++k) vw[k] = Vb[2 - k];
+#pragma unroll
+    for (int k = 0; k < 6; ++k) dgv[k] = DG[qb * 8 + k];
+    const u32 tl_pd = DG[qb * 8 + 6];
+    __builtin_amdgcn_sched_barrier(0);
+    dgv[0] += tl_pd;                                         // dg_0: wavefront AH's own part + wavefront AL's limb at Pd
+    // (six independent chains — two per column: a lone wavefront waits for every dependent multiply-accumulate)
+    u64 ev[L] = {0, 0, 0}, od[L] = {0, 0, 0};
+#pragma unroll
+    for (int k = 0; k < 6; ++k) {
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        if (k & 1) od[j] += (u64)cfr[k][j] * dgv[k];
+        else ev[j] += (u64)cfr[k][j] * dgv[k];
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NC; ++i) {                                               // (limbs of c beyond its length are zero)
+#pragma unroll
+      for (int j = 0; j < L; ++j) {
+        if (i & 1) od[j] += (u64)climb[i] * vw[2 - j + i];                       // V[base + j - i]
+        else ev[j] += (u64)climb[i] * vw[2 - j + i];
+      }
+    }
+    u64 qc[L];
+#pragma unroll
+    for (int j = 0; j < L; ++j) qc[j] = ev[j] + od[j];
+    u32 r[L];
+    M.normalize_weak(r, qc);
+#pragma unroll
+    for (int j = 0; j < L; ++j) QC[p * L + j] = r[j];
+  };
+
   auto run_slot = [&](int pa, int fa, int pb, int fb, int ca_b, int qb, int nx_slot, int nxf) {
     u64 t[L];
     u32 dg0 = 0;
@@ -403,101 +507,15 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     }
     // ---- phase 1
     if (role == 1 && pa) {                   // (the H wavefronts first: theirs is the longest path of a slot)
-      u32 a[L];
-      H.gather(a, CA + ca * ROW);
-      if (pa == 1) {
-        H.template half_rec<true>(t, a, CA + ca * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
-      } else {
-        H.template half_rec<false>(t, a, F + (fa * 2 + 1) * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
-      }
-      dg0 = H.pre_rec(t, DG + qa * 8);
+      dg0 = ah_half(pa, fa, t);
     } else if (role == 3 && pb) {
-      u32 x0[L], x1[L];
-      H.gather(x0, CA + ca_b * ROW);
-      H.gather(x1, CB);
-      if (pb == 1) {
-        H.template half2<false, true>(t, x0, x0, CB, CB, A.pd, A.h_lo);          // 2 X0 X1: multiplier limb doubled
-      } else {
-        H.template half2<true, false>(t, x0, x1, F + fb * 2 * ROW, F + (fb * 2 + 1) * ROW, A.pd, A.h_lo);
-      }
-      dg0 = H.pre_rec(t, nullptr);
+      dg0 = bh_half(pb, fb, ca_b, t);
     } else if (role == 0 && pa) {
-      u32 a[L], r[L], q[L];
-#pragma unroll
-      for (int j = 0; j < L; ++j) a[j] = CA[ca * ROW + p * L + j];
-      M.lds = pa == 1 ? CA + ca * ROW : F + (fa * 2 + 1) * ROW;                // squaring: X0 itself; multiplication: Y0
-      if (pa == 1) {
-        M.template mulx<M_t::F_FRIENDLY | M_t::F_STAGED | M_t::F_RECORD_Q | M_t::F_SQUARE>(r, a, a, a, a, a, q, nullptr, nblk_lo);
-      } else {
-        M.template mulx<M_t::F_FRIENDLY | M_t::F_STAGED | M_t::F_RECORD_Q>(r, a, a, a, a, a, q, nullptr, nblk_lo);
-      }
-#pragma unroll
-      for (int j = 0; j < L; ++j) {
-        TLA[p * L + j] = r[j];
-        QM[qa * ROW + p * L + j] = q[j];
-        if (p * L + j == A.pd) DG[qa * 8 + 6] = r[j];          // (TLA is this wavefront's again before Q reads it)
-      }
+      al_half(pa, fa);
     } else if (role == 2 && pb) {
-      u32 x0[L], x1[L], r[L], qq[L];
-#pragma unroll
-      for (int j = 0; j < L; ++j) {
-        x0[j] = CA[ca_b * ROW + p * L + j];
-        x1[j] = CB[p * L + j];
-        const u32 qd = QM[qb * ROW + p * L + j];
-        qq[j] = (p < nblk_lo) ? (M_t::MASK - qd) : 0u;                          // u (2^(W hL) - 1 - Qm), limb-wise
-      }
-      if (pb == 1) {
-        M.lds = ST;
-        M.template mulx<M_t::F_INIT | M_t::F_INITQ | M_t::F_BDOUBLE | M_t::F_FRIENDLY>(r, x0, x1, x0, x1, c2p, nullptr, nullptr, nblk_lo, qq);
-      } else {
-        M.lds = F + fb * 2 * ROW;                                               // b = Y1 (with X0), d = Y0 (with X1)
-        M.template mulx<M_t::F_TWO | M_t::F_INIT | M_t::F_INITQ | M_t::F_STAGED | M_t::F_FRIENDLY>(r, x0, x0, x1, x1, c2p, nullptr, nullptr, nblk_lo, qq);
-      }
-#pragma unroll
-      for (int j = 0; j < L; ++j) TLB[p * L + j] = r[j];
+      bl_half(pb, fb, ca_b, qb);
     } else if (is_q && pb) {
-      // Qc = c * Vq + sum dg_k cf_k of the product whose pass 2 the B pair runs in this slot, for this lane's positions: from
-      // the digits its pass 1 recorded one slot ago (V, DG: double buffers) into the row QC that wavefront BH adds in its post.
-      // (Rounds of this work by the L wavefronts between the barriers cost 840 cycles of every slot, a lone wavefront issuing
-      // an instruction every five cycles; a wavefront of its own has a whole phase for them.)
-      const u32* Vb = V + qb * VROW + VOFF + p * L;            // V[pos] of this lane's first position
-      // (loop-invariant 32-bit multiplicands: opaque IN PLACE once per product, or the compiler keeps their zero-extensions
-      // in register pairs; the reads are issued as one batch — a scheduling barrier keeps them in front of their uses)
-#pragma unroll
-      for (int i = 0; i < NC; ++i) asm volatile("" : "+v"(climb[i]));
-      u32 vw[NC + 2], dgv[6];                                  // V[base + 2 - k], k = 0 .. NC + 1
-#pragma unroll
-      for (int k = 0; k < NC + 2; ++k) vw[k] = Vb[2 - k];
-#pragma unroll
-      for (int k = 0; k < 6; ++k) dgv[k] = DG[qb * 8 + k];
-      const u32 tl_pd = DG[qb * 8 + 6];
-      __builtin_amdgcn_sched_barrier(0);
-      dgv[0] += tl_pd;                                         // dg_0: wavefront AH's own part + wavefront AL's limb at Pd
-      // (six independent chains — two per column: a lone wavefront waits for every dependent multiply-accumulate)
-      u64 ev[L] = {0, 0, 0}, od[L] = {0, 0, 0};
-#pragma unroll
-      for (int k = 0; k < 6; ++k) {
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-          if (k & 1) od[j] += (u64)cfr[k][j] * dgv[k];
-          else ev[j] += (u64)cfr[k][j] * dgv[k];
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < NC; ++i) {                                               // (limbs of c beyond its length are zero)
-#pragma unroll
-        for (int j = 0; j < L; ++j) {
-          if (i & 1) od[j] += (u64)climb[i] * vw[2 - j + i];                       // V[base + j - i]
-          else ev[j] += (u64)climb[i] * vw[2 - j + i];
-        }
-      }
-      u64 qc[L];
-#pragma unroll
-      for (int j = 0; j < L; ++j) qc[j] = ev[j] + od[j];
-      u32 r[L];
-      M.normalize_weak(r, qc);
-#pragma unroll
-      for (int j = 0; j < L; ++j) QC[p * L + j] = r[j];
+      q_row(qb);
     }
     MX_BP_MARK(0)                                    // phase 1: this role's half (+ pre)
     __syncthreads();
@@ -520,8 +538,58 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     MX_BP_MARK(3)                                    // second barrier
   };
 
-  // ---- the tape: ONE call site of run_slot (the body holds four roles' code paths; inlined several times it would not fit
-  // the instruction cache), driven by a small state machine over the tape words
+  // ---- n squarings in a row whose predecessor is a squaring as well and that carry no look-ahead (the inside of a window's
+  // run): the same five halves, posts and two barriers per slot, but every wavefront stays in a loop of its own — no tape
+  // decode, no role dispatch and no operand-kind tests between two products.  (Every instruction of that control path was
+  // five cycles on the wavefront the others wait for; the run's first squaring — its predecessor is a multiplication — and
+  // its last — it fetches the next table pair — take the general path below.)
+  auto run_squarings = [&](int n) {
+    if (role == 1) {
+      for (int s = 0; s < n; ++s) {
+        u64 t[L];
+        const u32 dg0 = ah_half(1, 0, t);
+        __syncthreads();
+        u32 a[L];
+        H.post(t, dg0, TLA, CA + (ca ^ 1) * ROW, a, A.pd);
+        __syncthreads();
+        ca ^= 1; qa ^= 1;
+      }
+    } else if (role == 3) {
+      for (int s = 0; s < n; ++s) {
+        u64 t[L];
+        const u32 dg0 = bh_half(1, 0, ca ^ 1, t);
+        __syncthreads();
+        u32 a[L];
+        H.post_sum(t, dg0, TLB, QC, CB, a, A.pd);
+        __syncthreads();
+        ca ^= 1; qa ^= 1;
+      }
+    } else if (role == 0) {
+      for (int s = 0; s < n; ++s) {
+        al_half(1, 0);
+        __syncthreads();
+        __syncthreads();
+        ca ^= 1; qa ^= 1;
+      }
+    } else if (role == 2) {
+      for (int s = 0; s < n; ++s) {
+        bl_half(1, 0, ca ^ 1, qa ^ 1);
+        __syncthreads();
+        __syncthreads();
+        ca ^= 1; qa ^= 1;
+      }
+    } else {
+      for (int s = 0; s < n; ++s) {
+        q_row(qa ^ 1);
+        __syncthreads();
+        __syncthreads();
+        ca ^= 1; qa ^= 1;
+      }
+    }
+  };
+
+  // ---- the tape: ONE call site of run_slot (the body holds five roles' code paths for both kinds of product), driven by a
+  // small state machine over the tape words; the inside of a run of squarings goes through run_squarings
   const tape_ptr_t tape = (tape_ptr_t)A.tape;
   int pend = 0, pend_f = 0, pend_ca = 0, pend_q = 0;      // the product whose pass 2 is outstanding
   int fcur = 0;                                           // F buffer of the next multiplication
@@ -540,6 +608,12 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   bool done = false;
   while (!done) {
     int kind = 0, f = 0, nx = -1;
+    if (rem > 2 && pend == 1) {
+      run_squarings(rem - 1);
+      rem = 1;
+      pend_ca = ca ^ 1; pend_q = qa ^ 1; pend_f = 0;       // (pend stays 1: the run's last product so far is a squaring)
+      continue;
+    }
     if (rem > 0) {
       kind = 1;
       --rem;
