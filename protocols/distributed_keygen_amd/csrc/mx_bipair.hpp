@@ -311,7 +311,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   const i64 elem = elem_raw < A.batch ? elem_raw : A.batch - 1;
   u32* slots = A.slots + (slot_id * 64 + lane);
   const int dig = role >> 1;                                                    // the digit an L wavefront owns in the slots
-  auto slot_at = [&](int sl, int j) -> u32& { return slots[(((i64)sl * 2 + dig) * L + j) * A.nlanes]; };
+  auto slot_at = [&](int sl, int j) __attribute__((always_inline)) -> u32& { return slots[(((i64)sl * 2 + dig) * L + j) * A.nlanes]; };
   const int nblk_lo = A.h_lo / L;
 
   M_t M;
@@ -392,7 +392,9 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   int qa = 0;          // QM[qa] receives the quotient digits of the A pair's product
   // ---- what each role does in a time slot (phase 1: its half of a product; phase 2, H wavefronts: the post).  `ca`, `qa` as
   // above; ca_b, qb: the same two of the product the B pair works on (one slot older).
-  auto ah_half = [&](int pa, int fa, u64 (&t)[L]) -> u32 {
+  // (always_inline: called from two places each, they were left as functions otherwise — their captures, LDS pointers among
+  // them, read back from a closure in scratch memory through flat loads: 29.8 ms instead of 9.9)
+  auto ah_half = [&](int pa, int fa, u64 (&t)[L]) __attribute__((always_inline)) -> u32 {
     u32 a[L];
     H.gather(a, CA + ca * ROW);
     if (pa == 1) {
@@ -402,7 +404,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     }
     return H.pre_rec(t, DG + qa * 8);
   };
-  auto bh_half = [&](int pb, int fb, int ca_b, u64 (&t)[L]) -> u32 {
+  auto bh_half = [&](int pb, int fb, int ca_b, u64 (&t)[L]) __attribute__((always_inline)) -> u32 {
     u32 x0[L], x1[L];
     H.gather(x0, CA + ca_b * ROW);
     H.gather(x1, CB);
@@ -413,7 +415,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     }
     return H.pre_rec(t, nullptr);
   };
-  auto al_half = [&](int pa, int fa) {
+  auto al_half = [&](int pa, int fa) __attribute__((always_inline)) {
     u32 a[L], r[L], q[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) a[j] = CA[ca * ROW + p * L + j];
@@ -430,7 +432,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
       if (p * L + j == A.pd) DG[qa * 8 + 6] = r[j];          // (TLA is this wavefront's again before Q reads it)
     }
   };
-  auto bl_half = [&](int pb, int fb, int ca_b, int qb) {
+  auto bl_half = [&](int pb, int fb, int ca_b, int qb) __attribute__((always_inline)) {
     u32 x0[L], x1[L], r[L], qq[L];
 #pragma unroll
     for (int j = 0; j < L; ++j) {
@@ -449,7 +451,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
 #pragma unroll
     for (int j = 0; j < L; ++j) TLB[p * L + j] = r[j];
   };
-  auto q_row = [&](int qb) {
+  auto q_row = [&](int qb) __attribute__((always_inline)) {
     // Qc = c * Vq + sum dg_k cf_k of the product whose pass 2 the B pair runs in this slot, for this lane's positions: from
     // the digits its pass 1 recorded one slot ago (V, DG: double buffers) into the row QC that wavefront BH adds in its post.
     // (Rounds of this work by the L wavefronts between the barriers cost 840 cycles of every slot, a lone wavefront issuing
@@ -494,7 +496,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     for (int j = 0; j < L; ++j) QC[p * L + j] = r[j];
   };
 
-  auto run_slot = [&](int pa, int fa, int pb, int fb, int ca_b, int qb, int nx_slot, int nxf) {
+  auto run_slot = [&](int pa, int fa, int pb, int fb, int ca_b, int qb, int nx_slot, int nxf) __attribute__((always_inline)) {
     u64 t[L];
     u32 dg0 = 0;
     u32 ynext[L];
@@ -538,16 +540,17 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     MX_BP_MARK(3)                                    // second barrier
   };
 
-  // ---- n squarings in a row whose predecessor is a squaring as well and that carry no look-ahead (the inside of a window's
-  // run): the same five halves, posts and two barriers per slot, but every wavefront stays in a loop of its own — no tape
-  // decode, no role dispatch and no operand-kind tests between two products.  (Every instruction of that control path was
-  // five cycles on the wavefront the others wait for; the run's first squaring — its predecessor is a multiplication — and
-  // its last — it fetches the next table pair — take the general path below.)
-  auto run_squarings = [&](int n) {
+  // ---- a whole window of the exponent — w squarings and the multiplication by table pair T behind them — with every wavefront
+  // in a loop of its own: the same halves, posts and two barriers per slot as run_slot, but no tape decode, no role dispatch and
+  // no look-ahead bookkeeping between two products (every instruction of that control path was five cycles on the wavefront
+  // the others wait for: 10.5 -> 9.9 ms for the inside of the runs alone).  Slot s < w: the A pair squares; slot w: it multiplies
+  // by F[f], which the L wavefronts fill from the slots during slot w - 1.  The B pair is one product behind: in slot 0 it
+  // finishes the product in front of the window (kind pb0 — 0: none —, F buffer fb0), then the squarings.
+  auto run_window = [&](int w, int pb0, int fb0, int T, int f) __attribute__((always_inline)) {
     if (role == 1) {
-      for (int s = 0; s < n; ++s) {
+      for (int s = 0; s <= w; ++s) {
         u64 t[L];
-        const u32 dg0 = ah_half(1, 0, t);
+        const u32 dg0 = ah_half(s < w ? 1 : 2, f, t);
         __syncthreads();
         u32 a[L];
         H.post(t, dg0, TLA, CA + (ca ^ 1) * ROW, a, A.pd);
@@ -555,32 +558,43 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
         ca ^= 1; qa ^= 1;
       }
     } else if (role == 3) {
-      for (int s = 0; s < n; ++s) {
+      for (int s = 0; s <= w; ++s) {
+        const int pb = s == 0 ? pb0 : 1;
         u64 t[L];
-        const u32 dg0 = bh_half(1, 0, ca ^ 1, t);
+        u32 dg0 = 0;
+        if (pb) dg0 = bh_half(pb, fb0, ca ^ 1, t);
         __syncthreads();
-        u32 a[L];
-        H.post_sum(t, dg0, TLB, QC, CB, a, A.pd);
-        __syncthreads();
-        ca ^= 1; qa ^= 1;
-      }
-    } else if (role == 0) {
-      for (int s = 0; s < n; ++s) {
-        al_half(1, 0);
-        __syncthreads();
+        if (pb) {
+          u32 a[L];
+          H.post_sum(t, dg0, TLB, QC, CB, a, A.pd);
+        }
         __syncthreads();
         ca ^= 1; qa ^= 1;
       }
-    } else if (role == 2) {
-      for (int s = 0; s < n; ++s) {
-        bl_half(1, 0, ca ^ 1, qa ^ 1);
+    } else if (role == 0 || role == 2) {
+      for (int s = 0; s <= w; ++s) {
+        u32 ynext[L];
+        if (s == w - 1) {
+#pragma unroll
+          for (int j = 0; j < L; ++j) ynext[j] = slot_at(T, j);
+        }
+        if (role == 0) {
+          al_half(s < w ? 1 : 2, f);
+        } else {
+          const int pb = s == 0 ? pb0 : 1;
+          if (pb) bl_half(pb, fb0, ca ^ 1, qa ^ 1);
+        }
         __syncthreads();
+        if (s == w - 1) {                  // digit 0 -> F[f][1] (Y0), digit 1 -> F[f][0] (Y1)
+#pragma unroll
+          for (int j = 0; j < L; ++j) F[(f * 2 + (dig == 0 ? 1 : 0)) * ROW + p * L + j] = ynext[j];
+        }
         __syncthreads();
         ca ^= 1; qa ^= 1;
       }
     } else {
-      for (int s = 0; s < n; ++s) {
-        q_row(qa ^ 1);
+      for (int s = 0; s <= w; ++s) {
+        if (s > 0 || pb0) q_row(qa ^ 1);
         __syncthreads();
         __syncthreads();
         ca ^= 1; qa ^= 1;
@@ -589,7 +603,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   };
 
   // ---- the tape: ONE call site of run_slot (the body holds five roles' code paths for both kinds of product), driven by a
-  // small state machine over the tape words; the inside of a run of squarings goes through run_squarings
+  // small state machine over the tape words; whole windows go through run_window
   const tape_ptr_t tape = (tape_ptr_t)A.tape;
   int pend = 0, pend_f = 0, pend_ca = 0, pend_q = 0;      // the product whose pass 2 is outstanding
   int fcur = 0;                                           // F buffer of the next multiplication
@@ -599,7 +613,7 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   // load at the point of use was 200 cycles in which none of the five wavefronts had anything to issue, 1200 times per launch)
   constexpr u32 TAPE_END = N2_MULC << 28;
   u32 w0 = A.ntape > 0 ? tape[0] : TAPE_END, w1 = A.ntape > 1 ? tape[1] : TAPE_END;
-  auto next_word = [&]() {
+  auto next_word = [&]() __attribute__((always_inline)) {
     ++k;
     w0 = w1;
     w1 = k + 1 < A.ntape ? tape[k + 1] : TAPE_END;
@@ -608,12 +622,6 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   bool done = false;
   while (!done) {
     int kind = 0, f = 0, nx = -1;
-    if (rem > 2 && pend == 1) {
-      run_squarings(rem - 1);
-      rem = 1;
-      pend_ca = ca ^ 1; pend_q = qa ^ 1; pend_f = 0;       // (pend stays 1: the run's last product so far is a squaring)
-      continue;
-    }
     if (rem > 0) {
       kind = 1;
       --rem;
@@ -638,6 +646,15 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
         }
         pos += arg;
         next_word();
+        if (run_nx >= 0 && rem >= 2 && pos < A.pos_end) {   // a whole window: the run and the multiplication behind it (now at k)
+          const int fw = fcur;
+          fcur ^= 1;
+          run_window(rem, pend, pend_f, run_nx, fw);
+          next_word();
+          rem = 0;
+          staged = -1;
+          pend = 2; pend_f = fw; pend_ca = ca ^ 1; pend_q = qa ^ 1;
+        }
         continue;
       } else if (op == N2_MUL) {
         if (staged != arg) {
