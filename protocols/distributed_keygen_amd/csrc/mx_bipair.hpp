@@ -394,9 +394,8 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   // above; ca_b, qb: the same two of the product the B pair works on (one slot older).
   // (always_inline: called from two places each, they were left as functions otherwise — their captures, LDS pointers among
   // them, read back from a closure in scratch memory through flat loads: 29.8 ms instead of 9.9)
-  auto ah_half = [&](int pa, int fa, u64 (&t)[L]) __attribute__((always_inline)) -> u32 {
-    u32 a[L];
-    H.gather(a, CA + ca * ROW);
+  auto ah_half = [&](int pa, int fa, u64 (&t)[L], u32 (&a)[L], bool fetch) __attribute__((always_inline)) -> u32 {
+    if (fetch) H.gather(a, CA + ca * ROW);          // (in a window AH keeps X0 = its own last post's Z0 in registers)
     if (pa == 1) {
       H.template half_rec<true>(t, a, CA + ca * ROW, A.pd, A.h_lo, V + qa * VROW + VOFF);
     } else {
@@ -509,7 +508,8 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     }
     // ---- phase 1
     if (role == 1 && pa) {                   // (the H wavefronts first: theirs is the longest path of a slot)
-      dg0 = ah_half(pa, fa, t);
+      u32 a[L];
+      dg0 = ah_half(pa, fa, t, a, true);
     } else if (role == 3 && pb) {
       dg0 = bh_half(pb, fb, ca_b, t);
     } else if (role == 0 && pa) {
@@ -548,11 +548,12 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   // finishes the product in front of the window (kind pb0 — 0: none —, F buffer fb0), then the squarings.
   auto run_window = [&](int w, int pb0, int fb0, int T, int f) __attribute__((always_inline)) {
     if (role == 1) {
+      u32 a[L];
+      H.gather(a, CA + ca * ROW);
       for (int s = 0; s <= w; ++s) {
         u64 t[L];
-        const u32 dg0 = ah_half(s < w ? 1 : 2, f, t);
+        const u32 dg0 = ah_half(s < w ? 1 : 2, f, t, a, false);
         __syncthreads();
-        u32 a[L];
         H.post(t, dg0, TLA, CA + (ca ^ 1) * ROW, a, A.pd);
         __syncthreads();
         ca ^= 1; qa ^= 1;
