@@ -404,12 +404,12 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
     return H.pre_rec(t, DG + qa * 8);
   };
   auto bh_half = [&](int pb, int fb, int ca_b, u64 (&t)[L]) __attribute__((always_inline)) -> u32 {
-    u32 x0[L], x1[L];
+    u32 x0[L], x1[L] = {0u, 0u, 0u};
     H.gather(x0, CA + ca_b * ROW);
-    H.gather(x1, CB);
     if (pb == 1) {
       H.template half2<false, true>(t, x0, x0, CB, CB, A.pd, A.h_lo);          // 2 X0 X1: multiplier limb doubled
     } else {
+      H.gather(x1, CB);
       H.template half2<true, false>(t, x0, x1, F + fb * 2 * ROW, F + (fb * 2 + 1) * ROW, A.pd, A.h_lo);
     }
     return H.pre_rec(t, nullptr);
