@@ -119,7 +119,7 @@ int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* 
  * one 10 000-ciphertext sequence; 4 (ABI 4.3; limbs_per_lane 3 or 0; moduli whose groups have 16 or 32 lanes: key_length
  * 1024 and 2048) = BOTH passes bipartite on two wavefronts each — four wavefronts per group of elements and a fifth that
  * forms the quotient correction one product behind —, the shortest dependent chain there is, for launches of at most one
- * workgroup per compute unit (a lone decrypt: 10.6 instead of 12.95 ms at key_length 2048); 0 = the library's choice (which takes 4 for such launches).  With both at 0 the library estimates the duration
+ * workgroup per compute unit (a lone decrypt: 9.4 instead of 12.95 ms at key_length 2048); 0 = the library's choice (which takes 4 for such launches).  With both at 0 the library estimates the duration
  * of ONE launch of this batch on an idle GPU for every shape and takes the shortest; callers that keep several
  * launches in flight fill the machine between them and should pass 18 / 1.  mx_nsquare_launch_shape reports the
  * choice.  Same result bit for bit in every shape.

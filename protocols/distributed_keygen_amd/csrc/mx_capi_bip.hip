@@ -23,11 +23,12 @@ static int launch(const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s)
   return MX_OK;
 }
 // groups of 16 / 32 lanes: moduli of ~800 .. 2700 bits (key_length 1024 and 2048)
-bool n2_bipair_instance(int K) { return K == 16 || K == 32; }
+bool n2_bipair_instance(int K) { return K == 16 || K == 32 || K == 64; }
 int launch_n2_bipair(int K, const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s) {
   switch (K) {
     case 16: return launch<16>(a, nblocks, s);
     case 32: return launch<32>(a, nblocks, s);
+    case 64: return launch<64>(a, nblocks, s);
   }
   return MX_ERR_SIZE;
 }

@@ -50,8 +50,9 @@ N2_CASES = [
     # at key_length 2048); batches that leave the last group ragged, more groups than one workgroup's two pairs
     ("n2", 2051, 18, 70, 200, 2, 2), ("n2", 2075, 18, 37, 200, 2, 2), ("n2", 4099, 18, 35, 96, 2, 2),
     # FOUR wavefronts per group (round 6, csrc/mx_bipair.hpp: both passes of every pair product bipartite), latency geometry,
-    # K = 16 and 32 (key_length 1024 / 2048); ragged last groups, a modulus that fills its geometry and one that does not
+    # K = 16, 32 and 64 (key_length 1024 / 2048 / 4096); ragged last groups, a modulus that fills its geometry and one that does not
     ("n2", 1027, 3, 9, 130, 4), ("n2", 1100, 3, 5, 300, 4), ("n2", 2051, 3, 5, 200, 4), ("n2", 1700, 3, 7, 64, 4), ("n2", 2535, 3, 3, 96, 4),
+    ("n2", 4099, 3, 3, 70, 4), ("n2", 3000, 3, 2, 64, 4), ("n2", 5300, 3, 1, 40, 4),
     # the library's choice: a handful of elements -> the latency geometry on four wavefronts where that form exists, on two elsewhere
     ("n2", 2051, 0, 7, 64, 0), ("n2", 4099, 0, 7, 64, 0),
 ]

@@ -17,7 +17,7 @@ import bipair_model as bp  # noqa: E402
 from bimont_model import Geometry, L, MASK, W, limbs_of, value_of  # noqa: E402
 
 
-@pytest.mark.parametrize("bits", [1027, 1029, 2051, 2053, 1500])
+@pytest.mark.parametrize("bits", [1027, 1029, 2051, 2053, 1500, 4099])
 def test_chains_of_pair_products_match_big_integer_arithmetic(bits):
     rng = random.Random(bits)
     for n in (rng.getrandbits(bits) | (1 << (bits - 1)) | 1, (1 << bits) - 1, (1 << (bits - 1)) + 1):
@@ -70,7 +70,7 @@ def test_the_whole_flow_with_the_kernels_constants():
     (radix 2^(W Pd), as the two-wavefront kernel's last segment runs it) by E = (2^(W (Pd - hL)), 0) leaves digits below 2 N
     whose N-adic value is the residue."""
     rng = random.Random(9)
-    for bits in (2053, 1029):
+    for bits in (2053, 1029, 4099):
         n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
         n2 = n * n
         geo = Geometry(bits)

@@ -33,7 +33,7 @@ def test_every_reachable_instance_has_a_parity_case():
         assert {k for _, k, l, w, fr, ts in n2 if l == 18 and w == wpg} == {1, 2, 4, 8, 16}
     assert {k for _, k, l, w, fr, ts in n2 if l == 3 and w == 2} == {1, 2, 4, 8, 16, 32, 64}
     assert not {k for _, k, l, w, fr, ts in n2 if l == 3 and w == 1}     # latency geometries are split only
-    assert {k for _, k, l, w, fr, ts in n2 if w == 4} == {16, 32} and all(l == 3 and fr and not ts for _, k, l, w, fr, ts in n2 if w == 4)   # four-wavefront form (round 6)
+    assert {k for _, k, l, w, fr, ts in n2 if w == 4} == {16, 32, 64} and all(l == 3 and fr and not ts for _, k, l, w, fr, ts in n2 if w == 4)   # four-wavefront form (round 6)
     # the friendly-modulus and the time-sliced instances are instances of their own (VERDICT r03 "weak" 1b)
     assert {(k, l, w) for _, k, l, w, fr, ts in n2 if fr and l != 3} == {(8, 9, 2), (16, 9, 2), (4, 18, 1), (8, 18, 1)}
     assert {(k, l, w, fr) for _, k, l, w, fr, ts in n2 if ts} >= {(8, 9, 2, 1), (8, 9, 2, 0), (16, 9, 2, 1)}

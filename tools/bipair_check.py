@@ -15,7 +15,7 @@ from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 eng = Engine()
 rng = random.Random(int(sys.argv[1]) if len(sys.argv) > 1 else 1)
 bad = 0
-for nb in (2051, 2053, 1027, 1029, 2050, 1500, 2600):
+for nb in (2051, 2053, 1027, 1029, 2050, 1500, 2600, 4099, 4102, 5300, 5700):
     for trial in range(3):
         n = [rng.getrandbits(nb) | (1 << (nb - 1)) | 1, (1 << nb) - 1, (1 << (nb - 1)) + 1][trial]
         n2 = n * n
@@ -28,7 +28,7 @@ for nb in (2051, 2053, 1027, 1029, 2050, 1500, 2600):
             try:
                 got = eng.powmod_nsquare_batch(bases, e, n)
             except Exception as exc:
-                if nb == 2600 and "MX_ERR_SIZE" in str(exc):        # beyond the form's instances: refused, not computed
+                if nb == 5700 and "MX_ERR_SIZE" in str(exc):        # beyond the form's instances: refused, not computed
                     break
                 print("ERROR", nb, trial, ebits, batch, type(exc).__name__, exc)
                 bad += 1

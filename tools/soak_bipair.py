@@ -29,11 +29,11 @@ def soak(eng, seed, seconds=None, rounds_limit=None, procs=16):
     rounds = done = 0
     # modulus lengths with an instance of the form (probed through the library's own query)
     lens = []
-    for nb in list(range(600, 2800, 13)) + [1026, 1027, 1028, 1029, 2050, 2051, 2052, 2053]:
+    for nb in list(range(600, 2800, 13)) + list(range(2800, 5700, 61)) + [1026, 1027, 1028, 1029, 2050, 2051, 2052, 2053, 4098, 4099, 4100, 4102]:
         k, l, wv, fr, ts = (ctypes.c_int() for _ in range(5))
         if eng.lib.mx_nsquare_launch_instance(nb, 1, 3, 4, k, l, wv, fr, ts) == 0:
             lens.append(nb)
-    assert lens and min(lens) < 900 and max(lens) > 2500, (min(lens), max(lens))
+    assert lens and min(lens) < 900 and max(lens) > 5000, (min(lens), max(lens))
     try:
         while (seconds is None or time.time() - t0 < seconds) and (rounds_limit is None or rounds < rounds_limit):
             rounds += 1
