@@ -465,7 +465,7 @@ def test_bipartite_form_with_moduli_of_different_lengths_in_one_launch(eng):
         eng.set_limbs_per_lane(0)
 
 
-@pytest.mark.parametrize("n_bits", [1027, 1029, 2050, 2051, 2053, 1500, 900])
+@pytest.mark.parametrize("n_bits", [1027, 1029, 2050, 2051, 2053, 1500, 900, 4099, 3100])
 def test_four_wavefront_latency_form_of_the_pair_kernel(eng, n_bits):
     """csrc/mx_bipair.hpp (round 6): both passes of every pair product bipartite, four wavefronts per group of elements and a fifth for the quotient correction —
     what a lone decrypt() and every launch of at most one workgroup per compute unit run at key_length 1024 / 2048.
@@ -511,12 +511,13 @@ def test_four_wavefront_latency_form_of_the_pair_kernel(eng, n_bits):
 
 
 def test_four_wavefront_form_exists_only_where_its_kernel_does(eng):
-    """Groups of 16 and 32 lanes (moduli of ~700 .. 2700 bits); an explicit request elsewhere is refused, the library's own
-    choice falls back to two wavefronts."""
+    """Groups of 16, 32 and 64 lanes (moduli of ~800 .. 2560 and ~2800 .. 5500 bits: key_length 1024, 2048, 4096); an explicit
+    request elsewhere — below, and between the ranges, where the two geometries the form combines disagree — is refused, the
+    library's own choice falls back to two wavefronts."""
     from protocols.distributed_keygen_amd._lib import MxError
 
     rng = random.Random(3)
-    for n_bits in (300, 4099):
+    for n_bits in (300, 2600):
         n = rng.getrandbits(n_bits) | (1 << (n_bits - 1)) | 1
         bases = [rng.randrange(n * n) for _ in range(3)]
         try:

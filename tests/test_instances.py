@@ -60,7 +60,7 @@ def test_auto_launch_shapes_match_the_measured_crossovers():
                         (6144, (4, 18, 2)), (8192, (4, 18, 2)), (10000, (4, 18, 2)), (12288, (4, 18, 2)), (16384, (4, 18, 1)),
                         (20000, (4, 18, 2)), (24576, (4, 18, 2)), (30000, (4, 18, 1))):
         assert shape(2051, batch) == ("n2",) + want, batch
-    for batch, want in ((1, (64, 3, 2)), (512, (64, 3, 2)), (1024, (64, 3, 2)), (2048, (16, 9, 2)), (4096, (8, 18, 2)), (16000, (8, 18, 1))):
+    for batch, want in ((1, (64, 3, 4)), (256, (64, 3, 4)), (257, (64, 3, 2)), (512, (64, 3, 2)), (1024, (64, 3, 2)), (2048, (16, 9, 2)), (4096, (8, 18, 2)), (16000, (8, 18, 1))):
         assert shape(4099, batch) == ("n2",) + want, batch
     assert shape(1027, 256) == ("n2", 16, 3, 4) and shape(1027, 1025) == ("n2", 16, 3, 2) and shape(1027, 1000000)[3] == 1
     # an explicit argument pins that half of the choice
