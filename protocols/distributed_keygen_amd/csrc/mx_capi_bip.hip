@@ -22,7 +22,7 @@ static int launch(const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s)
 #endif
   return MX_OK;
 }
-// groups of 16 / 32 lanes: moduli of ~800 .. 2700 bits (key_length 1024 and 2048)
+// groups of 16 / 32 / 64 lanes: moduli of ~800 .. 2560 and ~2800 .. 5500 bits (key_length 1024, 2048, 4096)
 bool n2_bipair_instance(int K) { return K == 16 || K == 32 || K == 64; }
 int launch_n2_bipair(int K, const mx::PowmodBiPairArgs& a, int64_t nblocks, hipStream_t s) {
   switch (K) {

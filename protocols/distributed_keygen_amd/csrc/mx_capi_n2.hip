@@ -233,9 +233,9 @@ N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
   }
   if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1, 0, 0};   // reported as MX_ERR_SIZE by the caller
   // Launches that the two-wavefront latency form would run with at most ONE workgroup of the five-wavefront form per compute
-  // unit take that form where it exists (key_length 1024 / 2048): both passes of every product on two wavefronts each,
-  // 11.3 instead of 12.95 ms for 1 .. 512 ciphertexts at key_length 2048 (tools/bipair_check.py, profiles/r06_bipair_*);
-  // a second workgroup per unit costs more than it saves (1024: 15.0 against 13.4 ms).
+  // unit take that form where it exists (key_length 1024 / 2048 / 4096): both passes of every product on two wavefronts each,
+  // 9.4 instead of 12.95 ms for 1 .. 512 ciphertexts at key_length 2048, 38.9 instead of 47 for 1 .. 256 at 4096
+  // (tools/lone_decrypt_time.py, profiles/r06_lone_decrypt.txt); a second workgroup per unit costs more than it saves.
   if (wpg == 0 && best.lpl == LIMBS_PER_LANE_LAT && best.wpg == 2 && g_knob_n2_bipair != 1) {
     Geometry gb;
     if (bipair_geometry(n_bits, gb) && batch <= (int64_t)device_cus() * (64 / gb.K)) best.wpg = 4;

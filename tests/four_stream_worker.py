@@ -13,7 +13,7 @@ what = "nsquare": powmod_nsquare at key_length 2048 with a full-length exponent 
 two-wavefront groups, 3 / 9 / 18 limbs per lane, time-sliced, and the five-wavefront latency form), 4 x 10 000 rows = 4 x 625 wavefronts of the 18-limb shape
 on 1024 SIMDs; "biprime": biprime_v_t (Jacobi filter, selection, generic fixed-window modexps in every lane geometry incl. the
 bipartite latency form) at key_length 2048;
-"jacobi8192": the 257-word Jacobi instance; "k4096": the K = 16 friendly and time-sliced shapes at key_length 4096.
+"jacobi8192": the 257-word Jacobi instance; "k4096": the K = 16 friendly and time-sliced shapes and the five-wavefront latency form (K = 64) at key_length 4096.
 Every row of every stream is compared with pow() computed on the host cores (tests/hostpow.py: libgmp's mpz_powm, itself
 checked against CPython pow in every worker process) / the oracle.  Prints "ok <what> rows=<rows> ..." per leg."""
 import multiprocessing as mp
@@ -72,7 +72,7 @@ def main() -> None:
         limbs2 = L.limbs_for(n2)
         c_t, want_t = eng.to_device(L.pack(cts, limbs2)), eng.to_device(L.pack(want, limbs2))
         shapes = (((18, 1, 0), (9, 1, 0), (18, 2, 0), (9, 2, 0), (9, 2, 2), (18, 2, 2), (3, 2, 0), (3, 4, 0)) if what == "nsquare" else
-                  ((18, 1, 0), (9, 2, 0), (9, 2, 2), (18, 2, 0), (18, 2, 2)))
+                  ((18, 1, 0), (9, 2, 0), (9, 2, 2), (18, 2, 0), (18, 2, 2), (3, 4, 0)))
         try:
             for lpl, wpg, sliced in shapes:
                 eng.set_limbs_per_lane(lpl)
