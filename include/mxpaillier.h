@@ -119,7 +119,7 @@ int mx_powmod_nsquare(const uint32_t* d_bases, uint32_t* d_out, const uint32_t* 
  * one 10 000-ciphertext sequence; 4 (ABI 4.3; limbs_per_lane 3 or 0; moduli whose groups have 16, 32 or 64 lanes: key_length
  * 1024, 2048 and 4096 — ~800 .. 2560 and ~2800 .. 5500 bits, MX_ERR_SIZE elsewhere) = BOTH passes bipartite on two wavefronts each — four wavefronts per group of elements and a fifth that
  * forms the quotient correction one product behind —, the shortest dependent chain there is, for launches of at most one
- * workgroup per compute unit (a lone decrypt: 9.4 instead of 12.95 ms at key_length 2048, 38.9 instead of 47 at 4096); 0 = the library's choice (which takes 4 for such launches).  With both at 0 the library estimates the duration
+ * workgroup per compute unit (a lone decrypt: 9.4 instead of 12.95 ms at key_length 2048, 31.8 instead of 47 at 4096); 0 = the library's choice (which takes 4 for such launches).  With both at 0 the library estimates the duration
  * of ONE launch of this batch on an idle GPU for every shape and takes the shortest; callers that keep several
  * launches in flight fill the machine between them and should pass 18 / 1.  mx_nsquare_launch_shape reports the
  * choice.  Same result bit for bit in every shape.

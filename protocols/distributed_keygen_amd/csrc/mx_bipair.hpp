@@ -547,15 +547,22 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
   // by F[f], which the L wavefronts fill from the slots during slot w - 1.  The B pair is one product behind: in slot 0 it
   // finishes the product in front of the window (kind pb0 — 0: none —, F buffer fb0), then the squarings.
   auto run_window = [&](int w, int pb0, int fb0, int T, int f) __attribute__((always_inline)) {
+#ifdef MX_DEV_BP_TRACE
+    u64 mark_ = __builtin_readcyclecounter();       // (the probe's four intervals per slot, as in run_slot)
+#endif
     if (role == 1) {
       u32 a[L];
       H.gather(a, CA + ca * ROW);
       for (int s = 0; s <= w; ++s) {
         u64 t[L];
         const u32 dg0 = ah_half(s < w ? 1 : 2, f, t, a, false);
+        MX_BP_MARK(0)
         __syncthreads();
+        MX_BP_MARK(1)
         H.post(t, dg0, TLA, CA + (ca ^ 1) * ROW, a, A.pd);
+        MX_BP_MARK(2)
         __syncthreads();
+        MX_BP_MARK(3)
         ca ^= 1; qa ^= 1;
       }
     } else if (role == 3) {
@@ -564,12 +571,16 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
         u64 t[L];
         u32 dg0 = 0;
         if (pb) dg0 = bh_half(pb, fb0, ca ^ 1, t);
+        MX_BP_MARK(0)
         __syncthreads();
+        MX_BP_MARK(1)
         if (pb) {
           u32 a[L];
           H.post_sum(t, dg0, TLB, QC, CB, a, A.pd);
         }
+        MX_BP_MARK(2)
         __syncthreads();
+        MX_BP_MARK(3)
         ca ^= 1; qa ^= 1;
       }
     } else if (role == 0 || role == 2) {
@@ -585,19 +596,27 @@ __global__ void __launch_bounds__(BP_THREADS) powmod_n2_bipair_kernel(PowmodBiPa
           const int pb = s == 0 ? pb0 : 1;
           if (pb) bl_half(pb, fb0, ca ^ 1, qa ^ 1);
         }
+        MX_BP_MARK(0)
         __syncthreads();
+        MX_BP_MARK(1)
         if (s == w - 1) {                  // digit 0 -> F[f][1] (Y0), digit 1 -> F[f][0] (Y1)
 #pragma unroll
           for (int j = 0; j < L; ++j) F[(f * 2 + (dig == 0 ? 1 : 0)) * ROW + p * L + j] = ynext[j];
         }
+        MX_BP_MARK(2)
         __syncthreads();
+        MX_BP_MARK(3)
         ca ^= 1; qa ^= 1;
       }
     } else {
       for (int s = 0; s <= w; ++s) {
         if (s > 0 || pb0) q_row(qa ^ 1);
+        MX_BP_MARK(0)
         __syncthreads();
+        MX_BP_MARK(1)
+        MX_BP_MARK(2)
         __syncthreads();
+        MX_BP_MARK(3)
         ca ^= 1; qa ^= 1;
       }
     }

@@ -234,7 +234,7 @@ N2Choice n2_auto_shape(int n_bits, int64_t batch, int limbs_per_lane, int wpg) {
   if (best_t < 0) best = N2Choice{limbs_per_lane ? limbs_per_lane : LIMBS_PER_LANE, wpg ? wpg : 1, 0, 0};   // reported as MX_ERR_SIZE by the caller
   // Launches that the two-wavefront latency form would run with at most ONE workgroup of the five-wavefront form per compute
   // unit take that form where it exists (key_length 1024 / 2048 / 4096): both passes of every product on two wavefronts each,
-  // 9.4 instead of 12.95 ms for 1 .. 512 ciphertexts at key_length 2048, 38.9 instead of 47 for 1 .. 256 at 4096
+  // 9.4 instead of 12.95 ms for 1 .. 512 ciphertexts at key_length 2048, 31.8 instead of 47 for 1 .. 256 at 4096
   // (tools/lone_decrypt_time.py, profiles/r06_lone_decrypt.txt); a second workgroup per unit costs more than it saves.
   if (wpg == 0 && best.lpl == LIMBS_PER_LANE_LAT && best.wpg == 2 && g_knob_n2_bipair != 1) {
     Geometry gb;
@@ -261,6 +261,20 @@ bool bipair_geometry(int n_bits, Geometry& gb) {
   if (!choose_geometry(n_bits, gb, LIMBS_PER_LANE_BI) || !choose_geometry(n_bits, g3, LIMBS_PER_LANE_LAT)) return false;
   if (gb.K != g3.K || gb.nblk != g3.nblk || !mxb::n2_bipair_instance(gb.K)) return false;
   const int pd = gb.L * gb.nblk;
+  // The pivot of the PAIR form (tools/bipair_model.py: pair_geometry): 0.52 of the steps on the L wavefronts, to the nearest
+  // block — 21 of 42 at key_length 1024, 39 of 75 at 2048, 75 of 147 at 4096.  The generic form's pivot (mx_host.hpp: 24, 39,
+  // 54) is fitted to ITS halves; here the H wavefronts record fold digits or carry two product rows, and at K = 64 its 54
+  // left the L wavefronts waiting for 45 % of every slot (tools/bp_phase_probe.py; one decrypt 38.9 -> 31.5 ms, 3.55 -> 3.27 ms
+  // at key_length 1024; profiles/r06_bipair_pivot_sweep.txt).
+  if (g_knob_bi_pivot <= 0) {
+    const int steps = pd + gb.L;
+    int h = gb.L * ((52 * steps + 150) / (100 * gb.L));
+    if (h > steps - gb.L) h = steps - gb.L;
+    if (h < gb.L) h = gb.L;
+    const int lo_min = gb.L * ((pd - (n_bits - 2) / gb.W + gb.L - 1) / gb.L);
+    if (h < lo_min) h = lo_min;
+    gb.h_lo = h;
+  }
   return gb.h_lo < pd && LIMB_BITS * (pd - gb.h_lo) < n_bits - 1;      // E = 2^(W (Pd - hL)) is a digit below N
 }
 // its section of a plan's device block, behind the tape: constants for R' = 2^(W hL) | fold rows | quotient rows

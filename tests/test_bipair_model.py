@@ -21,7 +21,7 @@ from bimont_model import Geometry, L, MASK, W, limbs_of, value_of  # noqa: E402
 def test_chains_of_pair_products_match_big_integer_arithmetic(bits):
     rng = random.Random(bits)
     for n in (rng.getrandbits(bits) | (1 << (bits - 1)) | 1, (1 << bits) - 1, (1 << (bits - 1)) + 1):
-        geo = Geometry(bits)
+        geo = bp.pair_geometry(bits)
         cst = bp.PairConstants(n, geo)
         n2 = n * n
         track = {}
@@ -43,7 +43,7 @@ def test_every_width_holds_for_operands_at_their_bounds():
     the value identity and every asserted width (fold digits, carry words, 64-bit columns, quotient columns) still hold."""
     rng = random.Random(5)
     bits = 2053
-    geo = Geometry(bits)
+    geo = bp.pair_geometry(bits)
     cnt = L * geo.K
     big = (1 << W) + (1 << 7) - 1
 
@@ -73,7 +73,7 @@ def test_the_whole_flow_with_the_kernels_constants():
     for bits in (2053, 1029, 4099):
         n = rng.getrandbits(bits) | (1 << (bits - 1)) | 1
         n2 = n * n
-        geo = Geometry(bits)
+        geo = bp.pair_geometry(bits)
         cst = bp.PairConstants(n, geo)
         cnt = L * geo.K
         m, k = W * geo.h_lo, bits - 1

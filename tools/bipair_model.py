@@ -26,6 +26,15 @@ sys.path.insert(0, str(Path(__file__).resolve().parent))
 from bimont_model import L, MASK, U32, U64, W, Constants, Geometry, limbs_of, sq_weight, value_of  # noqa: E402
 
 
+def pair_geometry(nbits: int) -> Geometry:
+    """The geometry of the pair form (csrc/mx_capi_n2.hip: bipair_geometry): the bipartite geometry with a pivot of its own —
+    0.52 of the steps on the L wavefronts, to the nearest block."""
+    g = Geometry(nbits)
+    steps = g.Pd + L
+    h = min(L * ((52 * steps + 150) // (100 * L)), steps - L)
+    return Geometry(nbits, h)
+
+
 class PairConstants(Constants):
     def __init__(self, n: int, geo: Geometry) -> None:
         super().__init__(n, geo)

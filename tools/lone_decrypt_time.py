@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """One decrypt() at key_length 2048 in the latency form of the pair kernel, best and median of N calls (the number the
 bench's latency leg reports, without the bench around it) — for A/B runs of library variants through MX_LIBRARY
-(tools/build_variant.py).   usage: lone_decrypt_time.py [key_length] [calls]"""
+(tools/build_variant.py).   usage: lone_decrypt_time.py [key_length] [calls] [pivot]   (pivot: developer knob bi_pivot — the
+multiplier limbs on the L wavefronts — for sweeps of the split)"""
 import os
 import statistics
 import sys
@@ -13,6 +14,8 @@ import torch
 from protocols.distributed_keygen_amd import Engine, limbs as L, synthetic
 
 eng = Engine()
+if len(sys.argv) > 3:
+    eng.debug_knob("bi_pivot", int(sys.argv[3]))
 key = synthetic.make_key(int(sys.argv[1]) if len(sys.argv) > 1 else 2048, 3, 1)
 calls = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 own = next(i for i in (1, 2, 3) if key.exponent(i) > 0)
@@ -30,4 +33,4 @@ for i in range(calls + 2):
 got = L.unpack(eng.to_host(out))[0]
 shape = eng.nsquare_launch_shape(n.bit_length(), 1)
 print(f"lone decrypt: best {min(times[2:]):.3f} ms, median {statistics.median(times[2:]):.3f} ms over {calls} calls; "
-      f"bit-exact {got == want}; library {os.environ.get('MX_LIBRARY', 'shipped')}; shape {shape}")
+      f"bit-exact {got == want}; library {os.environ.get('MX_LIBRARY', 'shipped')}; shape {shape}" + (f"; pivot {sys.argv[3]}" if len(sys.argv) > 3 else ""))
