@@ -1280,6 +1280,8 @@ def compact_result(out: dict) -> dict:
         summary[name] = _leg_summary(leg)
         if isinstance(leg, dict) and leg.get("n_gpus", 1) > 1:
             summary[name]["n_gpus"] = leg["n_gpus"]
+        if isinstance(leg, dict) and isinstance(leg.get("latency"), dict) and "n1" in leg["latency"]:
+            summary[name]["latency_ms"] = _num(leg["latency"]["n1"].get("ms"), 4)       # one decrypt() at this key length
     sk = out.get("short_kernels")
     if isinstance(sk, dict):
         summary["short_kernels"] = ({"error": str(sk["error"])[:80]} if "error" in sk else
@@ -1572,9 +1574,13 @@ def main() -> None:
                             bases = [c if c5wl.exps[c5wl.own] >= 0 else pow(c, -1, c5wl.n2) for c in c5wl.cts[:32]]
                             c5["cpu_baseline"] = cpu_baseline(c5wl.n2, c5wl.own_exp, bases, min(args.cpu_seconds, 3.0),
                                                               "same modulus/exponent, first 32 ciphertexts cycled")
+                        if cpu:
+                            # the lone call at this key length (decrypt() of ONE ciphertext, 64, 1024), as leg `latency` at 2048
+                            lat = leg_latency(eng, torch, c5wl, (c5.get("cpu_baseline") or {}).get("single_core_value"))
+                            c5["latency"] = {k: lat[k] for k in ("unit", "n1", "n64", "n1024", "gmpy2_one_core_ms", "vs_gmpy2_one_core") if k in lat}
                         del c5wl
                         torch.cuda.empty_cache()
-                        return {k: c5[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "cpu_baseline") if k in c5}
+                        return {k: c5[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "cpu_baseline", "latency") if k in c5}
 
                     out["extra"]["biprime_k2048"] = guarded("biprime_k2048", lambda: biprime_leg(2048, 4096, 8, True))
                     # configs[1]: key_length 1024, at the size of a keygen round's survivors and at a saturating size
