@@ -380,6 +380,12 @@ int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs_per_lane, 
  * template instance: every 3-limb one, the 9-limb two-wavefront ones for groups of 8 / 16 lanes and the 18-limb
  * one-wavefront ones for groups of 4 / 8 lanes where the modulus leaves the room), *timesliced = 1 for the time-sliced
  * form.  A friendly one-wavefront launch also runs the plain instance of the same geometry (last product, epilogue). */
+/* The five-wavefront latency form (wavefronts_per_group 4) for moduli of n_bits bits (ABI 4.4): MX_ERR_SIZE where it has no
+ * instance; otherwise *lanes per element (16, 32 or 64), the data *positions Pd of its rows, its *pivot (multiplier limbs on the
+ * least-significant-first wavefronts: 0.52 of Pd + 3 to the nearest multiple of 3 — tools/bipair_model.py: pair_geometry) and the
+ * largest batch (*max_batch: one workgroup per compute unit of the current device) for which mx_powmod_nsquare_run takes
+ * the form by itself.  Any of the pointers may be NULL. */
+int mx_nsquare_latency_form(int n_bits, int* lanes, int* positions, int* pivot, int64_t* max_batch);
 int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                                int* lanes_per_element, int* limbs_per_lane_out, int* wavefronts_per_group_out,
                                int* friendly, int* timesliced);

@@ -56,6 +56,7 @@ SYMBOLS = {
     "mx_powmod_nsquare_run": (c_int, [POINTER(NsquarePlan), c_void_p, c_void_p, c_int, c_int64, c_int, c_int, c_int, c_void_p, c_int64, c_void_p]),
     "mx_nsquare_launch_shape": (c_int, [c_int, c_int64, c_int, c_int, *_P4, POINTER(c_int)]),
     "mx_nsquare_launch_instance": (c_int, [c_int, c_int64, c_int, c_int, *[POINTER(c_int)] * 5]),
+    "mx_nsquare_latency_form": (c_int, [c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int), POINTER(c_int64)]),
     "mx_nsquare_launch_split": (c_int, [c_int, c_int64, POINTER(c_int64), *[POINTER(c_int)] * 4]),
     "mx_nsquare_launch_timesliced": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_int), POINTER(c_int)]),
     "mx_nsquare_pieces_shape": (c_int, [c_int, c_int64, c_int, c_int, POINTER(c_int), POINTER(c_int)]),

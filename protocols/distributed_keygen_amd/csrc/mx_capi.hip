@@ -318,7 +318,7 @@ __global__ void lanes_selftest_kernel(int* out) {
 
 extern "C" {
 
-int mx_version(void) { return 403; }
+int mx_version(void) { return 404; }
 
 const char* mx_error_string(int code) {
   switch (code) {

@@ -395,6 +395,17 @@ extern "C" int mx_nsquare_launch_timesliced(int n_bits, int64_t batch, int limbs
   return MX_OK;
 }
 
+extern "C" int mx_nsquare_latency_form(int n_bits, int* lanes, int* positions, int* pivot, int64_t* max_batch) {
+  if (n_bits < 2) return MX_ERR_ARG;
+  Geometry gb;
+  if (!bipair_geometry(n_bits, gb)) return MX_ERR_SIZE;
+  if (lanes) *lanes = gb.K;
+  if (positions) *positions = gb.L * gb.nblk;
+  if (pivot) *pivot = gb.h_lo;
+  if (max_batch) *max_batch = (int64_t)device_cus() * (64 / gb.K);
+  return MX_OK;
+}
+
 extern "C" int mx_nsquare_launch_instance(int n_bits, int64_t batch, int limbs_per_lane, int wavefronts_per_group,
                                           int* k, int* l, int* wavefronts, int* friendly, int* timesliced) {
   if (!k || !l || !wavefronts || !friendly || !timesliced || batch <= 0) return MX_ERR_ARG;

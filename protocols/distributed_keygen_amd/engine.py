@@ -384,6 +384,18 @@ class Engine:
         _lib.check(self.lib.mx_nsquare_launch_shape(n_bits, batch, self._lpl_n2(), self._wpg, k, l, w, b, wv), "mx_nsquare_launch_shape")
         return k.value, l.value, w.value, b.value, wv.value
 
+    def nsquare_latency_form(self, n_bits: int) -> Optional[Tuple[int, int, int, int]]:
+        """(lanes per element, data positions, pivot, largest batch the library takes the form for by itself) of the
+        five-wavefront latency form of powmod_nsquare for moduli of n_bits bits, or None where it has no instance."""
+        import ctypes
+
+        k, pd, pivot, most = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        rc = self.lib.mx_nsquare_latency_form(n_bits, k, pd, pivot, most)
+        if rc == -2:                                  # MX_ERR_SIZE
+            return None
+        _lib.check(rc, "mx_nsquare_latency_form")
+        return k.value, pd.value, pivot.value, most.value
+
     def saturating_shape(self, n_bits: int, total: int) -> Tuple[int, int]:
         """(limbs per lane, wavefronts per group) for powmod_nsquare launches that run SIDE BY SIDE on several
         streams, `total` elements between them.  When they bring about two wavefronts per SIMD or more at one

@@ -95,3 +95,23 @@ def test_the_whole_flow_with_the_kernels_constants():
         z0, q = redc(x0 * e0)
         z1, _ = redc(x1 * e0 + n * (-(-r // n)) - q)
         assert z0 < 2 * n and z1 < 2 * n + 2 and (z0 + z1 * n) % n2 == x
+
+
+def test_the_librarys_geometry_of_the_form_is_the_models():
+    """mx_nsquare_latency_form (ABI 4.4): lanes, data positions and the pair form's own pivot as tools/bipair_model.py's
+    pair_geometry has them, over the three ranges of instances; refused below, between and beyond them."""
+    import ctypes
+
+    sys.path.insert(0, str(Path(__file__).resolve().parent.parent))
+    from protocols.distributed_keygen_amd import _lib
+
+    lib = _lib.lib()
+    for bits in (830, 1027, 1029, 1500, 2051, 2053, 2535, 2900, 3100, 4099, 4102, 5300):
+        geo = bp.pair_geometry(bits)
+        k, pd, pivot, most = ctypes.c_int(), ctypes.c_int(), ctypes.c_int(), ctypes.c_int64()
+        assert lib.mx_nsquare_latency_form(bits, k, pd, pivot, most) == 0, bits
+        assert (k.value, pd.value, pivot.value) == (geo.K, geo.Pd, geo.h_lo), (bits, k.value, pd.value, pivot.value, geo.K, geo.Pd, geo.h_lo)
+        assert most.value % (64 // geo.K) == 0 and most.value > 0
+    assert {bits: bp.pair_geometry(bits).h_lo for bits in (1027, 2051, 4099)} == {1027: 21, 2051: 39, 4099: 75}
+    for bits in (300, 2600, 5700):
+        assert lib.mx_nsquare_latency_form(bits, None, None, None, None) == -2      # MX_ERR_SIZE

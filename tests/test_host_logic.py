@@ -33,8 +33,9 @@ def test_library_builds_loads_and_exports_every_declared_symbol():
     # 3.2: mx_nsquare_launch_instance, MX_KNOB_N2_FRIENDLY_1W; 3.3: limbs_per_lane 3 for the generic kernel,
     # mx_nsquare_launch_split, MX_KNOB_GENERIC_LATENCY / MX_KNOB_N2_SPLIT
     # 4.0: mx_set_limbs_per_lane removed (no process-wide launch-shape state), knobs atomic, mx_powmod_nsquare_prepare_ex
-    # with MX_PLAN_FIXED_WINDOW
-    assert lib.mx_version() == 403
+    # with MX_PLAN_FIXED_WINDOW; 4.3: wavefronts_per_group 4 (the five-wavefront latency form), MX_KNOB_N2_BIPAIR;
+    # 4.4: mx_nsquare_latency_form
+    assert lib.mx_version() == 404
     assert lib.mx_error_string(-3).decode().startswith("modulus")
 
 
