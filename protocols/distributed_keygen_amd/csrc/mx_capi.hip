@@ -954,8 +954,9 @@ extern "C" int mx_modinv(const uint32_t* d_values, uint32_t* d_out, uint8_t* d_s
   MX_TRY(upload_words(d_ws, h_mod, (size_t)limbs, s));
   mx::ModinvArgs a;
   a.vals = d_values; a.mod = (const u32*)d_ws; a.out = d_out; a.status = d_status; a.batch = batch; a.limbs = limbs;
-  // the almost-inverse keeps values below 2 M: capacity 64 * LPL words >= bits + 2, and >= limbs words
-  const int need = std::max(limbs, (bits + 2 + 31) / 32);
+  // the almost-inverse keeps values below 2 M, the word-wise halvings form x + q M with a one-word q: capacity
+  // 64 * LPL words >= bits + 34 bits, and >= limbs words
+  const int need = std::max(limbs, (bits + 34 + 31) / 32);
   if (need <= 64) return launch_modinv<1>(a, s);
   if (need <= 128) return launch_modinv<2>(a, s);
   if (need <= 192) return launch_modinv<3>(a, s);

@@ -15,8 +15,9 @@
 // All branch conditions are wave-uniform (scalar), so the wavefront never diverges.
 //
 // Algorithm: Kaliski's almost-inverse (u = M, v = a, r = 0, s = 1; k halving steps keeping
-// M = u*s + v*r), giving a^-1 * 2^k mod M with only shifts, additions and subtractions, followed by
-// k halvings modulo M.  gcd(a, M) != 1 (incl. a = 0) is reported in the status byte, like the
+// M = u*s + v*r), giving a^-1 * 2^k mod M with only shifts, additions and subtractions — the trailing
+// zeros a subtraction leaves taken in the same trip of the loop —, followed by k halvings modulo M,
+// 32 at a time (one multiply-accumulate of M per word: a Montgomery reduction step).  gcd(a, M) != 1 (incl. a = 0) is reported in the status byte, like the
 // ValueError of `pow(a, -1, M)`.
 #pragma once
 #include "mx_lanes.hpp"
@@ -84,6 +85,27 @@ struct WaveInt {
     for (int j = LPL - 1; j > 0; --j) x[j] = __builtin_amdgcn_alignbit(x[j], x[j - 1], 31);
     x[0] = __builtin_amdgcn_alignbit(x[0], prev, 31);
   }
+  // the same by 1 .. 31 bits
+  __device__ __forceinline__ void shr(int n) {
+    const u32 next = dpp_mov<DPP_WAVE_SHL1, 0xF, 0xF, true>(0, x[0]);
+#pragma unroll
+    for (int j = 0; j < LPL - 1; ++j) x[j] = __builtin_amdgcn_alignbit(x[j + 1], x[j], (u32)n);
+    x[LPL - 1] = __builtin_amdgcn_alignbit(next, x[LPL - 1], (u32)n);
+  }
+  __device__ __forceinline__ void shl(int n) {
+    const u32 prev = dpp_mov<DPP_WAVE_SHR1, 0xF, 0xF, true>(0, x[LPL - 1]);
+    const u32 inv = 32u - (u32)n;
+#pragma unroll
+    for (int j = LPL - 1; j > 0; --j) x[j] = __builtin_amdgcn_alignbit(x[j], x[j - 1], inv);
+    x[0] = __builtin_amdgcn_alignbit(x[0], prev, inv);
+  }
+  // by one whole word
+  __device__ __forceinline__ void shr_word() {
+    const u32 next = dpp_mov<DPP_WAVE_SHL1, 0xF, 0xF, true>(0, x[0]);
+#pragma unroll
+    for (int j = 0; j < LPL - 1; ++j) x[j] = x[j + 1];
+    x[LPL - 1] = next;
+  }
   // carries between lanes from the generate / propagate ballots
   static __device__ __forceinline__ bool carry_in(bool g, bool p) {
     const unsigned long long G = __ballot(g), P = __ballot(p);
@@ -120,6 +142,22 @@ struct WaveInt {
       for (int j = 0; j < LPL; ++j) { const u32 old = x[j]; x[j] = old - k; k = (old == 0u) ? k : 0u; }
     }
   }
+  // this += q * y for a one-word q: lane-local multiply-accumulate chains, the carry WORD of every lane added to the next
+  // lane's first limb (the ripple of that addition through the ballots, as in add).  The sum must fit the 64 * LPL words.
+  __device__ __forceinline__ void add_mul(const WaveInt& y, u32 q) {
+    u32 c = 0;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      const u64 t = (u64)x[j] + (u64)q * y.x[j] + c;
+      x[j] = (u32)t;
+      c = (u32)(t >> 32);
+    }
+    WaveInt w;
+#pragma unroll
+    for (int j = 1; j < LPL; ++j) w.x[j] = 0;
+    w.x[0] = dpp_mov<DPP_WAVE_SHR1, 0xF, 0xF, true>(0, c);                   // lane l <- lane l-1, lane 0 <- 0
+    add(w);
+  }
   // this > y
   __device__ __forceinline__ bool gt(const WaveInt& y) const {
     int s = 0;
@@ -141,20 +179,46 @@ __global__ void __launch_bounds__(64) modinv_kernel(ModinvArgs A) {
   s.set_small(1);
   int k = 0;
   const int bound = 64 * A.limbs + 8;            // k <= 2 * bits(M)
-  while (k < bound && !v.is_zero()) {
-    if (!(u.low() & 1u)) { u.shr1(); s.shl1(); }
-    else if (!(v.low() & 1u)) { v.shr1(); r.shl1(); }
-    else if (u.gt(v)) { u.sub(v); u.shr1(); r.add(s); s.shl1(); }
-    else { v.sub(u); v.shr1(); s.add(r); r.shl1(); }
-    ++k;
+  // (A subtraction leaves an even number: all its trailing zero bits — two on average — go in the same trip as the
+  // subtraction, one variable shift each for the halved and the doubled number, instead of a trip of the loop per bit; the
+  // sequence of Kaliski's steps, and k, are the same.  A wavefront alone on its SIMD issues an instruction every five cycles
+  // whatever it is: the trips saved were a third of this kernel's 2.1 ms at 4102 bits.)
+  auto zeros = [](u32 low) -> int { return low ? __builtin_ctz(low) : 31; };     // (a zero low word: 31 now, the rest next trip)
+  bool vzero = v.is_zero();                      // (v reaches zero only through v - u with v = u: looked at there)
+  while (k < bound && !vzero) {
+    const u32 ul = u.low(), vl = v.low();
+    int n;
+    if (!(ul & 1u)) { n = zeros(ul); u.shr(n); s.shl(n); }
+    else if (!(vl & 1u)) { n = zeros(vl); v.shr(n); r.shl(n); }
+    else if (u.gt(v)) { u.sub(v); r.add(s); n = zeros(u.low()); u.shr(n); s.shl(n); }          // (u - v > 0: never all zero)
+    else {
+      v.sub(u); s.add(r);
+      const u32 low = v.low();
+      n = 31;
+      if (low) n = __builtin_ctz(low);
+      else if (v.is_zero()) { vzero = true; n = 1; }                           // v = u: the one halving step Kaliski's loop ends on
+      v.shr(n); r.shl(n);
+    }
+    k += n;
   }
-  const bool ok = v.is_zero() && u.is_one();
+  const bool ok = vzero && u.is_one();
   if (!m.gt(r)) r.sub(m);                        // r < 2M  ->  r mod M
   WI x = m;
   x.sub(r);                                      // a^-1 * 2^k mod M
-  for (int i = 0; i < k; ++i) {
-    if (x.low() & 1u) x.add(m);
-    x.shr1();
+  // k halvings modulo M, a word at a time: x <- (x + q M) / 2^32 with q = -x M^-1 mod 2^32 (the low word becomes zero; the
+  // value stays below M), then the k mod 32 bits that are left the same way.  (Bit by bit this was a fifth of the kernel.)
+  u32 minv = m.low();                            // Newton: M^-1 mod 2^32 (M odd)
+#pragma unroll
+  for (int i = 0; i < 4; ++i) minv *= 2u - m.low() * minv;
+  const u32 nminv = 0u - minv;
+  int left = k;
+  for (; left >= 32; left -= 32) {
+    x.add_mul(m, x.low() * nminv);
+    x.shr_word();
+  }
+  if (left > 0) {
+    x.add_mul(m, (x.low() * nminv) & ((1u << left) - 1u));
+    x.shr(left);
   }
   if (!ok) x.set_small(0);
   x.store(A.out + e * A.limbs, A.limbs);
