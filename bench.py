@@ -654,6 +654,21 @@ def leg_latency(eng, torch, wl: DecryptWorkload, single_core_rate) -> dict:
         geo = eng.nsquare_launch_shape(wl.n.bit_length(), count)
         out[f"n{count}"] = {"ms": times[len(times) // 2] * 1e3, "best_ms": times[0] * 1e3, "geometry_K_L_W_blocks": list(geo[:4]),
                             "wavefronts_per_group": geo[4], "ciphertexts_per_s": count / times[len(times) // 2]}
+    # the same lone call by a party whose Lagrange exponent is negative (two of three parties at t = 1): PSK:89-91 inverts
+    # the ciphertext modulo N^2 first — one more kernel, a host look at its status byte, then the exponentiation
+    neg = next((i for i in wl.parties if wl.exps[i] < 0), None)
+    if neg is not None:
+        gk2 = GpuPaillierSharedKey(key.n, key.t, neg, ShareView(dict(key.shares), key.degree, key.n_fac), key.theta, engine=eng)
+        ct = PlainCiphertext(wl.cts[0], key.n)
+        times = []
+        for rep in range(6):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            got2 = gk2.partial_decrypt(ct)
+            times.append(time.perf_counter() - t0)
+        assert got2 == pow(pow(wl.cts[0], -1, wl.n2), -wl.exps[neg], wl.n2)
+        times = sorted(times[1:])
+        out["n1_negative_exponent"] = {"ms": times[len(times) // 2] * 1e3, "best_ms": times[0] * 1e3, "party": neg}
     eng.set_limbs_per_lane(saved[0])
     eng.set_wavefronts_per_group(saved[1])
     out["value"] = out["n1"]["ms"]
@@ -1577,7 +1592,7 @@ def main() -> None:
                         if cpu:
                             # the lone call at this key length (decrypt() of ONE ciphertext, 64, 1024), as leg `latency` at 2048
                             lat = leg_latency(eng, torch, c5wl, (c5.get("cpu_baseline") or {}).get("single_core_value"))
-                            c5["latency"] = {k: lat[k] for k in ("unit", "n1", "n64", "n1024", "gmpy2_one_core_ms", "vs_gmpy2_one_core") if k in lat}
+                            c5["latency"] = {k: lat[k] for k in ("unit", "n1", "n1_negative_exponent", "n64", "n1024", "gmpy2_one_core_ms", "vs_gmpy2_one_core") if k in lat}
                         del c5wl
                         torch.cuda.empty_cache()
                         return {k: c5[k] for k in ("metric", "value", "unit", "steps", "ms_per_step", "config", "roofline", "cpu_baseline", "latency") if k in c5}
