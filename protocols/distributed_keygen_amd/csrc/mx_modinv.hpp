@@ -160,10 +160,16 @@ struct WaveInt {
   }
   // this > y
   __device__ __forceinline__ bool gt(const WaveInt& y) const {
-    int s = 0;
+    // per lane through one borrow chain (this lane's limbs as one number: borrow out = less, all-zero difference = equal; a
+    // limb-by-limb select chain was thirty instructions with its wait states), the lanes' verdicts compared as 64-bit integers
+    u32 b = 0, any = 0;
 #pragma unroll
-    for (int j = LPL - 1; j >= 0; --j) s = (s != 0) ? s : (x[j] > y.x[j] ? 1 : (x[j] < y.x[j] ? -1 : 0));
-    return __ballot(s > 0) > __ballot(s < 0);
+    for (int j = 0; j < LPL; ++j) {
+      const u64 t = (u64)x[j] - y.x[j] - b;
+      b = (u32)(t >> 63);
+      any |= (u32)t;
+    }
+    return __ballot(b == 0 && any != 0) > __ballot(b != 0);
   }
 };
 
