@@ -142,6 +142,42 @@ struct WaveInt {
       for (int j = 0; j < LPL; ++j) { const u32 old = x[j]; x[j] = old - k; k = (old == 0u) ? k : 0u; }
     }
   }
+  // ---- the pieces of add / sub apart, for a trip of the main loop that runs several of them side by side: the lane-local
+  // chain (result words, carry / borrow out of the lane, "all ones" / "all zero" of the lane's words), the ripple between the
+  // lanes from the two ballots, and the lane's own +1 / -1
+  static __device__ __forceinline__ void add_local(u32 (&w)[LPL], const WaveInt& a, const WaveInt& b, u32& carry, u32& all) {
+    u32 c = 0, al = 0xFFFFFFFFu;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      const u64 t = (u64)a.x[j] + b.x[j] + c;
+      w[j] = (u32)t;
+      c = (u32)(t >> 32);
+      al &= w[j];
+    }
+    carry = c; all = al;
+  }
+  static __device__ __forceinline__ void sub_local(u32 (&w)[LPL], const WaveInt& a, const WaveInt& b, u32& borrow, u32& any) {
+    u32 bo = 0, an = 0;
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) {
+      const u64 t = (u64)a.x[j] - b.x[j] - bo;
+      w[j] = (u32)t;
+      bo = (u32)(t >> 63);
+      an |= w[j];
+    }
+    borrow = bo; any = an;
+  }
+  static __device__ __forceinline__ unsigned long long ripple(unsigned long long G, unsigned long long P) { return (P + (G << 1)) ^ P; }
+  __device__ __forceinline__ void take_plus(const u32 (&w)[LPL], unsigned long long cin) {
+    u32 k = (u32)((cin >> lane()) & 1ull);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) { x[j] = w[j] + k; k = (x[j] == 0u) ? k : 0u; }
+  }
+  __device__ __forceinline__ void take_minus(const u32 (&w)[LPL], unsigned long long cin) {
+    u32 k = (u32)((cin >> lane()) & 1ull);
+#pragma unroll
+    for (int j = 0; j < LPL; ++j) { const u32 old = w[j]; x[j] = old - k; k = (old == 0u) ? k : 0u; }
+  }
   // this += q * y for a one-word q: lane-local multiply-accumulate chains, the carry WORD of every lane added to the next
   // lane's first limb (the ripple of that addition through the ballots, as in add).  The sum must fit the 64 * LPL words.
   __device__ __forceinline__ void add_mul(const WaveInt& y, u32 q) {
@@ -196,14 +232,31 @@ __global__ void __launch_bounds__(64) modinv_kernel(ModinvArgs A) {
     int n;
     if (!(ul & 1u)) { n = zeros(ul); u.shr(n); s.shl(n); }
     else if (!(vl & 1u)) { n = zeros(vl); v.shr(n); r.shl(n); }
-    else if (u.gt(v)) { u.sub(v); r.add(s); n = zeros(u.low()); u.shr(n); s.shl(n); }          // (u - v > 0: never all zero)
     else {
-      v.sub(u); s.add(r);
-      const u32 low = v.low();
-      n = 31;
-      if (low) n = __builtin_ctz(low);
-      else if (v.is_zero()) { vzero = true; n = 1; }                           // v = u: the one halving step Kaliski's loop ends on
-      v.shr(n); r.shl(n);
+      // both odd: u - v, v - u and r + s lane by lane SIDE BY SIDE, their six ballots, the three ripples — then the difference
+      // that is not negative and the sum are taken.  (One after the other — compare, subtract, add — every one of them was a
+      // round trip vector -> scalar -> vector of its own, and a wavefront alone on its SIMD has nothing to put into those.)
+      u32 duv[LPL], dvu[LPL], sm[LPL], b1, z1, b2, z2, c3, a3;
+      WI::sub_local(duv, u, v, b1, z1);
+      WI::sub_local(dvu, v, u, b2, z2);
+      WI::add_local(sm, r, s, c3, a3);
+      const unsigned long long G1 = __ballot(b1 != 0), Z1 = __ballot(z1 == 0u), G2 = __ballot(b2 != 0), Z2 = __ballot(z2 == 0u);
+      const unsigned long long G3 = __ballot(c3 != 0), P3 = __ballot(a3 == 0xFFFFFFFFu);
+      const unsigned long long cin1 = WI::ripple(G1, Z1), cin2 = WI::ripple(G2, Z2), cin3 = WI::ripple(G3, P3);
+      const bool u_less = (((G1 >> 63) | ((Z1 >> 63) & (cin1 >> 63))) & 1ull) != 0;        // the borrow out of the top lane
+      const bool equal = !u_less && Z1 == ~0ull;
+      if (!u_less && !equal) {                                                 // u > v
+        u.take_minus(duv, cin1);
+        r.take_plus(sm, cin3);
+        n = zeros(u.low());                                                    // (u - v > 0: never all zero)
+        u.shr(n); s.shl(n);
+      } else {
+        v.take_minus(dvu, cin2);
+        s.take_plus(sm, cin3);
+        n = zeros(v.low());
+        if (equal) { vzero = true; n = 1; }                                    // v = u: the one halving step Kaliski's loop ends on
+        v.shr(n); r.shl(n);
+      }
     }
     k += n;
   }
