@@ -219,13 +219,22 @@ struct BiHi {
       asm volatile("" : "+v"(one));
       asm volatile("" : "+v"(one2));
     };
-    int i = pd + 2;
+    // The chain opens at limb Pd (round 6): the multiplier limbs at Pd + 1 and Pd + 2 are zero in every row this kernel
+    // multiplies by (a product leaves at most 2 at Pd and nothing above it, the converted base is below 2 N;
+    // tools/bimont_model.py asserts it), so the two steps that would run on an empty accumulator are left out.
+    int i = pd - 1;
     // three blocks (nine limb steps) per trip — the loop control and address arithmetic of a one-block trip are a fifth of
     // its instructions —, the next trip's multiplier limbs fetched behind this trip's work
-    if (i - 8 >= h_lo) {
-      u32 nb[9];
+    const bool trips = i - 8 >= h_lo;
+    u32 nb[9];
+    const u32 btop = B[pd];
+    if (trips) {
 #pragma unroll
       for (int k = 0; k < 9; ++k) nb[k] = B[i - k];
+    }
+    opaque();
+    step<SQ, 0>(t, al, rl, one, one2, btop);
+    if (trips) {
       for (; i - 8 >= h_lo; i -= 9) {
         opaque();
         u32 b[9];

@@ -150,7 +150,10 @@ def half_hi_and_sum(geo: Geometry, cst: Constants, a, B, t_lo, square: bool, tra
         assert rf[p] == [0, 0, 0]
     t = [[0] * L for _ in range(K)]
     vmax = cymax = 0
-    for i in range(Pd + L - 1, geo.h_lo - 1, -1):
+    # (the limbs at Pd + 1 and Pd + 2 of every multiplier row are zero: the two steps that would open the chain on an empty
+    # accumulator are not run)
+    assert all(x == 0 for x in B[Pd + 1:]), "a multiplier limb above Pd"
+    for i in range(Pd, geo.h_lo - 1, -1):
         bi = B[i] if i < len(B) else 0
         out = [t[p][0] for p in range(K)]
         v = out[0]
